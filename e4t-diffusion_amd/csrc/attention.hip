@@ -1,0 +1,444 @@
+// Fused multi-head attention  O = softmax(Q K^T * scale) V  — forward and backward — for gfx950.
+//
+// Replaces the reference's SDPA / baddbmm+softmax+bmm / xFormers processors
+// (e4t/models/cross_attention.py:521-531, 222-251 + 313-314, 473-481) and the open_clip ViT's
+// nn.MultiheadAttention core.  No (T x S) score matrix is ever written to HBM.
+//
+// Layout: Q, K, V, O, dO, dQ, dK, dV are the projection GEMMs' outputs as they are:
+// row-major (B*T, heads*DH) bf16 with an arbitrary row stride; head h is the column slice
+// [h*DH, (h+1)*DH).  No head split / merge permutes exist anywhere.
+//
+// MFMA mapping (v_mfma_f32_32x32x16_bf16, K = 16 so DH = 40/80/160/64 pad to 48/80/160/64 only):
+//   forward, one wave = 32 queries:   S^T[key][q] = K . Q^T   (A = K tile from LDS, B = Q in registers)
+//     -> every lane owns ONE query column (q = lane & 31) and 16 of the 32 keys in registers, so the
+//        row max / row sum are 16 in-register ops + one cross-half exchange, and m, l are per-lane scalars;
+//     O^T[d][q] += V^T . P^T   (A = V^T tile from LDS, B = P^T straight from the S^T accumulator registers)
+//     -> the S^T accumulator layout IS the B-operand layout once the 32 keys of a sub-tile are
+//        enumerated in the order the accumulator holds them; V^T is read from LDS in that same order,
+//        so P never goes through LDS or a cross-lane shuffle.  O^T keeps q in the lane: rescale is a scalar.
+//   backward dQ: same skeleton (dQ^T[d][q] += K^T . dS^T).
+//   backward dK/dV, one wave = 32 keys: S[q][key] = Q . K^T (key in the lane), dV^T[d][key] += dO^T . P,
+//     dK^T[d][key] += Q^T . dS.   Two kernels (dQ | dK,dV) -> no atomics, bitwise deterministic.
+// Softmax statistics are fp32, exp2 domain (scale * log2 e folded in).  LSE is stored in log2 units.
+#include "common.h"
+#include "../../include/e4t_hip.h"
+#include <math.h>
+
+namespace {
+
+struct AttnArgs {
+  const bf16_t *Q, *K, *V, *dO;
+  const bf16_t* O;
+  bf16_t *Out, *dQ, *dK, *dV;
+  float* L;      // [B][H][T] log2-domain logsumexp
+  float* Delta;  // [B][H][T] rowsum(dO * O)
+  int T, S, H;
+  int ldq, ldk, ldv, ldo;      // row strides (elements)
+  long long bq, bk, bv, bo;    // batch strides (elements)
+  float scale2;                // scale * log2(e)
+  float scale;
+};
+
+template <int DH>
+struct Cfg {
+  static constexpr int DK = (DH + 15) / 16 * 16;  // contraction padding for Q.K^T
+  static constexpr int DV = (DH + 31) / 32 * 32;  // row-tile padding for the transposed accumulators
+  static constexpr int NKS = DK / 16;
+  static constexpr int NDT = DV / 32;
+  static constexpr int KLD = DK + 8;   // LDS row stride (elements) of row-major tiles: 16-B aligned, conflict-free b128
+  static constexpr int TLD = 64 + 4;   // LDS row stride of transposed tiles [d][64 rows]: 8-B aligned, conflict-free b64
+};
+
+union Frag {
+  bf16x8 v;
+  uint4 q;
+  uint2 h[2];
+  uint32_t w[4];
+};
+
+// rows [r0, r0+64) x DH of a row-major global matrix -> lds[64][KLD]; rows >= R and pad columns are zero
+template <int DH>
+__device__ __forceinline__ void stage_rows(const bf16_t* g, int ld, int r0, int R, bf16_t* lds) {
+  constexpr int NCH = Cfg<DH>::DK / 8, KLD = Cfg<DH>::KLD;
+  for (int c = threadIdx.x; c < 64 * NCH; c += 256) {
+    const int row = c / NCH, ch = c - row * NCH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + row < R && ch < DH / 8) v = *(const uint4*)(g + (long long)(r0 + row) * ld + ch * 8);
+    *(uint4*)(lds + row * KLD + ch * 8) = v;
+  }
+}
+// the same rows, transposed: ldsT[d][TLD] with column = row - r0 (rows >= R are zero)
+template <int DH>
+__device__ __forceinline__ void stage_rows_T(const bf16_t* g, int ld, int r0, int R, bf16_t* ldsT) {
+  constexpr int NCH = DH / 8, TLD = Cfg<DH>::TLD;
+  for (int it = threadIdx.x; it < 32 * NCH; it += 256) {
+    const int kp = it / NCH, ch = it - kp * NCH;
+    const int k0 = r0 + 2 * kp;
+    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+    if (k0 < R) v0 = *(const uint4*)(g + (long long)k0 * ld + ch * 8);
+    if (k0 + 1 < R) v1 = *(const uint4*)(g + (long long)(k0 + 1) * ld + ch * 8);
+    const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *(uint32_t*)(ldsT + (ch * 8 + 2 * j) * TLD + 2 * kp) = (a[j] & 0xffffu) | (b[j] << 16);
+      *(uint32_t*)(ldsT + (ch * 8 + 2 * j + 1) * TLD + 2 * kp) = (a[j] >> 16) | (b[j] & 0xffff0000u);
+    }
+  }
+}
+
+// B-operand fragments of a row held in registers: 8 consecutive d starting at ks*16 + hi*8 (zero beyond DH / R)
+template <int DH>
+__device__ __forceinline__ void load_row_frags(const bf16_t* g, int ld, int row, int R, int hi, bf16x8* f) {
+#pragma unroll
+  for (int ks = 0; ks < Cfg<DH>::NKS; ++ks) {
+    Frag t;
+    t.q = make_uint4(0, 0, 0, 0);
+    const int d0 = ks * 16 + hi * 8;
+    if (row < R && d0 < DH) t.q = *(const uint4*)(g + (long long)row * ld + d0);
+    f[ks] = t.v;
+  }
+}
+
+// A-operand from a transposed tile: row d, the 8 slots of MFMA k-step k2 of 32-row sub-tile `sub`:
+// columns sub*32 + k2*16 + 4*hi + {0..3} and + 8 + {0..3}  (= the order the 32x32 accumulator holds its rows)
+__device__ __forceinline__ bf16x8 load_T_frag(const bf16_t* ldsT, int TLD, int d, int sub, int k2, int hi) {
+  Frag t;
+  const bf16_t* p = ldsT + d * TLD + sub * 32 + k2 * 16 + 4 * hi;
+  t.h[0] = *(const uint2*)p;
+  t.h[1] = *(const uint2*)(p + 8);
+  return t.v;
+}
+// accumulator registers [8*k2, 8*k2+8) -> bf16 B-operand
+__device__ __forceinline__ bf16x8 pack_acc(const float* p, int k2) {
+  Frag t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t.w[j] = pack2bf(p[8 * k2 + 2 * j], p[8 * k2 + 2 * j + 1]);
+  return t.v;
+}
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// transposed accumulator [d][row] -> global[row][d] (bf16), 4 consecutive d per 8-byte store
+template <int DH>
+__device__ __forceinline__ void store_T_acc(const f32x16* acc, float mul, bf16_t* g, int ld, int row, int R, int hi) {
+  if (row >= R) return;
+#pragma unroll
+  for (int dt = 0; dt < Cfg<DH>::NDT; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = dt * 32 + 8 * rg + 4 * hi;
+      if (d < DH) {
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = acc[dt][rg * 4 + j] * mul;
+        *(uint2*)(g + (long long)row * ld + d) = pack4(f);
+      }
+    }
+}
+
+// ================================================================================================
+// forward
+// ================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  using C = Cfg<DH>;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[C::DV * C::TLD];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int q = blockIdx.x * 128 + wave * 32 + li;
+  const bf16_t* Qb = p.Q + b * p.bq + h * DH;
+  const bf16_t* Kb = p.K + b * p.bk + h * DH;
+  const bf16_t* Vb = p.V + b * p.bv + h * DH;
+
+  bf16x8 qf[C::NKS];
+  load_row_frags<DH>(Qb, p.ldq, q, p.T, hi, qf);
+
+  f32x16 o[C::NDT];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  for (int kv0 = 0; kv0 < p.S; kv0 += 64) {
+    __syncthreads();
+    stage_rows<DH>(Kb, p.ldk, kv0, p.S, Ks);
+    stage_rows_T<DH>(Vb, p.ldv, kv0, p.S, Vt);
+    __syncthreads();
+    const int nsub = (p.S - kv0 > 32) ? 2 : 1;
+    for (int sub = 0; sub < nsub; ++sub) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < C::NKS; ++ks) {
+        const bf16x8 a = *(const bf16x8*)(Ks + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
+      }
+      float pr[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + sub * 32 + acc_row(r, hi);
+        pr[r] = key < p.S ? s[r] * p.scale2 : -INFINITY;
+        mx = fmaxf(mx, pr[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = exp2f(m - mn);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pr[r] = exp2f(pr[r] - mn); rs += pr[r]; }
+      rs += __shfl_xor(rs, 32, 64);
+      l = l * alpha + rs;
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) {
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Vt, C::TLD, dt * 32 + li, sub, 0, hi), pf0, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Vt, C::TLD, dt * 32 + li, sub, 1, hi), pf1, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  const float inv = 1.f / l;
+  store_T_acc<DH>(o, inv, p.Out + b * p.bo + h * DH, p.ldo, q, p.T, hi);
+  if (p.L && hi == 0 && q < p.T) p.L[((long long)b * p.H + h) * p.T + q] = m + log2f(l);
+}
+
+// ================================================================================================
+// backward: Delta[b][h][q] = sum_d dO * O
+// ================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p, int Bn) {
+  const long long total = (long long)Bn * p.H * p.T;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int q = (int)(i % p.T); const long long t = i / p.T; const int h = (int)(t % p.H); const int b = (int)(t / p.H);
+    const bf16_t* o = p.O + b * p.bo + (long long)q * p.ldo + h * DH;
+    const bf16_t* d = p.dO + b * p.bo + (long long)q * p.ldo + h * DH;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < DH / 8; ++c) {
+      float a[8], g[8];
+      unpack8(*(const uint4*)(o + c * 8), a);
+      unpack8(*(const uint4*)(d + c * 8), g);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += a[k] * g[k];
+    }
+    p.Delta[i] = s;
+  }
+}
+
+// ================================================================================================
+// backward dQ: one wave = 32 queries, loop over key tiles
+// ================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+  using C = Cfg<DH>;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * C::KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Kt[C::DV * C::TLD];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int q = blockIdx.x * 128 + wave * 32 + li;
+  const bf16_t* Kb = p.K + b * p.bk + h * DH;
+  const bf16_t* Vb = p.V + b * p.bv + h * DH;
+
+  bf16x8 qf[C::NKS], dof[C::NKS];
+  load_row_frags<DH>(p.Q + b * p.bq + h * DH, p.ldq, q, p.T, hi, qf);
+  load_row_frags<DH>(p.dO + b * p.bo + h * DH, p.ldo, q, p.T, hi, dof);
+  float Lq = 0.f, Dq = 0.f;
+  if (q < p.T) { Lq = p.L[((long long)b * p.H + h) * p.T + q]; Dq = p.Delta[((long long)b * p.H + h) * p.T + q]; }
+
+  f32x16 acc[C::NDT];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+
+  for (int kv0 = 0; kv0 < p.S; kv0 += 64) {
+    __syncthreads();
+    stage_rows<DH>(Kb, p.ldk, kv0, p.S, Ks);
+    stage_rows<DH>(Vb, p.ldv, kv0, p.S, Vs);
+    stage_rows_T<DH>(Kb, p.ldk, kv0, p.S, Kt);
+    __syncthreads();
+    const int nsub = (p.S - kv0 > 32) ? 2 : 1;
+    for (int sub = 0; sub < nsub; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < C::NKS; ++ks) {
+        const bf16x8 a = *(const bf16x8*)(Ks + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
+        const bf16x8 a2 = *(const bf16x8*)(Vs + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dof[ks], dp, 0, 0, 0);
+      }
+      float ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kv0 + sub * 32 + acc_row(r, hi);
+        const float pv = key < p.S ? exp2f(s[r] * p.scale2 - Lq) : 0.f;
+        ds[r] = pv * (dp[r] - Dq);
+      }
+      const bf16x8 f0 = pack_acc(ds, 0), f1 = pack_acc(ds, 1);
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) {
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Kt, C::TLD, dt * 32 + li, sub, 0, hi), f0, acc[dt], 0, 0, 0);
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Kt, C::TLD, dt * 32 + li, sub, 1, hi), f1, acc[dt], 0, 0, 0);
+      }
+    }
+  }
+  store_T_acc<DH>(acc, p.scale, p.dQ + b * p.bq + h * DH, p.ldq, q, p.T, hi);
+}
+
+// ================================================================================================
+// backward dK, dV: one wave = 32 keys, loop over query tiles
+// ================================================================================================
+template <int DH>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+  using C = Cfg<DH>;
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * C::KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * C::KLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Qt[C::DV * C::TLD];
+  __shared__ __attribute__((aligned(16))) bf16_t dOt[C::DV * C::TLD];
+  __shared__ float Ls[64], Dls[64];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int key = blockIdx.x * 128 + wave * 32 + li;
+  const bf16_t* Qb = p.Q + b * p.bq + h * DH;
+  const bf16_t* dOb = p.dO + b * p.bo + h * DH;
+
+  bf16x8 kf[C::NKS], vf[C::NKS];
+  load_row_frags<DH>(p.K + b * p.bk + h * DH, p.ldk, key, p.S, hi, kf);
+  load_row_frags<DH>(p.V + b * p.bv + h * DH, p.ldv, key, p.S, hi, vf);
+
+  f32x16 dvt[C::NDT], dkt[C::NDT];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dvt[dt][r] = 0.f; dkt[dt][r] = 0.f; }
+
+  for (int q0 = 0; q0 < p.T; q0 += 64) {
+    __syncthreads();
+    stage_rows<DH>(Qb, p.ldq, q0, p.T, Qs);
+    stage_rows<DH>(dOb, p.ldo, q0, p.T, dOs);
+    stage_rows_T<DH>(Qb, p.ldq, q0, p.T, Qt);
+    stage_rows_T<DH>(dOb, p.ldo, q0, p.T, dOt);
+    if (threadIdx.x < 64) {
+      const int qq = q0 + threadIdx.x;
+      Ls[threadIdx.x] = qq < p.T ? p.L[((long long)b * p.H + h) * p.T + qq] : 0.f;
+      Dls[threadIdx.x] = qq < p.T ? p.Delta[((long long)b * p.H + h) * p.T + qq] : 0.f;
+    }
+    __syncthreads();
+    const int nsub = (p.T - q0 > 32) ? 2 : 1;
+    for (int sub = 0; sub < nsub; ++sub) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < C::NKS; ++ks) {
+        const bf16x8 a = *(const bf16x8*)(Qs + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s, 0, 0, 0);
+        const bf16x8 a2 = *(const bf16x8*)(dOs + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vf[ks], dp, 0, 0, 0);
+      }
+      float pr[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = sub * 32 + acc_row(r, hi);
+        const bool ok = (q0 + ql < p.T) && (key < p.S);
+        pr[r] = ok ? exp2f(s[r] * p.scale2 - Ls[ql]) : 0.f;
+        ds[r] = pr[r] * (dp[r] - Dls[ql]);
+      }
+      const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);
+      const bf16x8 sf0 = pack_acc(ds, 0), sf1 = pack_acc(ds, 1);
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) {
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(dOt, C::TLD, dt * 32 + li, sub, 0, hi), pf0, dvt[dt], 0, 0, 0);
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(dOt, C::TLD, dt * 32 + li, sub, 1, hi), pf1, dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Qt, C::TLD, dt * 32 + li, sub, 0, hi), sf0, dkt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Qt, C::TLD, dt * 32 + li, sub, 1, hi), sf1, dkt[dt], 0, 0, 0);
+      }
+    }
+  }
+  store_T_acc<DH>(dvt, 1.f, p.dV + b * p.bv + h * DH, p.ldv, key, p.S, hi);
+  store_T_acc<DH>(dkt, p.scale, p.dK + b * p.bk + h * DH, p.ldk, key, p.S, hi);
+}
+
+template <int DH>
+int launch_fwd(const AttnArgs& p, int Bn, hipStream_t st) {
+  hipLaunchKernelGGL((attn_fwd_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
+  E4T_CHECK_LAUNCH("attn_fwd_kernel");
+  return 0;
+}
+template <int DH>
+int launch_bwd(const AttnArgs& p, int Bn, hipStream_t st) {
+  const long long total = (long long)Bn * p.H * p.T;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((attn_delta_kernel<DH>), dim3(blocks), dim3(256), 0, st, p, Bn);
+  E4T_CHECK_LAUNCH("attn_delta_kernel");
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH>), dim3(cdiv(p.S, 128), p.H, Bn), dim3(256), 0, st, p);
+  E4T_CHECK_LAUNCH("attn_bwd_dkv_kernel");
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
+  E4T_CHECK_LAUNCH("attn_bwd_dq_kernel");
+  return 0;
+}
+
+int check_common(int Bn, int H, int T, int S, int DH, int ldq, int ldk, int ldv, int ldo) {
+  E4T_REQUIRE(Bn > 0 && H > 0 && T > 0 && S > 0, "attention: bad shape B=%d H=%d T=%d S=%d", Bn, H, T, S);
+  E4T_REQUIRE(DH == 40 || DH == 64 || DH == 80 || DH == 160 || DH == 32, "attention: head dim %d not built (32/40/64/80/160)", DH);
+  E4T_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, "attention: row strides must be multiples of 8");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int e4t_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int Bn, int H, int T, int S,
+                                 int DH, int ldq, int ldk, int ldv, int ldo, long long bq, long long bk, long long bv,
+                                 long long bo, float scale, e4t_stream stream) {
+  if (int e = check_common(Bn, H, T, S, DH, ldq, ldk, ldv, ldo)) return e;
+  E4T_REQUIRE(Q && K && V && O, "attention_fwd: null operand");
+  AttnArgs p;
+  memset(&p, 0, sizeof(p));
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Out = (bf16_t*)O; p.L = lse;
+  p.T = T; p.S = S; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.bq = bq; p.bk = bk; p.bv = bv; p.bo = bo;
+  p.scale = scale; p.scale2 = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  switch (DH) {
+    case 32: return launch_fwd<32>(p, Bn, st);
+    case 40: return launch_fwd<40>(p, Bn, st);
+    case 64: return launch_fwd<64>(p, Bn, st);
+    case 80: return launch_fwd<80>(p, Bn, st);
+    default: return launch_fwd<160>(p, Bn, st);
+  }
+}
+
+extern "C" int e4t_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                                 float* delta_ws, void* dQ, void* dK, void* dV, int Bn, int H, int T, int S, int DH, int ldq,
+                                 int ldk, int ldv, int ldo, long long bq, long long bk, long long bv, long long bo, float scale,
+                                 e4t_stream stream) {
+  if (int e = check_common(Bn, H, T, S, DH, ldq, ldk, ldv, ldo)) return e;
+  E4T_REQUIRE(Q && K && V && O && dO && lse && delta_ws && dQ && dK && dV, "attention_bwd: null operand");
+  AttnArgs p;
+  memset(&p, 0, sizeof(p));
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (const bf16_t*)O; p.dO = (const bf16_t*)dO;
+  p.L = (float*)lse; p.Delta = delta_ws; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
+  p.T = T; p.S = S; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.bq = bq; p.bk = bk; p.bv = bv; p.bo = bo;
+  p.scale = scale; p.scale2 = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  switch (DH) {
+    case 32: return launch_bwd<32>(p, Bn, st);
+    case 40: return launch_bwd<40>(p, Bn, st);
+    case 64: return launch_bwd<64>(p, Bn, st);
+    case 80: return launch_bwd<80>(p, Bn, st);
+    default: return launch_bwd<160>(p, Bn, st);
+  }
+}

@@ -1,0 +1,349 @@
+// Streaming (HBM-bound) helper kernels on NHWC bf16 activations: GEGLU, SiLU, transposes, weight
+// relayout, 2x2 sum-pool (upsample backward), spatial mean (E4T UNet-feature pooling), sinusoidal
+// timestep embedding, bicubic resize + CLIP normalisation + patchify, fused AdamW.
+// All use 8/16-byte vector accesses with consecutive lanes on consecutive addresses.
+#include "common.h"
+#include "../../include/e4t_hip.h"
+
+namespace {
+
+// ---- GEGLU: h[m][j] = u[m][j] * gelu(u[m][H + j]),  u = proj(x) of width 2H  (attention.py:428-430) ----
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* u, bf16_t* h, long long M, int H) {
+  const int hc = H >> 3;
+  const long long total = M * hc;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / hc; const int j = (int)(i - m * hc) * 8;
+    float a[8], g[8];
+    unpack8(*(const uint4*)(u + m * 2 * H + j), a);
+    unpack8(*(const uint4*)(u + m * 2 * H + H + j), g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] *= gelu_f(g[k]);
+    *(uint4*)(h + m * H + j) = pack8(a);
+  }
+}
+// du[m][j] = dh * gelu(g) ; du[m][H+j] = dh * a * gelu'(g)
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* u, const bf16_t* dh, bf16_t* du, long long M, int H) {
+  const int hc = H >> 3;
+  const long long total = M * hc;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / hc; const int j = (int)(i - m * hc) * 8;
+    float a[8], g[8], d[8], oa[8], og[8];
+    unpack8(*(const uint4*)(u + m * 2 * H + j), a);
+    unpack8(*(const uint4*)(u + m * 2 * H + H + j), g);
+    unpack8(*(const uint4*)(dh + m * H + j), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { oa[k] = d[k] * gelu_f(g[k]); og[k] = d[k] * a[k] * dgelu_f(g[k]); }
+    *(uint4*)(du + m * 2 * H + j) = pack8(oa);
+    *(uint4*)(du + m * 2 * H + H + j) = pack8(og);
+  }
+}
+
+// ---- unary: op 0 = silu, 1 = silu backward (dy, x) , 2 = gelu, 3 = gelu backward, 4 = leaky_relu(0.01), 5 = its backward ----
+__global__ __launch_bounds__(256) void unary_kernel(const bf16_t* x, const bf16_t* dy, bf16_t* y, long long n8, int op) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float f[8], d[8];
+    unpack8(*(const uint4*)(x + i * 8), f);
+    if (dy) unpack8(*(const uint4*)(dy + i * 8), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      switch (op) {
+        case 0: f[k] = silu_f(f[k]); break;
+        case 1: f[k] = d[k] * dsilu_f(f[k]); break;
+        case 2: f[k] = gelu_f(f[k]); break;
+        case 3: f[k] = d[k] * dgelu_f(f[k]); break;
+        case 4: f[k] = f[k] > 0.f ? f[k] : 0.01f * f[k]; break;
+        default: f[k] = f[k] > 0.f ? d[k] : 0.01f * d[k]; break;
+      }
+    }
+    *(uint4*)(y + i * 8) = pack8(f);
+  }
+}
+
+// ---- out = a + b (bf16), optional fp32 b ----
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, const bf16_t* b, bf16_t* y, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float f[8], g[8];
+    unpack8(*(const uint4*)(a + i * 8), f);
+    unpack8(*(const uint4*)(b + i * 8), g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] += g[k];
+    *(uint4*)(y + i * 8) = pack8(f);
+  }
+}
+
+// ---- batched 2-D transpose of bf16: in[b][R][C] (row stride ldi) -> out[b][C][R] (row stride ldo) ----
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, bf16_t* out, int R, int C, int ldi, int ldo,
+                                                        long long bsi, long long bso) {
+  __shared__ bf16_t tile[64][66];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  in += (long long)b * bsi; out += (long long)b * bso;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int rl = ty * 4 + k, r = r0 + rl, c = c0 + tx * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[rl][tx * 4 + j] = (r < R && c + j < C) ? in[(long long)r * ldi + c + j] : (bf16_t)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cl = ty * 4 + k, c = c0 + cl, r = r0 + tx * 4;
+    if (c < C)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (r + j < R) out[(long long)c * ldo + r + j] = tile[tx * 4 + j][cl];
+  }
+}
+
+// ---- conv weight relayout: OIHW fp32 -> fwd [O][ky][kx][Ipad] bf16 and dgrad [I][2-ky][2-kx][Opad] bf16 ----
+__global__ __launch_bounds__(256) void conv_weight_kernel(const float* w, bf16_t* wf, bf16_t* wd, int O, int I, int Ipad, int Opad) {
+  const long long nf = (long long)O * 9 * Ipad, nd = (long long)I * 9 * Opad;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < nf + nd; idx += (long long)gridDim.x * 256) {
+    if (idx < nf) {
+      if (!wf) continue;
+      const int i = (int)(idx % Ipad); const long long t = idx / Ipad;
+      const int tap = (int)(t % 9), o = (int)(t / 9);
+      wf[idx] = i < I ? f2bf(w[((long long)o * I + i) * 9 + tap]) : (bf16_t)0;
+    } else {
+      if (!wd) continue;
+      const long long j = idx - nf;
+      const int o = (int)(j % Opad); const long long t = j / Opad;
+      const int tapd = (int)(t % 9), i = (int)(t / 9);
+      const int tap = 8 - tapd;  // (2-ky)*3 + (2-kx)
+      wd[j] = o < O ? f2bf(w[((long long)o * I + i) * 9 + tap]) : (bf16_t)0;
+    }
+  }
+}
+
+// ---- 2x2 sum pool: out[b][y][x][c] = sum in[b][2y+dy][2x+dx][c]  (backward of nearest x2 upsample) ----
+__global__ __launch_bounds__(256) void sumpool2_kernel(const bf16_t* in, bf16_t* out, int Bn, int H, int W, int C) {
+  const int c8 = C >> 3;
+  const long long total = (long long)Bn * H * W * c8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c8) * 8; long long t = i / c8;
+    const int x = (int)(t % W); t /= W; const int y = (int)(t % H); const int b = (int)(t / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float f[8];
+        unpack8(*(const uint4*)(in + (((long long)b * 2 * H + 2 * y + dy) * 2 * W + 2 * x + dx) * C + c), f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += f[k];
+      }
+    *(uint4*)(out + (((long long)b * H + y) * W + x) * C + c) = pack8(acc);
+  }
+}
+
+// ---- spatial mean: out[b][coff + c] = mean_p x[b][p][c]  (encoder.py:147) ; grid (ceil(C/256), B) ----
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const bf16_t* x, float* out, int HW, int C, int ldo, int coff) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  float s = 0.f;
+  const bf16_t* p = x + (long long)b * HW * C + c;
+  for (int i = 0; i < HW; ++i) s += bf2f(p[(long long)i * C]);
+  out[(long long)b * ldo + coff + c] = s / HW;
+}
+// dx[b][p][c] = (base ? base : 0) + g[b][coff + c] / HW
+__global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float* g, const bf16_t* base, bf16_t* dx, int Bn, int HW, int C, int ldg, int coff) {
+  const int c8 = C >> 3;
+  const long long total = (long long)Bn * HW * c8;
+  const float inv = 1.f / HW;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % c8) * 8; const long long pix = i / c8; const int b = (int)(pix / HW);
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (base) unpack8(*(const uint4*)(base + pix * C + c), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] += g[(long long)b * ldg + coff + c + k] * inv;
+    *(uint4*)(dx + pix * C + c) = pack8(f);
+  }
+}
+
+// ---- sinusoidal timestep embedding [cos | sin] (flip_sin_to_cos=True, freq_shift=0), bf16 out ----
+__global__ void timestep_embed_kernel(const long long* t, bf16_t* out, int Bn, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim >> 1;
+  if (i >= Bn * half) return;
+  const int b = i / half, k = i - b * half;
+  const float freq = __expf(-9.210340371976184f * (float)k / (float)half);
+  const float ang = (float)t[b] * freq;
+  out[(long long)b * dim + k] = f2bf(cosf(ang));
+  out[(long long)b * dim + half + k] = f2bf(sinf(ang));
+}
+
+// ---- bicubic (A=-0.75, align_corners=True) 512->224 + (x+1)/2 + CLIP mean/std + patchify ----
+// in: NCHW fp32 (B,3,Hin,Win) in [-1,1] ; out: bf16 [B*gh*gw][Kpad] with k = (c*P + py)*P + px  (conv1 weight order)
+__device__ __forceinline__ void cubic_w(float t, float* w) {
+  const float A = -0.75f;
+  w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+  w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+  w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+  w[3] = 1.f - w[0] - w[1] - w[2];
+}
+__global__ __launch_bounds__(256) void clip_preprocess_kernel(const float* in, bf16_t* out, int Bn, int Hin, int Win, int S, int P, int Kpad) {
+  const long long total = (long long)Bn * 3 * S * S;
+  const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+  const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+  const int g = S / P;
+  const float sy = S > 1 ? (float)(Hin - 1) / (float)(S - 1) : 0.f, sx = S > 1 ? (float)(Win - 1) / (float)(S - 1) : 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % S); long long t = i / S; const int oy = (int)(t % S); t /= S; const int c = (int)(t % 3); const int b = (int)(t / 3);
+    const float fy = oy * sy, fx = ox * sx;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_w(fy - iy, wy); cubic_w(fx - ix, wx);
+    const float* src = in + ((long long)b * 3 + c) * Hin * Win;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int yy = iy - 1 + a; yy = yy < 0 ? 0 : (yy >= Hin ? Hin - 1 : yy);
+      float r = 0.f;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        int xx = ix - 1 + bb; xx = xx < 0 ? 0 : (xx >= Win ? Win - 1 : xx);
+        r += wx[bb] * src[(long long)yy * Win + xx];
+      }
+      acc += wy[a] * r;
+    }
+    acc = ((acc + 1.f) * 0.5f - mean[c]) / stdv[c];
+    const int py = oy / P, px = ox / P;
+    const long long row = ((long long)b * g + py) * g + px;
+    const int k = (c * P + (oy - py * P)) * P + (ox - px * P);
+    out[row * Kpad + k] = f2bf(acc);
+  }
+}
+
+// ---- fused AdamW over a flat fp32 buffer (torch.optim.AdamW semantics: decoupled weight decay) ----
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      float4 P = *(float4*)(p + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
+      const float4 G = *(const float4*)(g + i);
+      float pp[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
+      const float gg[4] = {G.x * gscale, G.y * gscale, G.z * gscale, G.w * gscale};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pp[k] *= 1.f - lr * wd;
+        mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+        vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+        const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+        pp[k] -= (lr / bc1) * mm[k] / denom;
+      }
+      *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+      *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+      *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    } else {
+      for (long long j = i; j < n; ++j) {
+        float pp = p[j] * (1.f - lr * wd);
+        const float gg = g[j] * gscale;
+        const float mm = b1 * m[j] + (1.f - b1) * gg, vv = b2 * v[j] + (1.f - b2) * gg * gg;
+        pp -= (lr / bc1) * mm / (sqrtf(vv) / bc2_sqrt + eps);
+        p[j] = pp; m[j] = mm; v[j] = vv;
+      }
+    }
+  }
+}
+
+// sum of squares of a flat fp32 buffer -> partial[blockIdx.x]
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long long n, float* partial) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += g[i] * g[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+int grid_for(long long work, int cap = 2048) {
+  long long b = (work + 255) / 256;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" int e4t_geglu_fwd(const void* u, void* h, long long M, int H, e4t_stream s) {
+  E4T_REQUIRE(u && h && M > 0 && H > 0 && H % 8 == 0, "geglu_fwd: bad arguments");
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(M * (H / 8))), dim3(256), 0, (hipStream_t)s, (const bf16_t*)u, (bf16_t*)h, M, H);
+  E4T_CHECK_LAUNCH("geglu_fwd_kernel");
+  return 0;
+}
+extern "C" int e4t_geglu_bwd(const void* u, const void* dh, void* du, long long M, int H, e4t_stream s) {
+  E4T_REQUIRE(u && dh && du && M > 0 && H > 0 && H % 8 == 0, "geglu_bwd: bad arguments");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(M * (H / 8))), dim3(256), 0, (hipStream_t)s, (const bf16_t*)u, (const bf16_t*)dh, (bf16_t*)du, M, H);
+  E4T_CHECK_LAUNCH("geglu_bwd_kernel");
+  return 0;
+}
+extern "C" int e4t_unary(const void* x, const void* dy, void* y, long long n, int op, e4t_stream s) {
+  E4T_REQUIRE(x && y && n > 0 && n % 8 == 0 && op >= 0 && op <= 5, "unary: bad arguments (n %% 8 == 0 required)");
+  E4T_REQUIRE(((op & 1) == 0) || dy, "unary: backward ops need dy");
+  hipLaunchKernelGGL(unary_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)((op & 1) ? dy : nullptr), (bf16_t*)y, n / 8, op);
+  E4T_CHECK_LAUNCH("unary_kernel");
+  return 0;
+}
+extern "C" int e4t_add(const void* a, const void* b, void* y, long long n, e4t_stream s) {
+  E4T_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "add: bad arguments");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n / 8);
+  E4T_CHECK_LAUNCH("add_kernel");
+  return 0;
+}
+extern "C" int e4t_transpose(const void* in, void* out, int batch, int R, int C, int ldi, int ldo, long long bsi, long long bso, e4t_stream s) {
+  E4T_REQUIRE(in && out && batch > 0 && R > 0 && C > 0 && ldi >= C && ldo >= R, "transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 64), cdiv(R, 64), batch), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, (bf16_t*)out, R, C, ldi, ldo, bsi, bso);
+  E4T_CHECK_LAUNCH("transpose_kernel");
+  return 0;
+}
+extern "C" int e4t_conv_weight_prepare(const float* w_oihw, void* w_fwd, void* w_dgrad, int O, int I, int Ipad, int Opad, e4t_stream s) {
+  E4T_REQUIRE(w_oihw && (w_fwd || w_dgrad) && O > 0 && I > 0 && Ipad >= I && Opad >= O, "conv_weight_prepare: bad arguments");
+  const long long n = (long long)O * 9 * Ipad + (long long)I * 9 * Opad;
+  hipLaunchKernelGGL(conv_weight_kernel, dim3(grid_for(n, 4096)), dim3(256), 0, (hipStream_t)s, w_oihw, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, O, I, Ipad, Opad);
+  E4T_CHECK_LAUNCH("conv_weight_kernel");
+  return 0;
+}
+extern "C" int e4t_sumpool2(const void* in, void* out, int Bn, int H, int W, int C, e4t_stream s) {
+  E4T_REQUIRE(in && out && Bn > 0 && H > 0 && W > 0 && C % 8 == 0, "sumpool2: bad arguments");
+  hipLaunchKernelGGL(sumpool2_kernel, dim3(grid_for((long long)Bn * H * W * (C / 8))), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, (bf16_t*)out, Bn, H, W, C);
+  E4T_CHECK_LAUNCH("sumpool2_kernel");
+  return 0;
+}
+extern "C" int e4t_spatial_mean(const void* x, float* out, int Bn, int HW, int C, int ldo, int coff, e4t_stream s) {
+  E4T_REQUIRE(x && out && Bn > 0 && HW > 0 && C > 0, "spatial_mean: bad arguments");
+  hipLaunchKernelGGL(spatial_mean_kernel, dim3(cdiv(C, 256), Bn), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, out, HW, C, ldo, coff);
+  E4T_CHECK_LAUNCH("spatial_mean_kernel");
+  return 0;
+}
+extern "C" int e4t_spatial_mean_bwd(const float* g, const void* base, void* dx, int Bn, int HW, int C, int ldg, int coff, e4t_stream s) {
+  E4T_REQUIRE(g && dx && Bn > 0 && HW > 0 && C % 8 == 0, "spatial_mean_bwd: bad arguments");
+  hipLaunchKernelGGL(spatial_mean_bwd_kernel, dim3(grid_for((long long)Bn * HW * (C / 8))), dim3(256), 0, (hipStream_t)s, g, (const bf16_t*)base, (bf16_t*)dx, Bn, HW, C, ldg, coff);
+  E4T_CHECK_LAUNCH("spatial_mean_bwd_kernel");
+  return 0;
+}
+extern "C" int e4t_timestep_embedding(const long long* t, void* out, int Bn, int dim, e4t_stream s) {
+  E4T_REQUIRE(t && out && Bn > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad arguments");
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(cdiv(Bn * dim / 2, 256)), dim3(256), 0, (hipStream_t)s, t, (bf16_t*)out, Bn, dim);
+  E4T_CHECK_LAUNCH("timestep_embed_kernel");
+  return 0;
+}
+extern "C" int e4t_clip_preprocess(const float* pixels_nchw, void* patches, int Bn, int Hin, int Win, int S, int P, int Kpad, e4t_stream s) {
+  E4T_REQUIRE(pixels_nchw && patches && Bn > 0 && S % P == 0 && Kpad >= 3 * P * P, "clip_preprocess: bad arguments");
+  hipLaunchKernelGGL(clip_preprocess_kernel, dim3(grid_for((long long)Bn * 3 * S * S)), dim3(256), 0, (hipStream_t)s, pixels_nchw, (bf16_t*)patches, Bn, Hin, Win, S, P, Kpad);
+  E4T_CHECK_LAUNCH("clip_preprocess_kernel");
+  return 0;
+}
+extern "C" int e4t_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, float grad_scale, e4t_stream s) {
+  E4T_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
+  E4T_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw: buffers must be 16-B aligned");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  E4T_CHECK_LAUNCH("adamw_kernel");
+  return 0;
+}
+extern "C" int e4t_sumsq_partial(const float* g, long long n, float* partial, int nblocks, e4t_stream s) {
+  E4T_REQUIRE(g && partial && n > 0 && nblocks > 0, "sumsq_partial: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)s, g, n, partial);
+  E4T_CHECK_LAUNCH("sumsq_kernel");
+  return 0;
+}

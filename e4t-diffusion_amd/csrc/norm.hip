@@ -1,0 +1,465 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and backward, on NHWC bf16 activations (gfx950).
+//
+// All of these are HBM-bound streaming kernels: every thread owns fixed channel chunks and walks
+// pixels, so global accesses are 8/16-byte vectors with consecutive lanes on consecutive addresses;
+// statistics are fp32.  GroupNorm accepts the input split over two sources along C — that is how
+// torch.cat([hidden, skip], dim=1) in the up-blocks (e4t/models/unet_2d_blocks.py:1795,1883) is
+// consumed without a concat copy — and its backward writes dX back into two destinations.
+//
+// Reference call sites: [3P diffusers] ResnetBlock2D norm1/norm2 + SiLU (constructed at
+// e4t/models/unet_2d_blocks.py:481,760,881,1732,1855), Transformer2DModel.norm (eps 1e-6,
+// e4t/models/transformer_2d.py:149,253), conv_norm_out (e4t/models/unet_2d_condition.py:275-278,
+// 554-556), nn.LayerNorm in BasicTransformerBlock (e4t/models/attention.py:259,268,273) and in the
+// open_clip ViT (e4t/encoder.py:154).
+#include "common.h"
+#include "../../include/e4t_hip.h"
+
+namespace {
+
+constexpr int GN_MAXQ = 3;  // channel quads (4 ch) per thread: C <= 3*256*4 = 3072
+
+struct GNSrc {
+  const bf16_t* x1; const bf16_t* x2; int C1, C2;
+};
+__device__ __forceinline__ uint2 gn_load4(const GNSrc& s, size_t pix, int c) {
+  if (c < s.C1) return *(const uint2*)(s.x1 + pix * s.C1 + c);
+  return *(const uint2*)(s.x2 + pix * s.C2 + (c - s.C1));
+}
+
+// partial[b][chunk][g][2] = (sum, sumsq) of x over this chunk's pixels and group g's channels
+__global__ __launch_bounds__(256) void gn_stats_kernel(GNSrc s, int HW, int G, int pix_per_chunk, float* partial) {
+  extern __shared__ float lds[];  // [C][2]
+  const int C = s.C1 + s.C2, nq = C >> 2, cpg = C / G;
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int p0 = chunk * pix_per_chunk;
+  int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
+  float sm[GN_MAXQ][4], sq[GN_MAXQ][4];
+#pragma unroll
+  for (int i = 0; i < GN_MAXQ; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm[i][j] = sq[i][j] = 0.f;
+  for (int p = p0; p < p1; ++p) {
+    const size_t pix = (size_t)b * HW + p;
+#pragma unroll
+    for (int i = 0; i < GN_MAXQ; ++i) {
+      const int q = tid + i * 256;
+      if (q < nq) {
+        float f[4];
+        unpack4(gn_load4(s, pix, q * 4), f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sm[i][j] += f[j]; sq[i][j] += f[j] * f[j]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GN_MAXQ; ++i) {
+    const int q = tid + i * 256;
+    if (q < nq)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lds[(q * 4 + j) * 2] = sm[i][j]; lds[(q * 4 + j) * 2 + 1] = sq[i][j]; }
+  }
+  __syncthreads();
+  if (tid < G) {
+    float a = 0.f, c2 = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += lds[c * 2]; c2 += lds[c * 2 + 1]; }
+    float* o = partial + (((size_t)b * gridDim.x + chunk) * G + tid) * 2;
+    o[0] = a; o[1] = c2;
+  }
+}
+
+// mean_rstd[b][g] = (mean, rstd)
+__global__ void gn_finalize_kernel(const float* partial, int nchunk, int G, int BG, float inv_n, float eps, float* mean_rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BG) return;
+  const int b = i / G, g = i - b * G;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    const float* pp = partial + (((size_t)b * nchunk + c) * G + g) * 2;
+    s += pp[0]; q += pp[1];
+  }
+  const double mean = s * inv_n;
+  double var = q * inv_n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mean_rstd[i * 2] = (float)mean;
+  mean_rstd[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = act(gamma * (x - mean) * rstd + beta), written as one contiguous (B*HW, C) bf16 matrix
+__global__ __launch_bounds__(256) void gn_apply_kernel(GNSrc s, const float* mean_rstd, const float* gamma, const float* beta,
+                                                       bf16_t* y, int HW, int G, int pix_per_chunk, int silu) {
+  const int C = s.C1 + s.C2, nq = C >> 2, cpg = C / G;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int p0 = blockIdx.x * pix_per_chunk;
+  int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
+  float sc[GN_MAXQ][4], sh[GN_MAXQ][4];
+#pragma unroll
+  for (int i = 0; i < GN_MAXQ; ++i) {
+    const int q = tid + i * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[i][j] = 0.f; sh[i][j] = 0.f;
+      if (q < nq) {
+        const int c = q * 4 + j, g = c / cpg;
+        const float mean = mean_rstd[((size_t)b * G + g) * 2], rstd = mean_rstd[((size_t)b * G + g) * 2 + 1];
+        sc[i][j] = rstd * gamma[c];
+        sh[i][j] = beta[c] - mean * sc[i][j];
+      }
+    }
+  }
+  for (int p = p0; p < p1; ++p) {
+    const size_t pix = (size_t)b * HW + p;
+#pragma unroll
+    for (int i = 0; i < GN_MAXQ; ++i) {
+      const int q = tid + i * 256;
+      if (q < nq) {
+        float f[4];
+        unpack4(gn_load4(s, pix, q * 4), f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float z = f[j] * sc[i][j] + sh[i][j];
+          f[j] = silu ? silu_f(z) : z;
+        }
+        *(uint2*)(y + pix * C + q * 4) = pack4(f);
+      }
+    }
+  }
+}
+
+// Backward pass 1.  With z = gamma*xhat + beta, dz = dy * act'(z):
+//   partial[b][chunk][g] = ( sum_c gamma_c * sum_p dz , sum_c gamma_c * sum_p dz*xhat )
+//   chan_partial[b][chunk][c] = ( sum_p dz , sum_p dz*xhat )      (optional: gives dbeta, dgamma)
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(GNSrc s, const bf16_t* dy, const float* mean_rstd, const float* gamma,
+                                                           const float* beta, int HW, int G, int pix_per_chunk, int silu,
+                                                           float* partial, float* chan_partial) {
+  extern __shared__ float lds[];  // [C][2]
+  const int C = s.C1 + s.C2, nq = C >> 2, cpg = C / G;
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int p0 = chunk * pix_per_chunk;
+  int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
+  float s1[GN_MAXQ][4], s2[GN_MAXQ][4], mu[GN_MAXQ][4], rs[GN_MAXQ][4], ga[GN_MAXQ][4], be[GN_MAXQ][4];
+#pragma unroll
+  for (int i = 0; i < GN_MAXQ; ++i) {
+    const int q = tid + i * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[i][j] = s2[i][j] = 0.f; mu[i][j] = 0.f; rs[i][j] = 0.f; ga[i][j] = 0.f; be[i][j] = 0.f;
+      if (q < nq) {
+        const int c = q * 4 + j, g = c / cpg;
+        mu[i][j] = mean_rstd[((size_t)b * G + g) * 2]; rs[i][j] = mean_rstd[((size_t)b * G + g) * 2 + 1];
+        ga[i][j] = gamma[c]; be[i][j] = beta[c];
+      }
+    }
+  }
+  for (int p = p0; p < p1; ++p) {
+    const size_t pix = (size_t)b * HW + p;
+#pragma unroll
+    for (int i = 0; i < GN_MAXQ; ++i) {
+      const int q = tid + i * 256;
+      if (q < nq) {
+        float f[4], d[4];
+        unpack4(gn_load4(s, pix, q * 4), f);
+        unpack4(*(const uint2*)(dy + pix * C + q * 4), d);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (f[j] - mu[i][j]) * rs[i][j];
+          float dz = d[j];
+          if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
+          s1[i][j] += dz; s2[i][j] += dz * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < GN_MAXQ; ++i) {
+    const int q = tid + i * 256;
+    if (q < nq)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = q * 4 + j;
+        lds[c * 2] = s1[i][j] * ga[i][j]; lds[c * 2 + 1] = s2[i][j] * ga[i][j];
+        if (chan_partial) {
+          float* o = chan_partial + (((size_t)b * gridDim.x + chunk) * C + c) * 2;
+          o[0] = s1[i][j]; o[1] = s2[i][j];
+        }
+      }
+  }
+  __syncthreads();
+  if (tid < G) {
+    float a = 0.f, c2 = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += lds[c * 2]; c2 += lds[c * 2 + 1]; }
+    float* o = partial + (((size_t)b * gridDim.x + chunk) * G + tid) * 2;
+    o[0] = a; o[1] = c2;
+  }
+}
+
+// gsum[b][g] = (S1, S2) summed over chunks
+__global__ void gn_bwd_finalize_kernel(const float* partial, int nchunk, int G, int BG, float* gsum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BG) return;
+  const int b = i / G, g = i - b * G;
+  double s = 0.0, q = 0.0;
+  for (int c = 0; c < nchunk; ++c) {
+    const float* pp = partial + (((size_t)b * nchunk + c) * G + g) * 2;
+    s += pp[0]; q += pp[1];
+  }
+  gsum[i * 2] = (float)s; gsum[i * 2 + 1] = (float)q;
+}
+
+// Backward pass 2: dx = rstd * (dz*gamma - (S1 + xhat*S2)/n) (+ add), split into dx1 | dx2 along C
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t* dy, const float* mean_rstd, const float* gsum,
+                                                           const float* gamma, const float* beta, const bf16_t* add,
+                                                           bf16_t* dx1, bf16_t* dx2, int HW, int G, int pix_per_chunk, int silu,
+                                                           float inv_n) {
+  const int C = s.C1 + s.C2, nq = C >> 2, cpg = C / G;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int p0 = blockIdx.x * pix_per_chunk;
+  int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
+  float mu[GN_MAXQ][4], rs[GN_MAXQ][4], ga[GN_MAXQ][4], be[GN_MAXQ][4], g1[GN_MAXQ][4], g2[GN_MAXQ][4];
+#pragma unroll
+  for (int i = 0; i < GN_MAXQ; ++i) {
+    const int q = tid + i * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mu[i][j] = rs[i][j] = ga[i][j] = be[i][j] = g1[i][j] = g2[i][j] = 0.f;
+      if (q < nq) {
+        const int c = q * 4 + j, g = c / cpg;
+        mu[i][j] = mean_rstd[((size_t)b * G + g) * 2]; rs[i][j] = mean_rstd[((size_t)b * G + g) * 2 + 1];
+        ga[i][j] = gamma[c]; be[i][j] = beta[c];
+        g1[i][j] = gsum[((size_t)b * G + g) * 2] * inv_n; g2[i][j] = gsum[((size_t)b * G + g) * 2 + 1] * inv_n;
+      }
+    }
+  }
+  for (int p = p0; p < p1; ++p) {
+    const size_t pix = (size_t)b * HW + p;
+#pragma unroll
+    for (int i = 0; i < GN_MAXQ; ++i) {
+      const int q = tid + i * 256;
+      if (q < nq) {
+        float f[4], d[4], a[4] = {0.f, 0.f, 0.f, 0.f};
+        unpack4(gn_load4(s, pix, q * 4), f);
+        unpack4(*(const uint2*)(dy + pix * C + q * 4), d);
+        if (add) unpack4(*(const uint2*)(add + pix * C + q * 4), a);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (f[j] - mu[i][j]) * rs[i][j];
+          float dz = d[j];
+          if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
+          f[j] = rs[i][j] * (dz * ga[i][j] - g1[i][j] - xh * g2[i][j]) + a[j];
+        }
+        const int c = q * 4;
+        if (c < s.C1) *(uint2*)(dx1 + pix * s.C1 + c) = pack4(f);
+        else *(uint2*)(dx2 + pix * s.C2 + (c - s.C1)) = pack4(f);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim D (D % 8 == 0, D <= 3*64*8 = 1536): one wave per row.
+// ------------------------------------------------------------------------------------------------
+constexpr int LN_MAXC = 3;
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
+                                                     float* mean_rstd, int M, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nc = D >> 3;
+  float v[LN_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nc) {
+      unpack8(*(const uint4*)(x + (size_t)row * D + c * 8), v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nc)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0 && mean_rstd) { mean_rstd[(size_t)row * 2] = mean; mean_rstd[(size_t)row * 2 + 1] = rstd; }
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nc) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gamma[c * 8 + j] + beta[c * 8 + j];
+      *(uint4*)(y + (size_t)row * D + c * 8) = pack8(o);
+    }
+  }
+}
+
+// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* mean_rstd,
+                                                     bf16_t* dx, int M, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nc = D >> 3;
+  const float mean = mean_rstd[(size_t)row * 2], rstd = mean_rstd[(size_t)row * 2 + 1];
+  float xh[LN_MAXC][8], dg[LN_MAXC][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nc) {
+      float xv[8], dv[8];
+      unpack8(*(const uint4*)(x + (size_t)row * D + c * 8), xv);
+      unpack8(*(const uint4*)(dy + (size_t)row * D + c * 8), dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[i][j] = (xv[j] - mean) * rstd;
+        dg[i][j] = dv[j] * gamma[c * 8 + j];
+        s1 += dg[i][j]; s2 += dg[i][j] * xh[i][j];
+      }
+    }
+  }
+  s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+  for (int i = 0; i < LN_MAXC; ++i) {
+    const int c = lane + i * 64;
+    if (c < nc) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rstd * (dg[i][j] - s1 - xh[i][j] * s2);
+      *(uint4*)(dx + (size_t)row * D + c * 8) = pack8(o);
+    }
+  }
+}
+
+// column sums for norm parameter gradients: out[c] (+)= sum_r f(r, c); one thread per column, rows split over grid.y
+// mode 0: dbeta = sum dy ; mode 1: dgamma = sum dy * (x - mean_r) * rstd_r
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const bf16_t* x, const bf16_t* dy, const float* mean_rstd, int M, int D,
+                                                            int rows_per_block, float* part_dgamma, float* part_dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  int r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  float g = 0.f, b = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float d = bf2f(dy[(size_t)r * D + c]);
+    const float xh = (bf2f(x[(size_t)r * D + c]) - mean_rstd[(size_t)r * 2]) * mean_rstd[(size_t)r * 2 + 1];
+    g += d * xh; b += d;
+  }
+  part_dgamma[(size_t)blockIdx.y * D + c] = g;
+  part_dbeta[(size_t)blockIdx.y * D + c] = b;
+}
+
+int gn_chunks(int Bn, int HW) {
+  int ch = 1024 / (Bn > 0 ? Bn : 1);
+  if (ch < 1) ch = 1;
+  const int maxch = HW / 8 > 0 ? HW / 8 : 1;
+  if (ch > maxch) ch = maxch;
+  if (ch > 256) ch = 256;
+  return ch;
+}
+
+}  // namespace
+
+extern "C" int e4t_groupnorm_num_chunks(int Bn, int HW) { return gn_chunks(Bn, HW); }
+
+extern "C" size_t e4t_groupnorm_workspace_bytes(int Bn, int HW, int C, int G, int with_param_grads) {
+  const size_t ch = (size_t)gn_chunks(Bn, HW);
+  size_t b = (size_t)Bn * ch * G * 2 * sizeof(float);
+  if (with_param_grads) b += (size_t)Bn * ch * C * 2 * sizeof(float);
+  return b;
+}
+
+static int gn_check(const void* x1, int C1, const void* x2, int C2, int Bn, int HW, int G) {
+  const int C = C1 + C2;
+  E4T_REQUIRE(x1 && C1 > 0 && Bn > 0 && HW > 0 && G > 0, "groupnorm: bad arguments");
+  E4T_REQUIRE((x2 != nullptr) == (C2 > 0), "groupnorm: x2/C2 mismatch");
+  E4T_REQUIRE(C % G == 0 && C1 % 4 == 0 && C2 % 4 == 0, "groupnorm: C=%d must divide into G=%d groups, C1/C2 %% 4 == 0", C, G);
+  E4T_REQUIRE(C <= GN_MAXQ * 256 * 4 && G <= 256, "groupnorm: C=%d too large", C);
+  return 0;
+}
+
+extern "C" int e4t_groupnorm_stats(const void* x1, int C1, const void* x2, int C2, int Bn, int HW, int G, float eps,
+                                   float* mean_rstd, void* workspace, size_t ws_bytes, e4t_stream stream) {
+  if (int e = gn_check(x1, C1, x2, C2, Bn, HW, G)) return e;
+  const int C = C1 + C2, ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch);
+  E4T_REQUIRE(workspace && ws_bytes >= (size_t)Bn * ch * G * 2 * sizeof(float), "groupnorm_stats: workspace too small");
+  GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(ch, Bn), dim3(256), (size_t)C * 2 * sizeof(float), st, s, HW, G, ppc, (float*)workspace);
+  E4T_CHECK_LAUNCH("gn_stats_kernel");
+  const int BG = Bn * G;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(BG, 256)), dim3(256), 0, st, (const float*)workspace, ch, G, BG,
+                     1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
+  E4T_CHECK_LAUNCH("gn_finalize_kernel");
+  return 0;
+}
+
+extern "C" int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C2, const float* mean_rstd, const float* gamma,
+                                   const float* beta, void* y, int Bn, int HW, int G, int silu, e4t_stream stream) {
+  if (int e = gn_check(x1, C1, x2, C2, Bn, HW, G)) return e;
+  E4T_REQUIRE(mean_rstd && gamma && beta && y, "groupnorm_apply: null argument");
+  const int ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch);
+  GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(ch, Bn), dim3(256), 0, (hipStream_t)stream, s, mean_rstd, gamma, beta, (bf16_t*)y, HW, G, ppc, silu);
+  E4T_CHECK_LAUNCH("gn_apply_kernel");
+  return 0;
+}
+
+extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, const float* mean_rstd,
+                                 const float* gamma, const float* beta, const void* add, void* dx1, void* dx2,
+                                 float* dgamma_dbeta_partial, int Bn, int HW, int G, int silu, void* workspace,
+                                 size_t ws_bytes, e4t_stream stream) {
+  if (int e = gn_check(x1, C1, x2, C2, Bn, HW, G)) return e;
+  E4T_REQUIRE(dy && mean_rstd && gamma && beta && dx1 && ((dx2 != nullptr) == (C2 > 0)), "groupnorm_bwd: null argument");
+  const int C = C1 + C2, ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch), BG = Bn * G;
+  const size_t need = ((size_t)Bn * ch * G * 2 + (size_t)BG * 2) * sizeof(float);
+  E4T_REQUIRE(workspace && ws_bytes >= need, "groupnorm_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+  float* partial = (float*)workspace;
+  float* gsum = partial + (size_t)Bn * ch * G * 2;
+  GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ch, Bn), dim3(256), (size_t)C * 2 * sizeof(float), st, s, (const bf16_t*)dy, mean_rstd,
+                     gamma, beta, HW, G, ppc, silu, partial, dgamma_dbeta_partial);
+  E4T_CHECK_LAUNCH("gn_bwd_stats_kernel");
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(BG, 256)), dim3(256), 0, st, (const float*)partial, ch, G, BG, gsum);
+  E4T_CHECK_LAUNCH("gn_bwd_finalize_kernel");
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ch, Bn), dim3(256), 0, st, s, (const bf16_t*)dy, mean_rstd, (const float*)gsum, gamma, beta,
+                     (const bf16_t*)add, (bf16_t*)dx1, (bf16_t*)dx2, HW, G, ppc, silu, 1.f / ((float)(C / G) * (float)HW));
+  E4T_CHECK_LAUNCH("gn_bwd_apply_kernel");
+  return 0;
+}
+
+extern "C" int e4t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int M, int D,
+                                 float eps, e4t_stream stream) {
+  E4T_REQUIRE(x && gamma && beta && y && M > 0, "layernorm_fwd: null argument");
+  E4T_REQUIRE(D % 8 == 0 && D <= LN_MAXC * 64 * 8, "layernorm: D=%d must be a multiple of 8 and <= 1536", D);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, M, D, eps);
+  E4T_CHECK_LAUNCH("ln_fwd_kernel");
+  return 0;
+}
+
+extern "C" int e4t_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, void* dx, int M, int D,
+                                 e4t_stream stream) {
+  E4T_REQUIRE(x && dy && gamma && mean_rstd && dx && M > 0, "layernorm_bwd: null argument");
+  E4T_REQUIRE(D % 8 == 0 && D <= LN_MAXC * 64 * 8, "layernorm: D=%d must be a multiple of 8 and <= 1536", D);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, M, D);
+  E4T_CHECK_LAUNCH("ln_bwd_kernel");
+  return 0;
+}
+
+// part_dgamma / part_dbeta: [nblk][D] fp32 with nblk = e4t_layernorm_param_grad_blocks(M); caller sums over dim 0.
+extern "C" int e4t_layernorm_param_grad_blocks(int M) { int n = cdiv(M, 512); return n > 256 ? 256 : (n < 1 ? 1 : n); }
+
+extern "C" int e4t_layernorm_param_grad(const void* x, const void* dy, const float* mean_rstd, int M, int D, float* part_dgamma,
+                                        float* part_dbeta, e4t_stream stream) {
+  E4T_REQUIRE(x && dy && mean_rstd && part_dgamma && part_dbeta, "layernorm_param_grad: null argument");
+  const int nblk = e4t_layernorm_param_grad_blocks(M), rpb = cdiv(M, nblk);
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3(cdiv(D, 256), nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy,
+                     mean_rstd, M, D, rpb, part_dgamma, part_dbeta);
+  E4T_CHECK_LAUNCH("ln_param_grad_kernel");
+  return 0;
+}

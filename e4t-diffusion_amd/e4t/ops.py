@@ -1,0 +1,397 @@
+"""Op-level Python surface of the HIP library: torch tensors in, torch tensors out.
+
+Every function here launches hand-written HIP kernels through the C ABI (``_C.py``) on torch's
+current stream; torch is used only to own device memory.  The functions dispatch through a
+module-level backend object so that *tests* can substitute an instrumented double (tests/
+emu_backend.py) to validate the host-side graph logic on a machine without a GPU.  The product
+never installs another backend: with no GPU / no built library every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _C
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rowmajor(t: torch.Tensor, name: str):
+    if t.dim() < 2 or t.stride(-1) != 1:
+        raise ValueError(f"{name}: expected a row-major matrix with unit inner stride, got strides {t.stride()}")
+
+
+
+def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch):
+    """Mirror of launch_gemm()'s tile / split-K heuristic (csrc/gemm.hip) -> workspace bytes it will want."""
+    cd = lambda a, b: (a + b - 1) // b
+    nkt = cd(K, 64)
+    if tile not in (64, 128):
+        tile = 128 if cd(M, 128) * cd(N, 128) * nb >= 384 else 64
+    tiles = cd(N, tile) * cd(M, tile) * nb
+    if splitk <= 0:
+        splitk = 1
+        if tiles < 256 and nkt >= 16:
+            splitk = max(1, min(cd(512, tiles), nkt // 4))
+    splitk = min(splitk, nkt)
+    splitk = cd(nkt, cd(nkt, splitk))
+    return 4 * splitk * nb * M * N if (splitk > 1 or reduce_batch) else 0
+
+
+@dataclass
+class WOEntry:
+    """One WeightOffsets instance + the projection weight it modulates (row = in, col = out)."""
+    row: int
+    col: int
+    W: torch.Tensor                      # fp32 [col, row]
+    params: Optional[dict] = None        # v, w1, b1, w2, b2, wc, bc, wr, br (fp32) or None for a plain weight
+    weff: Optional[torch.Tensor] = None  # bf16 [col, >=row] view (row stride = ld)
+    weffT: Optional[torch.Tensor] = None # bf16 [row, >=col] view
+    dweff: Optional[torch.Tensor] = None # fp32 [col, >=row] view (backward input)
+    grads: Optional[dict] = None         # g_v ... g_br fp32 tensors (backward outputs)
+    g_W: Optional[torch.Tensor] = None
+    vecs: Optional[torch.Tensor] = None
+    partial: Optional[torch.Tensor] = None
+
+
+@dataclass
+class WOTable:
+    entries: List[WOEntry]
+    dev: Optional[torch.Tensor] = None   # packed e4t_wo_desc array in device memory (HIP backend)
+    _sig: tuple = field(default_factory=tuple)
+
+    @property
+    def max_row(self):
+        return max(e.row for e in self.entries)
+
+    @property
+    def max_col(self):
+        return max(e.col for e in self.entries)
+
+
+class HipBackend:
+    """The one and only product backend: libe4t_hip.so on the current CUDA(HIP) device."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _C.load()
+        self._ws = {}
+
+    # ------------------------------------------------------------------ workspaces
+    def workspace(self, nbytes: int, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ GEMM
+    def gemm(self, a, b, *, a2=None, bias=None, residual=None, rowbias=None, rows_per_batch=0, out=None,
+             out_dtype=bf16, gelu=False, accum=False, alpha=1.0, reduce_batch=False, tile=0, splitk=0):
+        batched = a.dim() == 3
+        _rowmajor(a, "gemm A"); _rowmajor(b, "gemm B")
+        if batched:
+            nb, M, K = a.shape
+            N = b.shape[1]
+            sA, sB = a.stride(0), b.stride(0)
+        else:
+            nb, (M, K), N, sA, sB = 1, a.shape, b.shape[0], 0, 0
+        K1 = K
+        if a2 is not None:
+            _rowmajor(a2, "gemm A2")
+            K = K1 + a2.shape[-1]
+        assert b.shape[-1] == K, f"gemm: B has K={b.shape[-1]}, A has K={K}"
+        if out is None:
+            shape = (M, N) if (not batched or reduce_batch) else (nb, M, N)
+            out = torch.empty(shape, dtype=out_dtype, device=a.device)
+        _rowmajor(out, "gemm C")
+        d = _C.GemmDesc()
+        d.A, d.A2, d.B, d.C = _ptr(a), _ptr(a2), _ptr(b), _ptr(out)
+        d.bias, d.residual, d.rowbias = _ptr(bias), _ptr(residual), _ptr(rowbias)
+        d.M, d.N, d.K, d.K1 = M, N, K, K1
+        d.lda, d.lda2, d.ldb, d.ldc = a.stride(-2), (a2.stride(-2) if a2 is not None else 0), b.stride(-2), out.stride(-2)
+        d.ldr = residual.stride(-2) if residual is not None else 0
+        d.rows_per_batch = rows_per_batch
+        flags = 0
+        if out.dtype == f32:
+            flags |= _C.OUT_F32
+        if residual is not None and residual.dtype == f32:
+            flags |= _C.RES_F32
+        if gelu:
+            flags |= _C.ACT_GELU
+        if accum:
+            flags |= _C.ACCUM
+        if reduce_batch:
+            flags |= _C.REDUCE_BATCH
+        d.flags, d.tile, d.splitk, d.batch, d.alpha = flags, tile, splitk, nb, alpha
+        d.strideA, d.strideB = sA, sB
+        d.strideC = out.stride(0) if (batched and not reduce_batch) else 0
+        d.strideBias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+        need = _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch)
+        ws = self.workspace(need, a.device) if need else None
+        d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
+        _C.check(self.lib.e4t_gemm_nt(C.byref(d), _stream()), "e4t_gemm_nt")
+        return out
+
+    # ------------------------------------------------------------------ conv
+    def conv3x3(self, x, w, B, Hin, Win, Hout, Wout, mode, *, bias=None, residual=None, rowbias=None, out=None,
+                out_dtype=bf16, accum=False, tile=0, splitk=0):
+        Cin, Cout = x.shape[-1], w.shape[0]
+        assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == 9 * Cin
+        M = B * Hout * Wout
+        if out is None:
+            out = torch.empty((M, Cout), dtype=out_dtype, device=x.device)
+        d = _C.ConvDesc()
+        d.X, d.W, d.Y, d.bias, d.residual, d.rowbias = _ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(rowbias)
+        d.B, d.Hin, d.Win, d.Cin, d.Hout, d.Wout, d.Cout = B, Hin, Win, Cin, Hout, Wout, Cout
+        flags = 0
+        if out.dtype == f32:
+            flags |= _C.OUT_F32
+        if residual is not None and residual.dtype == f32:
+            flags |= _C.RES_F32
+        if accum:
+            flags |= _C.ACCUM
+        d.mode, d.flags, d.tile, d.splitk = mode, flags, tile, splitk
+        need = _gemm_ws_need(M, Cout, 9 * Cin, 1, tile, splitk, False)
+        ws = self.workspace(need, x.device) if need else None
+        d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
+        _C.check(self.lib.e4t_conv3x3(C.byref(d), _stream()), "e4t_conv3x3")
+        return out
+
+    def conv_weight_prepare(self, w_oihw, Ipad=None, Opad=None, want_fwd=True, want_dgrad=True):
+        O, I = w_oihw.shape[:2]
+        Ipad = Ipad or (I + 63) // 64 * 64
+        Opad = Opad or (O + 63) // 64 * 64
+        w = w_oihw.detach().contiguous().float()
+        wf = torch.empty((O, 9 * Ipad), dtype=bf16, device=w.device) if want_fwd else None
+        wd = torch.empty((I, 9 * Opad), dtype=bf16, device=w.device) if want_dgrad else None
+        _C.check(self.lib.e4t_conv_weight_prepare(_ptr(w), _ptr(wf), _ptr(wd), O, I, Ipad, Opad, _stream()), "e4t_conv_weight_prepare")
+        return wf, wd
+
+    # ------------------------------------------------------------------ attention
+    def attention_fwd(self, q, k, v, B, H, T, S, DH, scale, out=None, need_lse=True):
+        """q: [B*T, *] view, k/v: [B*S, *] views (row stride arbitrary); returns (o [B*T, H*DH], lse [B,H,T])."""
+        for t in (q, k, v):
+            _rowmajor(t, "attention operand")
+        if out is None:
+            out = torch.empty((B * T, H * DH), dtype=bf16, device=q.device)
+        lse = torch.empty((B, H, T), dtype=f32, device=q.device) if need_lse else None
+        ldq, ldk, ldv, ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+        _C.check(self.lib.e4t_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, T, S, DH, ldq, ldk, ldv, ldo,
+                                            T * ldq, S * ldk, S * ldv, T * ldo, float(scale), _stream()), "e4t_attention_fwd")
+        return out, lse
+
+    def attention_bwd(self, q, k, v, o, do, lse, dq, dk, dv, B, H, T, S, DH, scale):
+        """dq/dk/dv are pre-allocated views with the SAME strides as q/k/v; do has the strides of o."""
+        ldq, ldk, ldv, ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+        assert dq.stride(0) == ldq and dk.stride(0) == ldk and dv.stride(0) == ldv and do.stride(0) == ldo
+        delta = torch.empty((B, H, T), dtype=f32, device=q.device)
+        _C.check(self.lib.e4t_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk),
+                                            _ptr(dv), B, H, T, S, DH, ldq, ldk, ldv, ldo, T * ldq, S * ldk, S * ldv, T * ldo,
+                                            float(scale), _stream()), "e4t_attention_bwd")
+
+    # ------------------------------------------------------------------ norms
+    def groupnorm_fwd(self, x1, x2, gamma, beta, B, HW, G, eps, silu):
+        C1, C2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+        Cn = C1 + C2
+        assert x1.is_contiguous() and (x2 is None or x2.is_contiguous())
+        stats = torch.empty((B, G, 2), dtype=f32, device=x1.device)
+        nb = self.lib.e4t_groupnorm_workspace_bytes(B, HW, Cn, G, 0)
+        ws = self.workspace(nb, x1.device)
+        _C.check(self.lib.e4t_groupnorm_stats(_ptr(x1), C1, _ptr(x2), C2, B, HW, G, float(eps), _ptr(stats), _ptr(ws), ws.numel(), _stream()),
+                 "e4t_groupnorm_stats")
+        y = torch.empty((B * HW, Cn), dtype=bf16, device=x1.device)
+        _C.check(self.lib.e4t_groupnorm_apply(_ptr(x1), C1, _ptr(x2), C2, _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(y), B, HW, G, int(silu), _stream()),
+                 "e4t_groupnorm_apply")
+        return y, stats
+
+    def groupnorm_bwd(self, x1, x2, dy, stats, gamma, beta, add, B, HW, G, silu, want_param_grads=False):
+        C1, C2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+        Cn = C1 + C2
+        assert dy.is_contiguous() and (add is None or add.is_contiguous())
+        dx1 = torch.empty_like(x1)
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        ch = self.lib.e4t_groupnorm_num_chunks(B, HW)
+        cpart = torch.empty((B * ch, Cn, 2), dtype=f32, device=x1.device) if want_param_grads else None
+        nb = self.lib.e4t_groupnorm_workspace_bytes(B, HW, Cn, G, 0) + B * G * 8
+        ws = self.workspace(nb, x1.device)
+        _C.check(self.lib.e4t_groupnorm_bwd(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(add), _ptr(dx1),
+                                            _ptr(dx2), _ptr(cpart), B, HW, G, int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_bwd")
+        dgamma = dbeta = None
+        if want_param_grads:
+            s = cpart.sum(dim=0)          # tiny (chunks x C) reduction of kernel partials
+            dbeta, dgamma = s[:, 0].contiguous(), s[:, 1].contiguous()
+        return dx1, dx2, dgamma, dbeta
+
+    def layernorm_fwd(self, x, gamma, beta, eps, need_stats=True):
+        M, D = x.shape
+        assert x.is_contiguous()
+        y = torch.empty_like(x)
+        stats = torch.empty((M, 2), dtype=f32, device=x.device) if need_stats else None
+        _C.check(self.lib.e4t_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), M, D, float(eps), _stream()), "e4t_layernorm_fwd")
+        return y, stats
+
+    def layernorm_bwd(self, x, dy, gamma, stats, want_param_grads=False):
+        M, D = x.shape
+        assert dy.is_contiguous()
+        dx = torch.empty_like(x)
+        _C.check(self.lib.e4t_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(stats), _ptr(dx), M, D, _stream()), "e4t_layernorm_bwd")
+        dgamma = dbeta = None
+        if want_param_grads:
+            nblk = self.lib.e4t_layernorm_param_grad_blocks(M)
+            pg = torch.empty((nblk, D), dtype=f32, device=x.device)
+            pb = torch.empty((nblk, D), dtype=f32, device=x.device)
+            _C.check(self.lib.e4t_layernorm_param_grad(_ptr(x), _ptr(dy), _ptr(stats), M, D, _ptr(pg), _ptr(pb), _stream()), "e4t_layernorm_param_grad")
+            dgamma, dbeta = pg.sum(0), pb.sum(0)
+        return dx, dgamma, dbeta
+
+    # ------------------------------------------------------------------ streaming ops
+    def geglu_fwd(self, u):
+        M, H2 = u.shape
+        h = torch.empty((M, H2 // 2), dtype=bf16, device=u.device)
+        _C.check(self.lib.e4t_geglu_fwd(_ptr(u), _ptr(h), M, H2 // 2, _stream()), "e4t_geglu_fwd")
+        return h
+
+    def geglu_bwd(self, u, dh):
+        du = torch.empty_like(u)
+        _C.check(self.lib.e4t_geglu_bwd(_ptr(u), _ptr(dh), _ptr(du), u.shape[0], u.shape[1] // 2, _stream()), "e4t_geglu_bwd")
+        return du
+
+    def unary(self, x, op, dy=None):
+        assert x.is_contiguous() and (dy is None or dy.is_contiguous())
+        y = torch.empty_like(x)
+        _C.check(self.lib.e4t_unary(_ptr(x), _ptr(dy), _ptr(y), x.numel(), op, _stream()), "e4t_unary")
+        return y
+
+    def add(self, a, b):
+        assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+        y = torch.empty_like(a)
+        _C.check(self.lib.e4t_add(_ptr(a), _ptr(b), _ptr(y), a.numel(), _stream()), "e4t_add")
+        return y
+
+    def transpose(self, x, pad_to=0):
+        """bf16 [R, C] (row stride arbitrary) -> contiguous [C, max(R, pad_to)] (pad columns zero)."""
+        _rowmajor(x, "transpose input")
+        R, Cn = x.shape
+        ldo = max(R, pad_to)
+        out = torch.zeros((Cn, ldo), dtype=bf16, device=x.device) if ldo > R else torch.empty((Cn, ldo), dtype=bf16, device=x.device)
+        _C.check(self.lib.e4t_transpose(_ptr(x), _ptr(out), 1, R, Cn, x.stride(0), ldo, 0, 0, _stream()), "e4t_transpose")
+        return out
+
+    def sumpool2(self, x, B, H, W):
+        Cn = x.shape[-1]
+        out = torch.empty((B * H * W, Cn), dtype=bf16, device=x.device)
+        _C.check(self.lib.e4t_sumpool2(_ptr(x), _ptr(out), B, H, W, Cn, _stream()), "e4t_sumpool2")
+        return out
+
+    def spatial_mean(self, x, B, HW, out, coff):
+        _C.check(self.lib.e4t_spatial_mean(_ptr(x), _ptr(out), B, HW, x.shape[-1], out.stride(0), coff, _stream()), "e4t_spatial_mean")
+
+    def spatial_mean_bwd(self, g, base, B, HW, Cn, coff):
+        dx = torch.empty((B * HW, Cn), dtype=bf16, device=g.device)
+        _C.check(self.lib.e4t_spatial_mean_bwd(_ptr(g), _ptr(base), _ptr(dx), B, HW, Cn, g.stride(0), coff, _stream()), "e4t_spatial_mean_bwd")
+        return dx
+
+    def timestep_embedding(self, t, dim):
+        t = t.to(torch.int64).contiguous()
+        out = torch.empty((t.shape[0], dim), dtype=bf16, device=t.device)
+        _C.check(self.lib.e4t_timestep_embedding(_ptr(t), _ptr(out), t.shape[0], dim, _stream()), "e4t_timestep_embedding")
+        return out
+
+    def clip_preprocess(self, pixels, S, P, Kpad):
+        pixels = pixels.float().contiguous()
+        B, _, Hin, Win = pixels.shape
+        g = S // P
+        out = torch.zeros((B * g * g, Kpad), dtype=bf16, device=pixels.device)
+        _C.check(self.lib.e4t_clip_preprocess(_ptr(pixels), _ptr(out), B, Hin, Win, S, P, Kpad, _stream()), "e4t_clip_preprocess")
+        return out
+
+    def adamw(self, p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+        _C.check(self.lib.e4t_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, grad_scale, _stream()), "e4t_adamw")
+
+    def sumsq(self, g):
+        nb = 1024
+        part = torch.empty(nb, dtype=f32, device=g.device)
+        _C.check(self.lib.e4t_sumsq_partial(_ptr(g), g.numel(), _ptr(part), nb, _stream()), "e4t_sumsq_partial")
+        return part.sum()
+
+    # ------------------------------------------------------------------ weight offsets
+    def _pack_table(self, table: WOTable, device):
+        sig = tuple((_ptr(e.W), _ptr(e.weff), _ptr(e.weffT), _ptr(e.dweff), _ptr(e.g_W),
+                     _ptr(e.grads["g_v"]) if e.grads else 0) for e in table.entries)
+        if table.dev is not None and table._sig == sig:
+            return
+        arr = (_C.WODesc * len(table.entries))()
+        for d, e in zip(arr, table.entries):
+            if e.params is not None:
+                for k in ("v", "w1", "b1", "w2", "b2", "wc", "bc", "wr", "br"):
+                    setattr(d, k, _ptr(e.params[k]))
+                if e.vecs is None:
+                    e.vecs = torch.empty(self.lib.e4t_wo_vecs_floats(e.row, e.col), dtype=f32, device=device)
+                if e.partial is None:
+                    e.partial = torch.empty(self.lib.e4t_wo_partial_floats(e.row, e.col), dtype=f32, device=device)
+                d.vecs, d.partial = _ptr(e.vecs), _ptr(e.partial)
+            d.W, d.weff, d.weffT, d.dweff, d.g_W = _ptr(e.W), _ptr(e.weff), _ptr(e.weffT), _ptr(e.dweff), _ptr(e.g_W)
+            if e.grads is not None:
+                for k in ("g_v", "g_w1", "g_b1", "g_w2", "g_b2", "g_wc", "g_bc", "g_wr", "g_br"):
+                    setattr(d, k, _ptr(e.grads[k]))
+            d.row, d.col = e.row, e.col
+            d.ld_weff = e.weff.stride(0) if e.weff is not None else 0
+            d.ld_weffT = e.weffT.stride(0) if e.weffT is not None else 0
+            d.ld_dweff = e.dweff.stride(0) if e.dweff is not None else 0
+        raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        table.dev = raw.to(device)
+        table._sig = sig
+
+    def wo_forward(self, table: WOTable):
+        dev = table.entries[0].W.device
+        self._pack_table(table, dev)
+        _C.check(self.lib.e4t_wo_forward(_ptr(table.dev), len(table.entries), table.max_row, table.max_col, _stream()), "e4t_wo_forward")
+
+    def wo_backward(self, table: WOTable, accumulate: bool):
+        dev = table.entries[0].W.device
+        self._pack_table(table, dev)
+        _C.check(self.lib.e4t_wo_backward(_ptr(table.dev), len(table.entries), table.max_row, table.max_col, int(accumulate), _stream()), "e4t_wo_backward")
+
+    def weight_prepare(self, table: WOTable):
+        dev = table.entries[0].W.device
+        self._pack_table(table, dev)
+        _C.check(self.lib.e4t_weight_prepare(_ptr(table.dev), len(table.entries), table.max_row, table.max_col, _stream()), "e4t_weight_prepare")
+
+    def probe_mfma(self, device):
+        rows = torch.zeros((64, 16), dtype=f32, device=device)
+        cols = torch.zeros((64, 16), dtype=f32, device=device)
+        _C.check(self.lib.e4t_probe_mfma_layout(_ptr(rows), _ptr(cols), _stream()), "e4t_probe_mfma_layout")
+        return rows, cols
+
+
+_backend = None
+
+
+def backend():
+    """The active backend.  Created on first use; raises if the HIP library cannot be loaded."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(b):
+    """TEST HOOK ONLY (tests/emu_backend.py).  The product never calls this."""
+    global _backend
+    old, _backend = _backend, b
+    return old

@@ -1,0 +1,180 @@
+/* libe4t_hip.so — C ABI of the MI355X-native (gfx950) E4T training hot path.
+ *
+ * The reference (mkshing/e4t-diffusion) is pure Python; its "FFI" for this path is the set of
+ * torch ops its modules call.  Each entry point below replaces those call sites (cited as
+ * reference file:line, relative to the reference root) with one hand-written HIP kernel family.
+ * The Python modules in e4t-diffusion_amd/e4t/ bind these symbols with ctypes and pass
+ * tensor.data_ptr() / torch.cuda.current_stream().cuda_stream.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it is a descriptor struct passed by host pointer;
+ *   - the caller owns every buffer, including workspaces; the library keeps no tensor state;
+ *   - activations: bf16, NHWC, i.e. row-major (B*H*W, C); statistics / grads of parameters: fp32;
+ *   - all launches are asynchronous on the caller's stream (hipStream_t passed as void*);
+ *   - return value 0 = OK, negative errno-style code otherwise (-22 bad argument, -12 workspace,
+ *     -5 launch failure); e4t_last_error() returns the message; nothing throws across the ABI;
+ *   - one host thread per process/rank; re-entrant across streams.
+ */
+#ifndef E4T_HIP_H
+#define E4T_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* e4t_stream; /* hipStream_t */
+
+int e4t_version(void);
+const char* e4t_last_error(void);
+/* device sanity: returns 0 and fills arch name (e.g. "gfx950"), CU count */
+int e4t_device_info(char* arch, int arch_len, int* cu_count);
+
+/* ---------------------------------------------------------------- GEMM / conv (gemm.hip) ---- */
+/* epilogue flags */
+#define E4T_OUT_F32 1   /* C stored as fp32 (default bf16) */
+#define E4T_RES_F32 2   /* residual is fp32 (default bf16) */
+#define E4T_ACT_GELU 4  /* exact-erf GELU after bias, before residual */
+#define E4T_ACCUM 8     /* C += result (read-modify-write in C's dtype) */
+#define E4T_REDUCE_BATCH 16 /* sum the batch entries into ONE C (needs workspace) */
+
+/* C[M,N] = epi(alpha * A[M,K] . B[N,K]^T): F.linear / 1x1 conv / their dX and dW GEMMs.
+ * Replaces cross_attention.py:506,516,518,534 ; attention.py:376,419 ; transformer_2d.py:153,205,
+ * 258-261 ; encoder.py:101-106,159-168 ; [3P] open_clip ViT linears ; time_emb_proj ; conv_shortcut. */
+typedef struct {
+  const void* A;       /* bf16 [M][lda] */
+  const void* A2;      /* optional second K-source: columns [K1,K) come from A2[M][lda2] (fused torch.cat) */
+  const void* B;       /* bf16 [N][ldb] */
+  void* C;             /* bf16 or fp32 [M][ldc] */
+  const float* bias;   /* optional fp32 [N] */
+  const void* residual;/* optional [M][ldr], added after activation */
+  const float* rowbias;/* optional fp32 [M/rows_per_batch][N] (ResBlock time-embedding add) */
+  void* workspace;     /* fp32 scratch for split-K / batch reduction, or NULL */
+  size_t workspace_bytes;
+  int M, N, K, K1;
+  int lda, lda2, ldb, ldc, ldr;
+  int rows_per_batch;
+  int flags;
+  int tile;            /* 0 = auto, 64 or 128 */
+  int splitk;          /* 0 = auto, >= 1 forced */
+  int batch;           /* >= 1; operand base pointers advance by the strides below (elements) */
+  long long strideA, strideB, strideC, strideBias;
+  float alpha;
+} e4t_gemm_desc;
+int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream);
+
+/* 3x3 convolution, pad 1, NHWC, implicit GEMM (no im2col buffer).
+ * Replaces [3P diffusers 0.14] ResnetBlock2D.conv1/conv2, Downsample2D.conv (stride 2),
+ * Upsample2D (nearest x2 + conv) built at unet_2d_blocks.py:481,760,804,881,1732,1774,1855,1872 and
+ * conv_in / conv_out (unet_2d_condition.py:106-108,285-287), plus their data gradients. */
+#define E4T_CONV_S1 1   /* stride 1 (also dgrad of stride 1 with flipped weights) */
+#define E4T_CONV_S2 2   /* stride 2 */
+#define E4T_CONV_UP2 3  /* nearest x2 upsample fused into the gather, then stride 1 */
+#define E4T_CONV_S2T 4  /* transposed stride 2 (dgrad of E4T_CONV_S2) */
+typedef struct {
+  const void* X;       /* bf16 [B][Hin][Win][Cin] */
+  const void* W;       /* bf16 [Cout][3][3][Cin]  (e4t_conv_weight_prepare) */
+  void* Y;             /* bf16/fp32 [B][Hout][Wout][Cout] */
+  const float* bias;   /* fp32 [Cout] or NULL */
+  const void* residual;/* [B][Hout][Wout][Cout] or NULL */
+  const float* rowbias;/* fp32 [B][Cout] or NULL */
+  void* workspace;
+  size_t workspace_bytes;
+  int B, Hin, Win, Cin, Hout, Wout, Cout;
+  int mode, flags, tile, splitk;
+} e4t_conv_desc;
+int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream);
+
+/* ---------------------------------------------------------------- attention (attention.hip) -- */
+/* O = softmax(Q K^T * scale) V ; Q/K/V/O are (B, T|S, heads*DH) bf16 matrices with row strides ld*
+ * and batch strides b* (elements); lse: fp32 [B][H][T] (log2 units) or NULL.  DH in {32,40,64,80,160}.
+ * Replaces cross_attention.py:521-531 (SDPA), :222-251,313-314 (math), :473-481 (xFormers). */
+int e4t_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int T, int S, int DH,
+                      int ldq, int ldk, int ldv, int ldo, long long bq, long long bk, long long bv, long long bo,
+                      float scale, e4t_stream stream);
+/* delta_ws: fp32 [B][H][T] scratch.  dQ/dK/dV share the layout (strides) of Q/K/V; dO that of O. */
+int e4t_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                      float* delta_ws, void* dQ, void* dK, void* dV, int B, int H, int T, int S, int DH, int ldq, int ldk,
+                      int ldv, int ldo, long long bq, long long bk, long long bv, long long bo, float scale,
+                      e4t_stream stream);
+
+/* ---------------------------------------------------------------- norms (norm.hip) ----------- */
+/* GroupNorm over NHWC input given as up to two channel-sources (x1: C1 ch, x2: C2 ch or NULL) —
+ * the fused form of torch.cat([h, skip], 1) -> GroupNorm -> SiLU (unet_2d_blocks.py:1795,1883;
+ * [3P] ResnetBlock2D.norm1/norm2; transformer_2d.py:149,253; unet_2d_condition.py:275-278,554-556). */
+int e4t_groupnorm_num_chunks(int B, int HW);
+size_t e4t_groupnorm_workspace_bytes(int B, int HW, int C, int G, int with_param_grads);
+int e4t_groupnorm_stats(const void* x1, int C1, const void* x2, int C2, int B, int HW, int G, float eps,
+                        float* mean_rstd /* [B][G][2] */, void* workspace, size_t ws_bytes, e4t_stream stream);
+int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C2, const float* mean_rstd, const float* gamma,
+                        const float* beta, void* y /* bf16 [B*HW][C1+C2] */, int B, int HW, int G, int silu,
+                        e4t_stream stream);
+/* dx1|dx2 = d/dx of act(GN(x)) given dy, plus optional `add` (bf16 [B*HW][C]); optional per-chunk
+ * channel partials [B][chunks][C][2] = (sum dz, sum dz*xhat) for dbeta/dgamma. */
+int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, const float* mean_rstd,
+                      const float* gamma, const float* beta, const void* add, void* dx1, void* dx2,
+                      float* dgamma_dbeta_partial, int B, int HW, int G, int silu, void* workspace, size_t ws_bytes,
+                      e4t_stream stream);
+/* LayerNorm over the last dim (attention.py:259,268,273; open_clip ViT ln_*). */
+int e4t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd /* [M][2] or NULL */,
+                      int M, int D, float eps, e4t_stream stream);
+int e4t_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, void* dx, int M, int D,
+                      e4t_stream stream);
+int e4t_layernorm_param_grad_blocks(int M);
+int e4t_layernorm_param_grad(const void* x, const void* dy, const float* mean_rstd, int M, int D, float* part_dgamma,
+                             float* part_dbeta, e4t_stream stream);
+
+/* ---------------------------------------------------------------- weight offsets (wo.hip) ---- */
+/* One descriptor per WeightOffsets instance (weightoffsets.py:5-23) + the projection weight it
+ * modulates (cross_attention.py:506,516,518).  row = in_features, col = out_features.
+ * Descriptors live in DEVICE memory (array of n); wc == NULL marks a plain weight (cast only). */
+typedef struct {
+  const float *v, *w1, *b1, *w2, *b2, *wc, *bc, *wr, *br; /* v[1] linear1.{w,b}[row] linear2.{w,b}[col] linear_column[row][row],[row] linear_row[col][col],[col] */
+  const float* W;        /* base weight fp32 [col][row] */
+  float* vecs;           /* fp32 scratch, e4t_wo_vecs_floats(row, col) */
+  float* partial;        /* fp32 scratch, e4t_wo_partial_floats(row, col) */
+  void* weff;            /* out: bf16 [col][ld_weff]  W o (1 + offsets)   (may be NULL) */
+  void* weffT;           /* out: bf16 [row][ld_weffT] transposed copy      (may be NULL) */
+  const float* dweff;    /* in (backward): fp32 [col][ld_dweff] dL/dW_eff */
+  float *g_v, *g_w1, *g_b1, *g_w2, *g_b2, *g_wc, *g_bc, *g_wr, *g_br; /* out (backward): parameter grads */
+  float* g_W;            /* out (backward, optional): dL/dW = dW_eff o (1 + offsets) */
+  int row, col, ld_weff, ld_weffT, ld_dweff, _pad;
+} e4t_wo_desc;
+size_t e4t_wo_vecs_floats(int row, int col);
+size_t e4t_wo_partial_floats(int row, int col);
+int e4t_wo_forward(const e4t_wo_desc* descs_dev, int n, int max_row, int max_col, e4t_stream stream);
+int e4t_wo_backward(const e4t_wo_desc* descs_dev, int n, int max_row, int max_col, int accumulate, e4t_stream stream);
+int e4t_weight_prepare(const e4t_wo_desc* descs_dev, int n, int max_row, int max_col, e4t_stream stream);
+/* OIHW fp32 3x3 weights -> [O][ky][kx][Ipad] (forward) and [I][2-ky][2-kx][Opad] (dgrad), bf16, zero padded */
+int e4t_conv_weight_prepare(const float* w_oihw, void* w_fwd, void* w_dgrad, int O, int I, int Ipad, int Opad, e4t_stream stream);
+
+/* ---------------------------------------------------------------- streaming ops (elementwise.hip) */
+int e4t_geglu_fwd(const void* u /* [M][2H] */, void* h /* [M][H] */, long long M, int H, e4t_stream stream);  /* attention.py:428-430 */
+int e4t_geglu_bwd(const void* u, const void* dh, void* du, long long M, int H, e4t_stream stream);
+#define E4T_OP_SILU 0
+#define E4T_OP_SILU_BWD 1
+#define E4T_OP_GELU 2
+#define E4T_OP_GELU_BWD 3
+#define E4T_OP_LRELU 4
+#define E4T_OP_LRELU_BWD 5
+int e4t_unary(const void* x, const void* dy, void* y, long long n, int op, e4t_stream stream);
+int e4t_add(const void* a, const void* b, void* y, long long n, e4t_stream stream);
+int e4t_transpose(const void* in, void* out, int batch, int R, int C, int ldi, int ldo, long long bsi, long long bso, e4t_stream stream);
+int e4t_sumpool2(const void* in /* [B][2H][2W][C] */, void* out /* [B][H][W][C] */, int B, int H, int W, int C, e4t_stream stream);
+int e4t_spatial_mean(const void* x, float* out, int B, int HW, int C, int ldo, int coff, e4t_stream stream);            /* encoder.py:147 */
+int e4t_spatial_mean_bwd(const float* g, const void* base, void* dx, int B, int HW, int C, int ldg, int coff, e4t_stream stream);
+int e4t_timestep_embedding(const long long* t, void* out /* bf16 [B][dim] = [cos|sin] */, int B, int dim, e4t_stream stream); /* unet_2d_condition.py:461 */
+int e4t_clip_preprocess(const float* pixels_nchw, void* patches /* bf16 [B*g*g][Kpad] */, int B, int Hin, int Win, int S, int P, int Kpad, e4t_stream stream); /* encoder.py:131-139 + patchify */
+int e4t_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, float grad_scale, e4t_stream stream);                                        /* pretrain_e4t.py:387-392,652 */
+int e4t_sumsq_partial(const float* g, long long n, float* partial, int nblocks, e4t_stream stream);                      /* tuning_e4t.py:335 grad-norm */
+
+/* ---------------------------------------------------------------- probe (probe.hip) ---------- */
+/* writes, for lane l and register r of v_mfma_f32_32x32x16_bf16 with A[i][k] = i*16+k... see probe.hip */
+int e4t_probe_mfma_layout(float* out_rows /* [64][16] */, float* out_cols /* [64][16] */, e4t_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E4T_HIP_H */

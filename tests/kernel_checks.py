@@ -1,0 +1,295 @@
+"""Per-kernel parity checks: HIP op (through the C ABI) vs the torch restatement in emu_backend.py,
+on the same seeded inputs.  Each check returns a list of (label, rel_l2_error, tolerance).
+Used by tests/test_kernels_gpu.py (pytest, -m gpu) and tests/gpu_report.py (prints everything).
+
+Tolerances (stated per check): outputs are bf16 (8 mantissa bits, eps = 2^-8 = 3.9e-3) computed from
+bf16 inputs with fp32 accumulation, so the relative L2 error against an fp32 evaluation of the same
+bf16 inputs is bounded by ~eps/sqrt(3) per output rounding (~2.3e-3) plus accumulation-order noise;
+we allow 6e-3 for single-rounding kernels, 1.5e-2 where an intermediate (P, dS) is also rounded to
+bf16 inside the kernel, 1e-5 for fp32-only kernels.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from emu_backend import EmuBackend, CONV_S1, CONV_S2, CONV_UP2, CONV_S2T
+
+bf16, f32 = torch.bfloat16, torch.float32
+TOL1, TOL2, TOLF = 6e-3, 1.5e-2, 2e-5
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    d = (a - b).norm()
+    n = b.norm()
+    if not torch.isfinite(d):
+        return float("inf")
+    return float(d / (n + 1e-20))
+
+
+def rnd(g, *shape, scale=1.0, dtype=bf16, dev="cuda"):
+    return (torch.randn(*shape, generator=g, device=dev, dtype=f32) * scale).to(dtype)
+
+
+def gen(seed, dev="cuda"):
+    return torch.Generator(device=dev).manual_seed(seed)
+
+
+def check_probe(hip, emu, dev):
+    rows, cols = hip.probe_mfma(dev)
+    l = torch.arange(64, device=dev)[:, None]
+    r = torch.arange(16, device=dev)[None, :]
+    exp_rows = ((r & 3) + 8 * (r >> 2) + 4 * (l >> 5) + 1).float()
+    exp_cols = ((l & 31) + 1).float().expand(64, 16)
+    return [("mfma32 row map", rel(rows, exp_rows), 0.0), ("mfma32 col map", rel(cols, exp_cols), 0.0)]
+
+
+def check_gemm(hip, emu, dev):
+    out = []
+    cases = [  # M, N, K, tile, splitk
+        (256, 256, 128, 0, 0), (200, 72, 64, 0, 0), (1000, 320, 320, 128, 1), (130, 200, 1032, 64, 3),
+        (16, 1280, 1280, 0, 0), (4096, 640, 2560, 0, 0), (64, 64, 4096, 0, 0),
+    ]
+    for i, (M, N, K, tile, sk) in enumerate(cases):
+        g = gen(10 + i, dev)
+        a, b = rnd(g, M, K, dev=dev), rnd(g, N, K, scale=K ** -0.5, dev=dev)
+        bias = rnd(g, N, dtype=f32, dev=dev)
+        res = rnd(g, M, N, dev=dev)
+        y = hip.gemm(a, b, bias=bias, residual=res, tile=tile, splitk=sk)
+        yr = emu.gemm(a, b, bias=bias, residual=res)
+        out.append((f"gemm {M}x{N}x{K} t{tile} s{sk} bias+res", rel(y, yr), TOL1))
+    g = gen(30, dev)
+    # two-source A, gelu, fp32 out, accumulate, rowbias
+    M, N, K1, K2 = 384, 192, 128, 64
+    a1, a2, b = rnd(g, M, K1, dev=dev), rnd(g, M, K2, dev=dev), rnd(g, N, K1 + K2, scale=0.07, dev=dev)
+    out.append(("gemm two-source A", rel(hip.gemm(a1, b, a2=a2), emu.gemm(a1, b, a2=a2)), TOL1))
+    out.append(("gemm gelu", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
+    c0 = rnd(g, M, N, dtype=f32, dev=dev)
+    c1, c2 = c0.clone(), c0.clone()
+    hip.gemm(a1, b[:, :K1].contiguous(), out=c1, accum=True, alpha=0.5)
+    emu.gemm(a1, b[:, :K1].contiguous(), out=c2, accum=True, alpha=0.5)
+    out.append(("gemm fp32 out + accumulate + alpha", rel(c1, c2), TOLF * 50))
+    rb = rnd(g, M // 96, N, dtype=f32, dev=dev)
+    out.append(("gemm rowbias", rel(hip.gemm(a1, b[:, :K1].contiguous(), rowbias=rb, rows_per_batch=96),
+                                    emu.gemm(a1, b[:, :K1].contiguous(), rowbias=rb, rows_per_batch=96)), TOL1))
+    # strided views (column slices of a wider buffer)
+    wide = rnd(g, M, 3 * K1, dev=dev)
+    out.append(("gemm strided A view", rel(hip.gemm(wide[:, K1:2 * K1], b[:, :K1].contiguous()), emu.gemm(wide[:, K1:2 * K1], b[:, :K1].contiguous())), TOL1))
+    # batched + reduce-batch (E4T head shape, small)
+    nb, M, N, K = 9, 16, 128, 128
+    A, Bw = rnd(g, nb, M, K, dev=dev), rnd(g, nb, N, K, scale=0.09, dev=dev)
+    bias = rnd(g, nb, N, dtype=f32, dev=dev)
+    out.append(("gemm batched", rel(hip.gemm(A, Bw, bias=bias), emu.gemm(A, Bw, bias=bias)), TOL1))
+    out.append(("gemm batched reduce (mean over slots)", rel(hip.gemm(A, Bw, reduce_batch=True, alpha=1.0 / nb, out_dtype=f32),
+                                                            emu.gemm(A, Bw, reduce_batch=True, alpha=1.0 / nb, out_dtype=f32)), TOLF * 50))
+    Ab = A[0].unsqueeze(0).expand(nb, M, K)   # broadcast operand (stride 0)
+    out.append(("gemm batched broadcast A", rel(hip.gemm(Ab, Bw), emu.gemm(Ab, Bw)), TOL1))
+    return out
+
+
+def check_conv(hip, emu, dev):
+    out = []
+    cases = [  # B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, splitk
+        (2, 16, 16, 64, 64, CONV_S1, 16, 16, 0, 0), (2, 8, 8, 128, 192, CONV_S1, 8, 8, 64, 3),
+        (3, 16, 16, 64, 128, CONV_S2, 8, 8, 0, 0), (2, 9, 9, 64, 64, CONV_S2, 5, 5, 0, 0),
+        (2, 8, 8, 64, 64, CONV_UP2, 16, 16, 0, 0), (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 0, 0),
+        (2, 5, 5, 64, 64, CONV_S2T, 9, 9, 0, 0), (4, 32, 32, 320, 320, CONV_S1, 32, 32, 128, 1),
+        (2, 16, 16, 64, 4, CONV_S1, 16, 16, 0, 0),
+    ]
+    for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
+        g = gen(50 + i, dev)
+        x = rnd(g, B * Hin * Win, Cin, dev=dev)
+        w = rnd(g, Cout, 9 * Cin, scale=(9 * Cin) ** -0.5, dev=dev)
+        bias = rnd(g, Cout, dtype=f32, dev=dev)
+        rb = rnd(g, B, Cout, dtype=f32, dev=dev)
+        res = rnd(g, B * Hout * Wout, Cout, dev=dev)
+        y = hip.conv3x3(x, w, B, Hin, Win, Hout, Wout, mode, bias=bias, rowbias=rb, residual=res, tile=tile, splitk=sk)
+        yr = emu.conv3x3(x, w, B, Hin, Win, Hout, Wout, mode, bias=bias, rowbias=rb, residual=res)
+        out.append((f"conv mode{mode} B{B} {Hin}x{Win} {Cin}->{Cout} t{tile} s{sk}", rel(y, yr), TOL1))
+    # weight relayout + dgrad identity: conv dgrad == autograd of conv
+    g = gen(70, dev)
+    O, I = 96, 64
+    w4 = rnd(g, O, I, 3, 3, scale=0.05, dtype=f32, dev=dev)
+    wf, wd = hip.conv_weight_prepare(w4)
+    wf2, wd2 = emu.conv_weight_prepare(w4)
+    out.append(("conv_weight_prepare fwd layout", rel(wf, wf2), 0.0))
+    out.append(("conv_weight_prepare dgrad layout", rel(wd, wd2), 0.0))
+    return out
+
+
+def check_attention(hip, emu, dev):
+    out = []
+    cases = [  # B, H, T, S, DH
+        (2, 2, 64, 64, 32), (2, 3, 200, 200, 40), (1, 2, 128, 77, 40), (2, 2, 96, 77, 80), (1, 2, 64, 64, 160),
+        (1, 2, 257, 257, 80), (2, 2, 130, 33, 64), (1, 8, 1024, 1024, 40),
+    ]
+    for i, (B, H, T, S, DH) in enumerate(cases):
+        g = gen(90 + i, dev)
+        d = H * DH
+        # q, k, v as column slices of fused buffers (self-attn layout) when T == S, separate otherwise
+        if T == S:
+            qkv = rnd(g, B * T, 3 * d, dev=dev)
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            dqkv_h = torch.zeros_like(qkv); dqkv_e = torch.zeros_like(qkv)
+            gh = (dqkv_h[:, :d], dqkv_h[:, d:2 * d], dqkv_h[:, 2 * d:])
+            ge = (dqkv_e[:, :d], dqkv_e[:, d:2 * d], dqkv_e[:, 2 * d:])
+        else:
+            q = rnd(g, B * T, d, dev=dev)
+            kv = rnd(g, B * S, 2 * d, dev=dev)
+            k, v = kv[:, :d], kv[:, d:]
+            dq_h, dq_e = torch.zeros_like(q), torch.zeros_like(q)
+            dkv_h, dkv_e = torch.zeros_like(kv), torch.zeros_like(kv)
+            gh = (dq_h, dkv_h[:, :d], dkv_h[:, d:]); ge = (dq_e, dkv_e[:, :d], dkv_e[:, d:])
+        scale = DH ** -0.5
+        o, lse = hip.attention_fwd(q, k, v, B, H, T, S, DH, scale)
+        o_r, lse_r = emu.attention_fwd(q, k, v, B, H, T, S, DH, scale)
+        tag = f"attn B{B} H{H} T{T} S{S} dh{DH}"
+        out.append((tag + " fwd O", rel(o, o_r), TOL2))
+        out.append((tag + " fwd LSE", rel(lse, lse_r), 1e-3))
+        do = rnd(g, B * T, d, dev=dev)
+        hip.attention_bwd(q, k, v, o, do, lse, gh[0], gh[1], gh[2], B, H, T, S, DH, scale)
+        emu.attention_bwd(q, k, v, o_r, do, lse_r, ge[0], ge[1], ge[2], B, H, T, S, DH, scale)
+        for nm, a, b in zip(("dQ", "dK", "dV"), gh, ge):
+            out.append((tag + " bwd " + nm, rel(a, b), TOL2))
+    # peaked scores: one key dominates (exercises the online-softmax rescale with large max jumps)
+    g = gen(120, dev)
+    B, H, T, S, DH = 1, 1, 64, 160, 64
+    q, k, v = rnd(g, T, DH, dev=dev), rnd(g, S, DH, dev=dev), rnd(g, S, DH, dev=dev)
+    k[130] = (q[5].float() * 6).to(bf16)
+    o, lse = hip.attention_fwd(q, k, v, B, H, T, S, DH, 1.0)
+    o_r, lse_r = emu.attention_fwd(q, k, v, B, H, T, S, DH, 1.0)
+    out.append(("attn peaked-score fwd", rel(o, o_r), TOL2))
+    return out
+
+
+def check_norms(hip, emu, dev):
+    out = []
+    for i, (B, HW, C1, C2, G, silu) in enumerate([(2, 64, 64, 0, 32, True), (3, 256, 320, 0, 32, True), (2, 100, 320, 640, 32, True),
+                                                  (2, 64, 1280, 1280, 32, False), (16, 4096, 320, 0, 32, True)]):
+        g = gen(140 + i, dev)
+        x1 = rnd(g, B * HW, C1, dev=dev) + 0.3
+        x2 = rnd(g, B * HW, C2, scale=2.0, dev=dev) if C2 else None
+        Cn = C1 + C2
+        gamma, beta = rnd(g, Cn, dtype=f32, dev=dev) * 0.3 + 1.0, rnd(g, Cn, dtype=f32, dev=dev) * 0.2
+        y, st = hip.groupnorm_fwd(x1, x2, gamma, beta, B, HW, G, 1e-5, silu)
+        yr, str_ = emu.groupnorm_fwd(x1, x2, gamma, beta, B, HW, G, 1e-5, silu)
+        tag = f"groupnorm B{B} HW{HW} C{C1}+{C2} silu{int(silu)}"
+        out.append((tag + " fwd", rel(y, yr), TOL1))
+        out.append((tag + " stats", rel(st, str_), 1e-4))
+        dy = rnd(g, B * HW, Cn, dev=dev)
+        add = rnd(g, B * HW, Cn, dev=dev) if i % 2 == 0 else None
+        dx1, dx2, dga, dbe = hip.groupnorm_bwd(x1, x2, dy, str_, gamma, beta, add, B, HW, G, silu, want_param_grads=True)
+        ex1, ex2, ega, ebe = emu.groupnorm_bwd(x1, x2, dy, str_, gamma, beta, add, B, HW, G, silu, want_param_grads=True)
+        out.append((tag + " bwd dx1", rel(dx1, ex1), TOL1))
+        if C2:
+            out.append((tag + " bwd dx2", rel(dx2, ex2), TOL1))
+        out.append((tag + " bwd dgamma", rel(dga, ega), 1e-3))
+        out.append((tag + " bwd dbeta", rel(dbe, ebe), 1e-3))
+    for i, (M, D) in enumerate([(37, 64), (1000, 320), (4112, 1280), (300, 768), (128, 1024)]):
+        g = gen(160 + i, dev)
+        x = rnd(g, M, D, dev=dev) + 0.5
+        gamma, beta = rnd(g, D, dtype=f32, dev=dev) * 0.3 + 1.0, rnd(g, D, dtype=f32, dev=dev) * 0.2
+        y, st = hip.layernorm_fwd(x, gamma, beta, 1e-5)
+        yr, str_ = emu.layernorm_fwd(x, gamma, beta, 1e-5)
+        out.append((f"layernorm {M}x{D} fwd", rel(y, yr), TOL1))
+        out.append((f"layernorm {M}x{D} stats", rel(st, str_), 1e-4))
+        dy = rnd(g, M, D, dev=dev)
+        dx, dga, dbe = hip.layernorm_bwd(x, dy, gamma, str_, want_param_grads=True)
+        ex, ega, ebe = emu.layernorm_bwd(x, dy, gamma, str_, want_param_grads=True)
+        out.append((f"layernorm {M}x{D} bwd dx", rel(dx, ex), TOL1))
+        out.append((f"layernorm {M}x{D} bwd dgamma", rel(dga, ega), 1e-3))
+        out.append((f"layernorm {M}x{D} bwd dbeta", rel(dbe, ebe), 1e-3))
+    return out
+
+
+def check_streaming(hip, emu, dev):
+    out = []
+    g = gen(180, dev)
+    u = rnd(g, 300, 2 * 640, dev=dev)
+    dh = rnd(g, 300, 640, dev=dev)
+    out.append(("geglu fwd", rel(hip.geglu_fwd(u), emu.geglu_fwd(u)), TOL1))
+    out.append(("geglu bwd", rel(hip.geglu_bwd(u, dh), emu.geglu_bwd(u, dh)), TOL1))
+    x, dy = rnd(g, 64, 1280, dev=dev), rnd(g, 64, 1280, dev=dev)
+    for op in range(6):
+        out.append((f"unary op{op}", rel(hip.unary(x, op, dy if op & 1 else None), emu.unary(x, op, dy if op & 1 else None)), TOL1))
+    out.append(("add", rel(hip.add(x, dy), emu.add(x, dy)), TOL1))
+    t = rnd(g, 130, 72, dev=dev)
+    out.append(("transpose", rel(hip.transpose(t), emu.transpose(t)), 0.0))
+    out.append(("transpose padded + strided in", rel(hip.transpose(u[:, 8:80], pad_to=320), emu.transpose(u[:, 8:80], pad_to=320)), 0.0))
+    xx = rnd(g, 2 * 16 * 16, 64, dev=dev)
+    out.append(("sumpool2", rel(hip.sumpool2(xx, 2, 8, 8), emu.sumpool2(xx, 2, 8, 8)), TOL1))
+    o1 = torch.zeros(2, 200, dtype=f32, device=dev); o2 = torch.zeros_like(o1)
+    hip.spatial_mean(xx, 2, 256, o1, 100); emu.spatial_mean(xx, 2, 256, o2, 100)
+    out.append(("spatial_mean", rel(o1, o2), TOLF))
+    gg = rnd(g, 2, 200, dtype=f32, dev=dev)
+    out.append(("spatial_mean_bwd", rel(hip.spatial_mean_bwd(gg, xx, 2, 256, 64, 100), emu.spatial_mean_bwd(gg, xx, 2, 256, 64, 100)), TOL1))
+    ts = torch.tensor([0, 1, 17, 500, 999], device=dev)
+    out.append(("timestep_embedding", rel(hip.timestep_embedding(ts, 320), emu.timestep_embedding(ts, 320)), TOL1))
+    px = torch.rand(2, 3, 512, 512, generator=g, device=dev) * 2 - 1
+    out.append(("clip_preprocess 512->224 p14", rel(hip.clip_preprocess(px, 224, 14, 640), emu.clip_preprocess(px, 224, 14, 640)), TOL1))
+    px = torch.rand(2, 3, 64, 64, generator=g, device=dev) * 2 - 1
+    out.append(("clip_preprocess 64->28 p14", rel(hip.clip_preprocess(px, 28, 14, 640), emu.clip_preprocess(px, 28, 14, 640)), TOL1))
+    n = 100003
+    p = rnd(g, n, dtype=f32, dev=dev); gr = rnd(g, n, dtype=f32, dev=dev); m = rnd(g, n, dtype=f32, dev=dev) * 0.1; v = rnd(g, n, dtype=f32, dev=dev).abs() * 0.01
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    hip.adamw(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3, 0.5)
+    emu.adamw(p2, gr, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3, 0.5)
+    out += [("adamw p", rel(p, p2), TOLF), ("adamw m", rel(m, m2), TOLF), ("adamw v", rel(v, v2), TOLF)]
+    out.append(("sumsq", rel(hip.sumsq(gr), emu.sumsq(gr)), 1e-4))
+    return out
+
+
+def make_wo_entry(g, row, col, dev, ops_mod, with_gW=False, ld_pad=0):
+    WOEntry = ops_mod.WOEntry
+    s = lambda *sh, sc=1.0: rnd(g, *sh, scale=sc, dtype=f32, dev=dev)
+    params = dict(v=torch.full((1,), 0.8, device=dev), w1=s(row, 1, sc=0.5), b1=s(row, sc=0.5), w2=s(col, 1, sc=0.5), b2=s(col, sc=0.5),
+                  wc=s(row, row, sc=row ** -0.5), bc=s(row, sc=0.1), wr=s(col, col, sc=col ** -0.5), br=s(col, sc=0.1))
+    grads = {"g_" + k: torch.zeros_like(v) for k, v in params.items()}
+    W = s(col, row, sc=row ** -0.5)
+    weff = torch.zeros(col, row + ld_pad, dtype=bf16, device=dev)
+    weffT = torch.zeros(row, col + ld_pad, dtype=bf16, device=dev)
+    dweff = s(col, row + ld_pad)
+    return WOEntry(row=row, col=col, W=W, params=params, weff=weff, weffT=weffT, dweff=dweff, grads=grads,
+                   g_W=torch.zeros_like(W) if with_gW else None)
+
+
+def check_wo(hip, emu, dev, ops_mod):
+    import copy
+    out = []
+    g = gen(200, dev)
+    dims = [(64, 64), (96, 160), (320, 320), (768, 320), (1280, 1280)]
+    ents = [make_wo_entry(g, r, c, dev, ops_mod, with_gW=(i == 1), ld_pad=(8 if i == 2 else 0)) for i, (r, c) in enumerate(dims)]
+    ents2 = copy.deepcopy(ents)
+    th, te = ops_mod.WOTable(ents), ops_mod.WOTable(ents2)
+    hip.wo_forward(th); emu.wo_forward(te)
+    for (r, c), a, b in zip(dims, ents, ents2):
+        out.append((f"wo fwd W_eff {r}->{c}", rel(a.weff, b.weff), TOL1))
+        out.append((f"wo fwd W_eff^T {r}->{c}", rel(a.weffT, b.weffT), TOL1))
+    hip.wo_backward(th, False); emu.wo_backward(te, False)
+    for (r, c), a, b in zip(dims, ents, ents2):
+        for k in a.grads:
+            out.append((f"wo bwd {k} {r}->{c}", rel(a.grads[k], b.grads[k]), 2e-4))
+        if a.g_W is not None:
+            out.append((f"wo bwd g_W {r}->{c}", rel(a.g_W, b.g_W), 2e-4))
+    hip.wo_backward(th, True); emu.wo_backward(te, True)
+    out.append(("wo bwd accumulate g_wc", rel(ents[2].grads["g_wc"], ents2[2].grads["g_wc"]), 2e-4))
+    # plain weights (cast + transpose only)
+    W = rnd(g, 200, 136, dtype=f32, dev=dev)
+    e1 = ops_mod.WOEntry(row=136, col=200, W=W, weff=torch.zeros(200, 136, dtype=bf16, device=dev), weffT=torch.zeros(136, 200, dtype=bf16, device=dev))
+    e2 = copy.deepcopy(e1)
+    hip.weight_prepare(ops_mod.WOTable([e1])); emu.weight_prepare(ops_mod.WOTable([e2]))
+    out.append(("weight_prepare cast", rel(e1.weff, e2.weff), 0.0))
+    out.append(("weight_prepare transpose", rel(e1.weffT, e2.weffT), 0.0))
+    return out
+
+
+def all_checks(hip, emu, dev, ops_mod):
+    yield "probe", lambda: check_probe(hip, emu, dev)
+    yield "gemm", lambda: check_gemm(hip, emu, dev)
+    yield "conv", lambda: check_conv(hip, emu, dev)
+    yield "attention", lambda: check_attention(hip, emu, dev)
+    yield "norms", lambda: check_norms(hip, emu, dev)
+    yield "streaming", lambda: check_streaming(hip, emu, dev)
+    yield "wo", lambda: check_wo(hip, emu, dev, ops_mod)
