@@ -1,0 +1,413 @@
+"""Autograd glue between torch's graph and the HIP kernels: one ``torch.autograd.Function`` per
+kernel family.  Forward and backward both call ``ops.backend()`` (the C ABI); nothing here
+computes on tensors with torch except trivial bias-gradient row sums.
+
+Activations are NHWC matrices: a feature map is a 2-D tensor [B*H*W, C] plus its (B, H, W) carried
+in Python; tokens of a transformer block are the same matrix (no NCHW<->NLC permutes exist).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _C, ops
+
+f32 = torch.float32
+
+
+def act_dtype():
+    return ops.ACT
+
+
+# ----------------------------------------------------------------------------------------------
+# prepared (compute-dtype) copies of fp32 master weights
+# ----------------------------------------------------------------------------------------------
+class PreparedLinear:
+    """bf16 [N,K] and transposed [K,N] copies of an fp32 nn.Linear / 1x1-conv weight.
+    Re-cast only when the master weight changed (frozen weights: exactly once)."""
+
+    def __init__(self, weight: torch.nn.Parameter):
+        self.weight = weight
+        self.key = None
+        self.w = self.wT = None
+
+    def get(self):
+        wt = self.weight
+        key = (wt._version, ops.weights_epoch(), wt.data_ptr(), wt.device)
+        if key != self.key:
+            W = wt.detach().reshape(wt.shape[0], -1)
+            N, K = W.shape
+            Kp = (K + 7) // 8 * 8          # pad K so that rows stay 16-B aligned (e.g. ViT patch embed 588 -> 592)
+            Np = (N + 7) // 8 * 8
+            self.w = torch.zeros((N, Kp), dtype=act_dtype(), device=W.device)
+            self.wT = torch.zeros((K, Np), dtype=act_dtype(), device=W.device)
+            e = ops.WOEntry(row=K, col=N, W=W.float().contiguous(), weff=self.w, weffT=self.wT)
+            if K % 4 or N % 4:
+                self.w[:, :K] = W.to(act_dtype()); self.wT[:, :N] = W.t().to(act_dtype())   # odd shapes (never on the hot path)
+            else:
+                ops.backend().weight_prepare(ops.WOTable([e]))
+            self.key = key
+        return self.w, self.wT
+
+
+class PreparedConv:
+    """bf16 [O][3][3][Ipad] (forward) and [I][3][3][Opad] (dgrad, taps flipped) copies of an OIHW fp32 weight."""
+
+    def __init__(self, weight: torch.nn.Parameter):
+        self.weight = weight
+        self.key = None
+        self.wf = self.wd = None
+
+    def get(self):
+        wt = self.weight
+        key = (wt._version, ops.weights_epoch(), wt.data_ptr(), wt.device)
+        if key != self.key:
+            self.wf, self.wd = ops.backend().conv_weight_prepare(wt.detach())
+            self.key = key
+        return self.wf, self.wd
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _weight_grad(dy, x, x2=None):
+    """dW[N, K] = dy^T . x  (fp32) via two transposes + one NT GEMM whose contraction runs over the rows."""
+    be = ops.backend()
+    M = dy.shape[0]
+    dyT = be.transpose(dy, pad_to=_pad8(M))
+    xT = be.transpose(x, pad_to=_pad8(M))
+    if x2 is not None:
+        xT = torch.cat([xT, be.transpose(x2, pad_to=_pad8(M))], dim=0)
+    return be.gemm(dyT, xT, out_dtype=f32)
+
+
+# ----------------------------------------------------------------------------------------------
+# Linear / 1x1 conv:  y = act(x W^T + b) + residual
+# ----------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, x2, prep: PreparedLinear, gelu: bool, out_f32: bool):
+        be = ops.backend()
+        w, wT = prep.get()
+        K = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+        wv = w[:, :K] if w.shape[1] != K else w
+        y = be.gemm(x, wv, a2=x2, bias=bias, residual=residual, gelu=gelu, out_dtype=f32 if out_f32 else act_dtype())
+        ctx.prep, ctx.gelu = prep, gelu
+        ctx.N = weight.shape[0]
+        need_w = weight.requires_grad
+        ctx.save_for_backward(x if need_w else None, x2 if need_w else None)
+        ctx.k1 = x.shape[1]
+        ctx.has = (bias is not None, residual is not None, x2 is not None)
+        ctx.res_dtype = residual.dtype if residual is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.gelu:
+            raise NotImplementedError("LinearFn: backward through the fused GELU epilogue (frozen ViT only)")
+        be = ops.backend()
+        x, x2 = ctx.saved_tensors
+        has_bias, has_res, has_x2 = ctx.has
+        _, wT = ctx.prep.get()
+        N = ctx.N
+        dyb = dy if dy.dtype == act_dtype() else dy.to(act_dtype())
+        dyb = dyb.contiguous()
+        dx = dw = db = dres = dx2 = None
+        wTn = wT[:, :N] if wT.shape[1] != N else wT
+        if ctx.needs_input_grad[0]:
+            dx = be.gemm(dyb, wTn[: ctx.k1])
+        if has_x2 and ctx.needs_input_grad[4]:
+            dx2 = be.gemm(dyb, wTn[ctx.k1:])
+        if ctx.needs_input_grad[1]:
+            dw = _weight_grad(dyb, x, x2).reshape(ctx.prep.weight.shape)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum(0)
+        if has_res and ctx.needs_input_grad[3]:
+            dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
+        return dx, dw, db, dres, dx2, None, None, None
+
+
+def linear(x, weight, bias, prep, residual=None, x2=None, gelu=False, out_f32=False):
+    return LinearFn.apply(x, weight, bias, residual, x2, prep, gelu, out_f32)
+
+
+# ----------------------------------------------------------------------------------------------
+# Weight-offset modulated projections (cross_attention.py:506,516,518)
+# ----------------------------------------------------------------------------------------------
+class WOSlot:
+    """One (possibly fused q|k|v) projection: views into its bank's W_eff / W_eff^T / dW_eff buffers."""
+
+    def __init__(self, weff, weffT, dweff):
+        self.weff, self.weffT, self.dweff = weff, weffT, dweff
+        self.dweff_valid = False
+
+
+class WOLinearFn(torch.autograd.Function):
+    """y = x . W_eff^T with W_eff = W o (1 + WO()) prepared by the bank; the backward accumulates
+    dW_eff into the bank's fp32 buffer (both UNet passes land in the same buffer) and leaves the
+    weight-offset parameter gradients to the bank's own backward node (reached through `token`)."""
+
+    @staticmethod
+    def forward(ctx, x, token, slot: WOSlot):
+        y = ops.backend().gemm(x, slot.weff)
+        ctx.slot = slot
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        (x,) = ctx.saved_tensors
+        slot = ctx.slot
+        dy = dy.contiguous()
+        dx = be.gemm(dy, slot.weffT) if ctx.needs_input_grad[0] else None
+        M = dy.shape[0]
+        dyT = be.transpose(dy, pad_to=_pad8(M))
+        xT = be.transpose(x, pad_to=_pad8(M))
+        be.gemm(dyT, xT, out=slot.dweff, accum=slot.dweff_valid)
+        slot.dweff_valid = True
+        return dx, torch.zeros_like(ctx.saved_tensors[0][:1, :1], dtype=f32).reshape(1) if False else _zero_token(dy.device), None
+
+
+_ZERO_TOKENS = {}
+
+
+def _zero_token(device):
+    t = _ZERO_TOKENS.get(device)
+    if t is None:
+        t = torch.zeros(1, dtype=f32, device=device)
+        _ZERO_TOKENS[device] = t
+    return t
+
+
+class WOBankFn(torch.autograd.Function):
+    """Autograd node of a weight-offset bank.  forward: one grouped launch evaluates every W_eff of the
+    bank; backward (runs after every consumer of `token` has accumulated its dW_eff): one grouped
+    launch turns the dW_eff buffers into the gradients of all nine parameters of every instance,
+    written straight into the parameters' .grad storage."""
+
+    @staticmethod
+    def forward(ctx, root, bank):
+        bank._run_forward()
+        ctx.bank = bank
+        return torch.zeros(1, dtype=f32, device=root.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.bank._run_backward()
+        return None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# 3x3 convolution (implicit GEMM) — ResnetBlock2D convs, Downsample2D, Upsample2D, conv_in/out
+# ----------------------------------------------------------------------------------------------
+class ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, rowbias, residual, prep: PreparedConv, geom, mode: int, out_f32: bool):
+        B, Hin, Win, Hout, Wout = geom
+        wf, _ = prep.get()
+        y = ops.backend().conv3x3(x, wf, B, Hin, Win, Hout, Wout, mode, bias=bias, rowbias=rowbias, residual=residual,
+                                  out_dtype=f32 if out_f32 else act_dtype())
+        ctx.prep, ctx.geom, ctx.mode = prep, geom, mode
+        ctx.cin = x.shape[1]
+        ctx.has = (bias is not None, rowbias is not None, residual is not None)
+        ctx.res_dtype = residual.dtype if residual is not None else None
+        if weight.requires_grad:
+            raise NotImplementedError("ConvFn: 3x3 weight gradients (tuning mode) are not built yet")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        be = ops.backend()
+        B, Hin, Win, Hout, Wout = ctx.geom
+        has_bias, has_rb, has_res = ctx.has
+        dyb = dy if dy.dtype == act_dtype() else dy.to(act_dtype())
+        dyb = dyb.contiguous()
+        cout = dyb.shape[1]
+        dx = db = drb = dres = None
+        if ctx.needs_input_grad[0]:
+            _, wd = ctx.prep.get()
+            opad = wd.shape[1] // 9
+            if opad != cout:   # conv_out: Cout = 4 padded to 64 in the dgrad weight layout
+                t = torch.zeros((dyb.shape[0], opad), dtype=dyb.dtype, device=dyb.device)
+                t[:, :cout] = dyb
+                dyb_p = t
+            else:
+                dyb_p = dyb
+            if ctx.mode == _C.CONV_S1:
+                dx = be.conv3x3(dyb_p, wd, B, Hout, Wout, Hin, Win, _C.CONV_S1)
+            elif ctx.mode == _C.CONV_S2:
+                dx = be.conv3x3(dyb_p, wd, B, Hout, Wout, Hin, Win, _C.CONV_S2T)
+            else:  # UP2: dgrad at the upsampled resolution, then fold the 2x2 replicas
+                up = be.conv3x3(dyb_p, wd, B, Hout, Wout, Hout, Wout, _C.CONV_S1)
+                dx = be.sumpool2(up, B, Hin, Win)
+            if dx.shape[1] != ctx.cin:
+                dx = dx[:, : ctx.cin].contiguous()
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum(0)
+        if has_rb and ctx.needs_input_grad[3]:
+            drb = torch.zeros((B, cout), dtype=f32, device=dy.device)
+            be.spatial_mean(dyb, B, Hout * Wout, drb, 0)
+            drb = drb * float(Hout * Wout)
+        if has_res and ctx.needs_input_grad[4]:
+            dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
+        return dx, None, db, drb, dres, None, None, None, None
+
+
+def conv3x3(x, weight, bias, prep, geom, mode=_C.CONV_S1, rowbias=None, residual=None, out_f32=False):
+    return ConvFn.apply(x, weight, bias, rowbias, residual, prep, geom, mode, out_f32)
+
+
+# ----------------------------------------------------------------------------------------------
+# norms
+# ----------------------------------------------------------------------------------------------
+class GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, gamma, beta, B, HW, G, eps, silu):
+        y, stats = ops.backend().groupnorm_fwd(x1, x2, gamma, beta, B, HW, G, eps, silu)
+        ctx.save_for_backward(x1, x2, stats, gamma, beta)
+        ctx.cfg = (B, HW, G, silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, stats, gamma, beta = ctx.saved_tensors
+        B, HW, G, silu = ctx.cfg
+        wp = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        dx1, dx2, dg, db = ops.backend().groupnorm_bwd(x1, x2, dy.contiguous(), stats, gamma, beta, None, B, HW, G, silu, want_param_grads=wp)
+        return dx1, dx2, dg, db, None, None, None, None, None
+
+
+def group_norm(x1, x2, gamma, beta, B, HW, G, eps, silu):
+    return GroupNormFn.apply(x1, x2, gamma, beta, B, HW, G, eps, silu)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, stats = ops.backend().layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, stats, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats, gamma = ctx.saved_tensors
+        wp = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dg, db = ops.backend().layernorm_bwd(x, dy.contiguous(), gamma, stats, want_param_grads=wp)
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------
+class AttentionFn(torch.autograd.Function):
+    """self: qkv = [B*T, 3d] (q | k | v column blocks), kv = None.  cross: qkv = q [B*T, d], kv = [B*S, 2d]."""
+
+    @staticmethod
+    def forward(ctx, qkv, kv, B, H, T, S, DH, scale):
+        d = H * DH
+        if kv is None:
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        else:
+            q, k, v = qkv, kv[:, :d], kv[:, d:]
+        o, lse = ops.backend().attention_fwd(q, k, v, B, H, T, S, DH, scale)
+        ctx.save_for_backward(qkv, kv, o, lse)
+        ctx.cfg = (B, H, T, S, DH, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, kv, o, lse = ctx.saved_tensors
+        B, H, T, S, DH, scale = ctx.cfg
+        d = H * DH
+        dqkv = torch.empty_like(qkv)
+        dkv = torch.empty_like(kv) if kv is not None else None
+        if kv is None:
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+        else:
+            q, k, v = qkv, kv[:, :d], kv[:, d:]
+            dq, dk, dv = dqkv, dkv[:, :d], dkv[:, d:]
+        ops.backend().attention_bwd(q, k, v, o, do.contiguous(), lse, dq, dk, dv, B, H, T, S, DH, scale)
+        return dqkv, dkv, None, None, None, None, None, None
+
+
+def attention(qkv, kv, B, H, T, S, DH, scale):
+    return AttentionFn.apply(qkv, kv, B, H, T, S, DH, scale)
+
+
+# ----------------------------------------------------------------------------------------------
+# streaming ops
+# ----------------------------------------------------------------------------------------------
+class GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u):
+        ctx.save_for_backward(u)
+        return ops.backend().geglu_fwd(u)
+
+    @staticmethod
+    def backward(ctx, dh):
+        (u,) = ctx.saved_tensors
+        return ops.backend().geglu_bwd(u, dh.contiguous())
+
+
+def geglu(u):
+    return GegluFn.apply(u)
+
+
+class UnaryFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        ctx.save_for_backward(x)
+        ctx.op = op
+        return ops.backend().unary(x, op)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.backend().unary(x, ctx.op + 1, dy.contiguous()), None
+
+
+def silu(x):
+    return UnaryFn.apply(x, _C.OP_SILU)
+
+
+def leaky_relu(x):
+    return UnaryFn.apply(x, _C.OP_LRELU)
+
+
+class SpatialMeanFn(torch.autograd.Function):
+    """cat([m.mean(dim=(2,3)) for m in maps], -1) for NHWC maps given as [B*HW, C] matrices (encoder.py:147-148)."""
+
+    @staticmethod
+    def forward(ctx, B, *maps):
+        be = ops.backend()
+        total = sum(m.shape[1] for m in maps)
+        out = torch.empty((B, total), dtype=f32, device=maps[0].device)
+        off, meta = 0, []
+        for m in maps:
+            hw = m.shape[0] // B
+            be.spatial_mean(m, B, hw, out, off)
+            meta.append((hw, m.shape[1], off))
+            off += m.shape[1]
+        ctx.meta, ctx.B = meta, B
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        be = ops.backend()
+        g = g.contiguous().float()
+        outs = []
+        for i, (hw, c, off) in enumerate(ctx.meta):
+            outs.append(be.spatial_mean_bwd(g, None, ctx.B, hw, c, off) if ctx.needs_input_grad[1 + i] else None)
+        return (None, *outs)
+
+
+def spatial_mean_cat(B, maps):
+    return SpatialMeanFn.apply(B, *maps)

@@ -19,6 +19,23 @@ from . import _C
 bf16 = torch.bfloat16
 f32 = torch.float32
 
+# Storage dtype of activations and compute copies of weights.  bf16 in the product (the HIP kernels
+# accept nothing else); tests that drive the host logic through the fp32 emulation set it to fp32.
+ACT = bf16
+
+_WEIGHTS_EPOCH = 0
+
+
+def weights_epoch() -> int:
+    """Bumped whenever master weights were updated behind autograd's back (our fused AdamW writes
+    through raw pointers, which does not touch tensor._version)."""
+    return _WEIGHTS_EPOCH
+
+
+def bump_weights_epoch():
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
