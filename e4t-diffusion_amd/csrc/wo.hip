@@ -88,9 +88,15 @@ __global__ __launch_bounds__(256) void wo_apply_kernel(const e4t_wo_desc* descs)
       if (has_wo) {
         const float bcv = V_b(d)[c], scv = V_s(d)[c], brv = d.br[c];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] *= 1.f + V_a(d)[r + j] * bcv + d.bc[r + j] * scv + brv;
+        for (int j = 0; j < 4; ++j) {
+          const float off = V_a(d)[r + j] * bcv + d.bc[r + j] * scv + brv;
+          o[j] = (d.mode & E4T_WO_OFFSETS_ONLY) ? off : o[j] * (1.f + off);
+        }
       }
-      if (d.weff) *(uint2*)((bf16_t*)d.weff + (size_t)c * d.ld_weff + r) = pack4(o);
+      if (d.weff) {
+        if (d.mode & E4T_WO_STORE_F32) *(float4*)((float*)d.weff + (size_t)c * d.ld_weff + r) = make_float4(o[0], o[1], o[2], o[3]);
+        else *(uint2*)((bf16_t*)d.weff + (size_t)c * d.ld_weff + r) = pack4(o);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) tile[cl][tx * 4 + j] = f2bf(o[j]);

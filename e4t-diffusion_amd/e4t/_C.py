@@ -39,7 +39,7 @@ class WODesc(C.Structure):
     _fields_ = (
         [(n, vp) for n in ("v", "w1", "b1", "w2", "b2", "wc", "bc", "wr", "br", "W", "vecs", "partial", "weff", "weffT", "dweff")]
         + [(n, vp) for n in ("g_v", "g_w1", "g_b1", "g_w2", "g_b2", "g_wc", "g_bc", "g_wr", "g_br", "g_W")]
-        + [(n, i32) for n in ("row", "col", "ld_weff", "ld_weffT", "ld_dweff", "_pad")]
+        + [(n, i32) for n in ("row", "col", "ld_weff", "ld_weffT", "ld_dweff", "mode")]
     )
 
 
@@ -86,6 +86,7 @@ SIGNATURES = {
 # flag / enum mirrors of the header
 OUT_F32, RES_F32, ACT_GELU, ACCUM, REDUCE_BATCH = 1, 2, 4, 8, 16
 CONV_S1, CONV_S2, CONV_UP2, CONV_S2T = 1, 2, 3, 4
+WO_STORE_F32, WO_OFFSETS_ONLY = 1, 2
 OP_SILU, OP_SILU_BWD, OP_GELU, OP_GELU_BWD, OP_LRELU, OP_LRELU_BWD = range(6)
 
 _lib = None

@@ -214,12 +214,13 @@ class ConvFn(torch.autograd.Function):
         ctx.cin = x.shape[1]
         ctx.has = (bias is not None, rowbias is not None, residual is not None)
         ctx.res_dtype = residual.dtype if residual is not None else None
-        if weight.requires_grad:
-            raise NotImplementedError("ConvFn: 3x3 weight gradients (tuning mode) are not built yet")
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("ConvFn: 3x3 weight gradients (tuning mode) are not built yet; "
+                                      "freeze the conv weights (pretrain never reads their gradients)")
         be = ops.backend()
         B, Hin, Win, Hout, Wout = ctx.geom
         has_bias, has_rb, has_res = ctx.has

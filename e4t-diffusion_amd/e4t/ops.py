@@ -81,6 +81,7 @@ class WOEntry:
     g_W: Optional[torch.Tensor] = None
     vecs: Optional[torch.Tensor] = None
     partial: Optional[torch.Tensor] = None
+    mode: int = 0                        # _C.WO_STORE_F32 | _C.WO_OFFSETS_ONLY
 
 
 @dataclass
@@ -366,7 +367,7 @@ class HipBackend:
             if e.grads is not None:
                 for k in ("g_v", "g_w1", "g_b1", "g_w2", "g_b2", "g_wc", "g_bc", "g_wr", "g_br"):
                     setattr(d, k, _ptr(e.grads[k]))
-            d.row, d.col = e.row, e.col
+            d.row, d.col, d.mode = e.row, e.col, e.mode
             d.ld_weff = e.weff.stride(0) if e.weff is not None else 0
             d.ld_weffT = e.weffT.stride(0) if e.weffT is not None else 0
             d.ld_dweff = e.dweff.stride(0) if e.dweff is not None else 0

@@ -129,6 +129,8 @@ int e4t_layernorm_param_grad(const void* x, const void* dy, const float* mean_rs
 /* One descriptor per WeightOffsets instance (weightoffsets.py:5-23) + the projection weight it
  * modulates (cross_attention.py:506,516,518).  row = in_features, col = out_features.
  * Descriptors live in DEVICE memory (array of n); wc == NULL marks a plain weight (cast only). */
+#define E4T_WO_STORE_F32 1    /* weff is fp32 [col][ld_weff] instead of bf16 */
+#define E4T_WO_OFFSETS_ONLY 2 /* weff receives the offsets themselves (WeightOffsets.forward()), not W o (1+offsets) */
 typedef struct {
   const float *v, *w1, *b1, *w2, *b2, *wc, *bc, *wr, *br; /* v[1] linear1.{w,b}[row] linear2.{w,b}[col] linear_column[row][row],[row] linear_row[col][col],[col] */
   const float* W;        /* base weight fp32 [col][row] */
@@ -139,7 +141,8 @@ typedef struct {
   const float* dweff;    /* in (backward): fp32 [col][ld_dweff] dL/dW_eff */
   float *g_v, *g_w1, *g_b1, *g_w2, *g_b2, *g_wc, *g_bc, *g_wr, *g_br; /* out (backward): parameter grads */
   float* g_W;            /* out (backward, optional): dL/dW = dW_eff o (1 + offsets) */
-  int row, col, ld_weff, ld_weffT, ld_dweff, _pad;
+  int row, col, ld_weff, ld_weffT, ld_dweff;
+  int mode;              /* E4T_WO_* bits */
 } e4t_wo_desc;
 size_t e4t_wo_vecs_floats(int row, int col);
 size_t e4t_wo_partial_floats(int row, int col);

@@ -305,7 +305,7 @@ class EmuBackend:
             W = e.W.float()
             if e.params is not None:
                 out, _ = self._wo_out(e)
-                W = W * (1 + out)
+                W = out if (getattr(e, "mode", 0) & 2) else W * (1 + out)
             if e.weff is not None:
                 e.weff[:, : e.row].copy_(W.to(e.weff.dtype))
             if e.weffT is not None:
