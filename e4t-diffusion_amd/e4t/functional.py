@@ -121,7 +121,11 @@ class LinearFn(torch.autograd.Function):
         if has_x2 and ctx.needs_input_grad[4]:
             dx2 = be.gemm(dyb, wTn[ctx.k1:])
         if ctx.needs_input_grad[1]:
-            dw = _weight_grad(dyb, x, x2).reshape(ctx.prep.weight.shape)
+            dw = _weight_grad(dyb, x, x2)
+            kw = ctx.prep.weight[0].numel()          # true K (x may carry zero pad columns, e.g. patch-embed 588 -> 592)
+            if dw.shape[1] != kw:
+                dw = dw[:, :kw].contiguous()
+            dw = dw.reshape(ctx.prep.weight.shape)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(0)
         if has_res and ctx.needs_input_grad[3]:
