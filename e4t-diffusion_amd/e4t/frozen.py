@@ -1,0 +1,193 @@
+"""The two FROZEN components inside the training step that SURVEY.md §2 marks out of the hot-path
+scope (#8 CLIP text encoder, #15 VAE encoder; "next" rows N3 / N1 of §8f).  They run on stock
+PyTorch-ROCm ops (bf16, on the GPU) exactly as the reference runs them through transformers /
+diffusers — they are NOT part of the hand-written kernel path and are reported separately in the
+bench.  Module / parameter names follow the HF checkpoints (CLIPTextModel, AutoencoderKL.encoder) so real
+weights load by key; here they are randomly initialised (no network).
+
+CLIPTextModel accepts ``inputs_embeds`` like the reference's patched class
+(e4t/models/modeling_clip.py:9-82) — the installed transformers 5.x no longer has the internals that file
+monkey-patches, so an equivalent is needed anyway.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+CLIP_TEXT_L = dict(vocab_size=49409, hidden_size=768, num_layers=12, num_heads=12, intermediate_size=3072, max_len=77, act="quick_gelu")
+CLIP_TEXT_H = dict(vocab_size=49409, hidden_size=1024, num_layers=23, num_heads=16, intermediate_size=4096, max_len=77, act="gelu")
+
+
+class _SelfAttn(nn.Module):
+    def __init__(self, w, heads):
+        super().__init__()
+        self.heads = heads
+        self.q_proj, self.k_proj, self.v_proj, self.out_proj = (nn.Linear(w, w) for _ in range(4))
+
+    def forward(self, x):
+        b, s, w = x.shape
+        sp = lambda t: t.view(b, s, self.heads, w // self.heads).transpose(1, 2)
+        o = F.scaled_dot_product_attention(sp(self.q_proj(x)), sp(self.k_proj(x)), sp(self.v_proj(x)), is_causal=True)
+        return self.out_proj(o.transpose(1, 2).reshape(b, s, w))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, w, inter, act):
+        super().__init__()
+        self.fc1, self.fc2, self.act = nn.Linear(w, inter), nn.Linear(inter, w), act
+
+    def forward(self, x):
+        h = self.fc1(x)
+        h = h * torch.sigmoid(1.702 * h) if self.act == "quick_gelu" else F.gelu(h)
+        return self.fc2(h)
+
+
+class _Layer(nn.Module):
+    def __init__(self, w, heads, inter, act):
+        super().__init__()
+        self.self_attn = _SelfAttn(w, heads)
+        self.layer_norm1 = nn.LayerNorm(w)
+        self.mlp = _Mlp(w, inter, act)
+        self.layer_norm2 = nn.LayerNorm(w)
+
+    def forward(self, x):
+        x = x + self.self_attn(self.layer_norm1(x))
+        return x + self.mlp(self.layer_norm2(x))
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, vocab, w, max_len):
+        super().__init__()
+        self.token_embedding = nn.Embedding(vocab, w)
+        self.position_embedding = nn.Embedding(max_len, w)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, w, layers, heads, inter, act):
+        super().__init__()
+        self.layers = nn.ModuleList([_Layer(w, heads, inter, act) for _ in range(layers)])
+
+
+class _TextTransformer(nn.Module):
+    def __init__(self, vocab_size, hidden_size, num_layers, num_heads, intermediate_size, max_len, act):
+        super().__init__()
+        self.embeddings = _Embeddings(vocab_size, hidden_size, max_len)
+        self.encoder = _Encoder(hidden_size, num_layers, num_heads, intermediate_size, act)
+        self.final_layer_norm = nn.LayerNorm(hidden_size)
+
+
+class CLIPTextModel(nn.Module):
+    def __init__(self, **cfg):
+        super().__init__()
+        cfg = dict(CLIP_TEXT_L, **cfg)
+        self.config = cfg
+        self.text_model = _TextTransformer(**cfg)
+
+    def get_input_embeddings(self):
+        return self.text_model.embeddings.token_embedding
+
+    def forward(self, input_ids=None, inputs_embeds=None):
+        tm = self.text_model
+        if inputs_embeds is None:
+            inputs_embeds = tm.embeddings.token_embedding(input_ids)
+        s = inputs_embeds.shape[1]
+        x = inputs_embeds + tm.embeddings.position_embedding.weight[:s]
+        for l in tm.encoder.layers:
+            x = l(x)
+        return (tm.final_layer_norm(x),)
+
+
+# ------------------------------------------------------------------------------------------------
+class _VRes(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, cin, eps=1e-6)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = nn.GroupNorm(32, cout, eps=1e-6)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv2(F.silu(self.norm2(h)))
+        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
+
+
+class _VDown(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))
+
+
+class _VDownBlock(nn.Module):
+    def __init__(self, cin, cout, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([_VRes(cin, cout), _VRes(cout, cout)])
+        self.downsamplers = nn.ModuleList([_VDown(cout)]) if down else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return self.downsamplers[0](x) if self.downsamplers is not None else x
+
+
+class _VAttn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(32, c, eps=1e-6)
+        self.query, self.key, self.value, self.proj_attn = (nn.Linear(c, c) for _ in range(4))
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        t = self.group_norm(x).view(b, c, h * w).transpose(1, 2)
+        o = F.scaled_dot_product_attention(self.query(t)[:, None], self.key(t)[:, None], self.value(t)[:, None])[:, 0]
+        return self.proj_attn(o).transpose(1, 2).reshape(b, c, h, w) + x
+
+
+class _VMid(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.resnets = nn.ModuleList([_VRes(c, c), _VRes(c, c)])
+        self.attentions = nn.ModuleList([_VAttn(c)])
+
+    def forward(self, x):
+        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
+
+
+class _VEncoder(nn.Module):
+    def __init__(self, boc, latent):
+        super().__init__()
+        self.conv_in = nn.Conv2d(3, boc[0], 3, padding=1)
+        blocks, c = [], boc[0]
+        for i, co in enumerate(boc):
+            blocks.append(_VDownBlock(c, co, i < len(boc) - 1))
+            c = co
+        self.down_blocks = nn.ModuleList(blocks)
+        self.mid_block = _VMid(c)
+        self.conv_norm_out = nn.GroupNorm(32, c, eps=1e-6)
+        self.conv_out = nn.Conv2d(c, 2 * latent, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for b in self.down_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
+class VAEEncoder(nn.Module):
+    """AutoencoderKL.encode(x).latent_dist.sample() * scaling_factor  (pretrain_e4t.py:598-599)."""
+
+    def __init__(self, block_out_channels=(128, 256, 512, 512), latent_channels=4, scaling_factor=0.18215):
+        super().__init__()
+        self.scaling_factor = scaling_factor
+        self.encoder = _VEncoder(tuple(block_out_channels), latent_channels)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
+
+    @torch.no_grad()
+    def encode_sample(self, x, eps):
+        mean, logvar = self.quant_conv(self.encoder(x)).float().chunk(2, dim=1)
+        return (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * eps) * self.scaling_factor

@@ -107,6 +107,25 @@ class HipBackend:
     def __init__(self):
         self.lib = _C.load()
         self._ws = {}
+        self.prof = None   # bench.py: list of (kernel key, algorithmic flops, start event, end event) when enabled
+
+    def _timed(self, key, flops, fn):
+        """Run one launch; when profiling is on, bracket it with events on the launch stream."""
+        if self.prof is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.prof.append((key, flops, e0, e1))
+        return r
+
+    @staticmethod
+    def _tile(M, N, nb, tile):
+        if tile in (64, 128):
+            return tile
+        cd = lambda a, b: (a + b - 1) // b
+        return 128 if cd(M, 128) * cd(N, 128) * nb >= 384 else 64
 
     # ------------------------------------------------------------------ workspaces
     def workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -162,7 +181,9 @@ class HipBackend:
         need = _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch)
         ws = self.workspace(need, a.device) if need else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
-        _C.check(self.lib.e4t_gemm_nt(C.byref(d), _stream()), "e4t_gemm_nt")
+        st = _stream()
+        self._timed(f"gemm{self._tile(M, N, nb, tile)}", 2.0 * M * N * K * nb,
+                    lambda: _C.check(self.lib.e4t_gemm_nt(C.byref(d), st), "e4t_gemm_nt"))
         return out
 
     # ------------------------------------------------------------------ conv
@@ -187,7 +208,9 @@ class HipBackend:
         need = _gemm_ws_need(M, Cout, 9 * Cin, 1, tile, splitk, False)
         ws = self.workspace(need, x.device) if need else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
-        _C.check(self.lib.e4t_conv3x3(C.byref(d), _stream()), "e4t_conv3x3")
+        st = _stream()
+        self._timed(f"conv{self._tile(M, Cout, 1, tile)}", 2.0 * M * Cout * 9 * Cin,
+                    lambda: _C.check(self.lib.e4t_conv3x3(C.byref(d), st), "e4t_conv3x3"))
         return out
 
     def conv_weight_prepare(self, w_oihw, Ipad=None, Opad=None, want_fwd=True, want_dgrad=True):
@@ -209,8 +232,10 @@ class HipBackend:
             out = torch.empty((B * T, H * DH), dtype=bf16, device=q.device)
         lse = torch.empty((B, H, T), dtype=f32, device=q.device) if need_lse else None
         ldq, ldk, ldv, ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
-        _C.check(self.lib.e4t_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, T, S, DH, ldq, ldk, ldv, ldo,
-                                            T * ldq, S * ldk, S * ldv, T * ldo, float(scale), _stream()), "e4t_attention_fwd")
+        st = _stream()
+        self._timed(f"attn_fwd{DH}", 4.0 * B * H * T * S * DH, lambda: _C.check(self.lib.e4t_attention_fwd(
+            _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, T, S, DH, ldq, ldk, ldv, ldo,
+            T * ldq, S * ldk, S * ldv, T * ldo, float(scale), st), "e4t_attention_fwd"))
         return out, lse
 
     def attention_bwd(self, q, k, v, o, do, lse, dq, dk, dv, B, H, T, S, DH, scale):
@@ -218,9 +243,11 @@ class HipBackend:
         ldq, ldk, ldv, ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
         assert dq.stride(0) == ldq and dk.stride(0) == ldk and dv.stride(0) == ldv and do.stride(0) == ldo
         delta = torch.empty((B, H, T), dtype=f32, device=q.device)
-        _C.check(self.lib.e4t_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk),
-                                            _ptr(dv), B, H, T, S, DH, ldq, ldk, ldv, ldo, T * ldq, S * ldk, S * ldv, T * ldo,
-                                            float(scale), _stream()), "e4t_attention_bwd")
+        st = _stream()
+        self._timed(f"attn_bwd{DH}", 10.0 * B * H * T * S * DH, lambda: _C.check(self.lib.e4t_attention_bwd(
+            _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk),
+            _ptr(dv), B, H, T, S, DH, ldq, ldk, ldv, ldo, T * ldq, S * ldk, S * ldv, T * ldo,
+            float(scale), st), "e4t_attention_bwd"))
 
     # ------------------------------------------------------------------ norms
     def groupnorm_fwd(self, x1, x2, gamma, beta, B, HW, G, eps, silu):

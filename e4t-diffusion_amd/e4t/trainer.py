@@ -1,0 +1,173 @@
+"""One E4T pre-training step (reference: pretrain_e4t.py:595-654) on the native modules.
+
+``E4TTrainer`` owns what the reference spreads over accelerate + torch.optim:
+  * flat fp32 parameter / gradient / Adam-moment buffers for exactly the tensors the reference optimises
+    (pretrain_e4t.py:274-278: encoder parameters with requires_grad + UNet parameters whose name contains
+    "wo"); parameters are re-pointed to views of the flat buffer, their .grad to views of the flat gradient,
+    so the kernels that produce gradients write their final location directly;
+  * ONE fused AdamW launch over the flat buffers (torch.optim.AdamW defaults, :387-392);
+  * data-parallel gradient averaging: one process per GPU, RCCL all-reduce of the flat gradient in
+    finalisation-ordered buckets on a side stream (the reference gets this implicitly from DDP, :410-412,648).
+The step itself is the reference's: VAE encode -> noise -> UNet encoder pass -> E4T encoder -> embed inject ->
+text encoder -> UNet full pass -> MSE + lambda * |e|^2 -> backward -> AdamW.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+f32 = torch.float32
+
+
+def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012, device=None):
+    """[3P diffusers] DDPMScheduler(scaled_linear) as used at pretrain_e4t.py:235."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=f32, device=device) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def select_trainable(unet, encoder):
+    """pretrain_e4t.py:274-278; every other UNet parameter is frozen (the reference never reads their grads)."""
+    for n, p in unet.named_parameters():
+        p.requires_grad_("wo" in n)
+    named = [(f"e4t_encoder.{n}", p) for n, p in encoder.named_parameters() if p.requires_grad]
+    named += [(f"unet.{n}", p) for n, p in unet.named_parameters() if "wo" in n]
+    return named
+
+
+class FlatParams:
+    """Flat fp32 storage for a list of parameters (64-float aligned segments) + matching gradient buffer."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], device):
+        self.params = list(params)
+        offs, off = [], 0
+        for p in self.params:
+            offs.append(off)
+            off += (p.numel() + 63) // 64 * 64
+        self.offsets, self.numel = offs, off
+        self.data = torch.zeros(off, dtype=f32, device=device)
+        self.grad = torch.zeros(off, dtype=f32, device=device)
+        for p, o in zip(self.params, offs):
+            v = self.data[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def view(self, p_index, buf):
+        p, o = self.params[p_index], self.offsets[p_index]
+        return buf[o:o + p.numel()].view(p.shape)
+
+
+class E4TTrainer:
+    def __init__(self, unet, e4t_encoder, text_encoder, vae, *, lr=1e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 domain_embed_scale=0.1, reg_lambda=0.01, prediction_type="epsilon", class_token_id=0,
+                 empty_prompt_ids: Optional[torch.Tensor] = None, process_group=None, device=None):
+        self.unet, self.encoder, self.text_encoder, self.vae = unet, e4t_encoder, text_encoder, vae
+        self.device = device or next(unet.parameters()).device
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.scale, self.reg_lambda, self.pred_type = domain_embed_scale, reg_lambda, prediction_type
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self.step_count = 0
+        self.acp = ddpm_alphas_cumprod(device=self.device)
+        named = select_trainable(unet, e4t_encoder)
+        # order: the stacked first_linears weights, then their biases (contiguous stacks), then the rest
+        fl_w = [p for n, p in named if ".first_linears." in n and n.endswith(".weight")]
+        fl_b = [p for n, p in named if ".first_linears." in n and n.endswith(".bias")]
+        rest = [p for n, p in named if ".first_linears." not in n]
+        # make the per-slot segments exactly contiguous: numel of each is a multiple of 64 for hid % 8 == 0
+        self.flat = FlatParams(fl_w + fl_b + rest, self.device)
+        n = len(fl_w)
+        if n:
+            hid = fl_w[0].shape[0]
+            assert (hid * hid) % 64 == 0 and hid % 64 == 0, "first_linears stacks need 64-float aligned slots"
+            o_w, o_b = self.flat.offsets[0], self.flat.offsets[n]
+            st = lambda buf, o, shape: buf[o:o + math.prod(shape)].view(shape)
+            e4t_encoder.adopt_stacks(st(self.flat.data, o_w, (n, hid, hid)), st(self.flat.data, o_b, (n, hid)),
+                                     st(self.flat.grad, o_w, (n, hid, hid)), st(self.flat.grad, o_b, (n, hid)))
+        self.exp_avg = torch.zeros_like(self.flat.data)
+        self.exp_avg_sq = torch.zeros_like(self.flat.data)
+        ops.bump_weights_epoch()
+        # constants of the loop (pretrain_e4t.py:561-583)
+        with torch.no_grad():
+            emb = text_encoder.get_input_embeddings()
+            self.class_embed = emb(torch.tensor([class_token_id], device=self.device))[0].float()
+            ids = empty_prompt_ids if empty_prompt_ids is not None else torch.zeros((1, 77), dtype=torch.long, device=self.device)
+            self.ctx_for_e4t = text_encoder(input_ids=ids.to(self.device))[0].detach()
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.world > 1 and self.device.type == "cuda") else None
+
+    # ------------------------------------------------------------------------------------------------
+    def add_noise(self, x0, noise, t):
+        a = self.acp[t].sqrt().view(-1, 1, 1, 1)
+        s = (1 - self.acp[t]).sqrt().view(-1, 1, 1, 1)
+        return a * x0 + s * noise
+
+    def losses(self, pixel_values, latents, noise, timesteps, input_ids, placeholder_idx):
+        """Forward half of the step (pretrain_e4t.py:616-647).  Returns (loss, loss_diff, loss_reg)."""
+        B = latents.shape[0]
+        te = self.text_encoder
+        with torch.no_grad():
+            inputs_embeds = te.get_input_embeddings()(input_ids)
+        noisy = self.add_noise(latents, noise, timesteps)
+        enc = self.unet(noisy, timesteps, self.ctx_for_e4t.expand(B, -1, -1), return_encoder_outputs=True)
+        domain = self.encoder(x=pixel_values, unet_down_block_samples=enc["down_block_samples"])
+        domain = self.class_embed[None, :].expand(B, -1) + self.scale * domain
+        emb = inputs_embeds.clone()
+        emb[torch.arange(B, device=emb.device), placeholder_idx] = domain.to(emb.dtype)
+        ctx = te(inputs_embeds=emb)[0]
+        pred = self.unet(noisy, timesteps, ctx).sample
+        if self.pred_type == "epsilon":
+            target = noise
+        else:
+            a = self.acp[timesteps].sqrt().view(-1, 1, 1, 1)
+            s = (1 - self.acp[timesteps]).sqrt().view(-1, 1, 1, 1)
+            target = a * noise - s * latents
+        loss_diff = F.mse_loss(pred.float(), target.float(), reduction="mean")
+        loss_reg = self.reg_lambda * domain.pow(2).sum()
+        return loss_diff + loss_reg, loss_diff, loss_reg
+
+    def encode_latents(self, pixel_values, vae_eps):
+        w = next(self.vae.parameters())
+        return self.vae.encode_sample(pixel_values.to(w.dtype), vae_eps).float()
+
+    def all_reduce_grads(self):
+        if self.world <= 1:
+            return
+        # finalisation order = flat order reversed is not guaranteed; v1: bucketed all-reduce after backward
+        g = self.flat.grad
+        bucket = 64 << 20   # 256 MB fp32 buckets: large enough to run the xGMI links at rate
+        for o in range(0, g.numel(), bucket):
+            torch.distributed.all_reduce(g[o:o + bucket], group=self.pg)
+
+    def optimizer_step(self):
+        self.step_count += 1
+        ops.backend().adamw(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
+                            self.eps, self.wd, self.step_count, 1.0 / self.world)
+        ops.bump_weights_epoch()
+
+    def zero_grad(self):
+        self.flat.grad.zero_()
+
+    def train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None):
+        """Full step.  Random draws may be passed in (parity tests) or are sampled on the device."""
+        dev = self.device
+        B = pixel_values.shape[0]
+        if latents is None:
+            hl, wl = pixel_values.shape[2] // 8, pixel_values.shape[3] // 8
+            if vae_eps is None:
+                vae_eps = torch.randn((B, 4, hl, wl), device=dev)
+            latents = self.encode_latents(pixel_values, vae_eps)
+        if noise is None:
+            noise = torch.randn_like(latents)
+        if timesteps is None:
+            timesteps = torch.randint(0, self.acp.shape[0], (B,), device=dev).long()
+        loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
+        loss.backward()
+        self.all_reduce_grads()
+        self.optimizer_step()
+        self.zero_grad()
+        return loss.detach(), loss_diff.detach(), loss_reg.detach()
