@@ -139,7 +139,7 @@ __device__ __forceinline__ void store_T_acc(const f32x16* acc, float mul, bf16_t
 // forward
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vt[C::DV * C::TLD];
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p, int Bn) {
 // backward dQ: one wave = 32 queries, loop over key tiles
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * C::KLD];
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 // backward dK, dV: one wave = 32 keys, loop over query tiles
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * C::KLD];
   __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * C::KLD];

@@ -138,13 +138,31 @@ __global__ __launch_bounds__(256) void sumpool2_kernel(const bf16_t* in, bf16_t*
 }
 
 // ---- spatial mean: out[b][coff + c] = mean_p x[b][p][c]  (encoder.py:147) ; grid (ceil(C/256), B) ----
-__global__ __launch_bounds__(256) void spatial_mean_kernel(const bf16_t* x, float* out, int HW, int C, int ldo, int coff) {
-  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (c >= C) return;
-  float s = 0.f;
-  const bf16_t* p = x + (long long)b * HW * C + c;
-  for (int i = 0; i < HW; ++i) s += bf2f(p[(long long)i * C]);
-  out[(long long)b * ldo + coff + c] = s / HW;
+// block = 1024 threads = 64 pixel groups x 16 lanes; each lane owns 4 channels of a 64-channel slab (8-byte loads,
+// 128 B contiguous per pixel per 16 lanes); fixed-order LDS tree -> deterministic.
+__global__ __launch_bounds__(1024) void spatial_mean_kernel(const bf16_t* x, float* out, int HW, int C, int ldo, int coff) {
+  __shared__ float red[64][65];
+  const int b = blockIdx.y, c0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  const int c = c0 + lane * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const bf16_t* p = x + (long long)b * HW * C + c;
+    for (int i = pg; i < HW; i += 64) {
+      float f[4];
+      unpack4(*(const uint2*)(p + (long long)i * C), f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += f[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[pg][lane * 4 + j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < 64 && c0 + threadIdx.x < C) {
+    float t = 0.f;
+    for (int g = 0; g < 64; ++g) t += red[g][threadIdx.x];
+    out[(long long)b * ldo + coff + c0 + threadIdx.x] = t / HW;
+  }
 }
 // dx[b][p][c] = (base ? base : 0) + g[b][coff + c] / HW
 __global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const float* g, const bf16_t* base, bf16_t* dx, int Bn, int HW, int C, int ldg, int coff) {
@@ -309,8 +327,8 @@ extern "C" int e4t_sumpool2(const void* in, void* out, int Bn, int H, int W, int
   return 0;
 }
 extern "C" int e4t_spatial_mean(const void* x, float* out, int Bn, int HW, int C, int ldo, int coff, e4t_stream s) {
-  E4T_REQUIRE(x && out && Bn > 0 && HW > 0 && C > 0, "spatial_mean: bad arguments");
-  hipLaunchKernelGGL(spatial_mean_kernel, dim3(cdiv(C, 256), Bn), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, out, HW, C, ldo, coff);
+  E4T_REQUIRE(x && out && Bn > 0 && HW > 0 && C > 0 && C % 4 == 0, "spatial_mean: bad arguments (C %% 4 == 0)");
+  hipLaunchKernelGGL(spatial_mean_kernel, dim3(cdiv(C, 64), Bn), dim3(1024), 0, (hipStream_t)s, (const bf16_t*)x, out, HW, C, ldo, coff);
   E4T_CHECK_LAUNCH("spatial_mean_kernel");
   return 0;
 }
@@ -345,5 +363,85 @@ extern "C" int e4t_sumsq_partial(const float* g, long long n, float* partial, in
   E4T_REQUIRE(g && partial && n > 0 && nblocks > 0, "sumsq_partial: bad arguments");
   hipLaunchKernelGGL(sumsq_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)s, g, n, partial);
   E4T_CHECK_LAUNCH("sumsq_kernel");
+  return 0;
+}
+
+// ---- in-place row softmax (VAE mid-block attention scores; fp32 math, one 256-thread block per row) ----
+namespace {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* x, int L, int ld) {
+  __shared__ float red[16];
+  bf16_t* row = x + (long long)blockIdx.x * ld;
+  const int nch = L >> 3;
+  float v[4][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nch) {
+      unpack8(*(const uint4*)(row + c * 8), v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[i][j]);
+    }
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nch)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[i][j] = __expf(v[i][j] - mx); s += v[i][j]; }
+  }
+  s = block_sum(s, red + 8);
+  const float inv = 1.f / s;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[i][j] *= inv;
+      *(uint4*)(row + c * 8) = pack8(v[i]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void im2col3_kernel(const float* px, bf16_t* out, int Bn, int H, int W) {
+  const long long total = (long long)Bn * H * W;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W); long long t = i / W; const int y = (int)(t % H); const int b = (int)(t / H);
+    float f[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) f[k] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) f[(ky * 3 + kx) * 3 + c] = px[(((long long)b * 3 + c) * H + yy) * W + xx];
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *(uint4*)(out + i * 32 + k * 8) = pack8(f + k * 8);
+  }
+}
+}  // namespace
+
+extern "C" int e4t_softmax_rows(void* x, long long rows, int L, int ld, e4t_stream s) {
+  E4T_REQUIRE(x && rows > 0 && L > 0 && L % 8 == 0 && L <= 8192 && ld >= L && ld % 8 == 0, "softmax_rows: bad arguments");
+  E4T_REQUIRE(rows <= 0x7fffffffLL, "softmax_rows: too many rows");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)s, (bf16_t*)x, L, ld);
+  E4T_CHECK_LAUNCH("softmax_rows_kernel");
+  return 0;
+}
+extern "C" int e4t_im2col3_rgb(const float* pixels_nchw, void* out, int Bn, int H, int W, e4t_stream s) {
+  E4T_REQUIRE(pixels_nchw && out && Bn > 0 && H > 0 && W > 0, "im2col3_rgb: bad arguments");
+  long long blocks = ((long long)Bn * H * W + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(im2col3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, pixels_nchw, (bf16_t*)out, Bn, H, W);
+  E4T_CHECK_LAUNCH("im2col3_kernel");
   return 0;
 }

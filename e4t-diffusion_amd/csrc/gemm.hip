@@ -175,6 +175,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
           iy = a_oy[i] + ky - 1; ix = a_ox[i] + kx - 1;
           ok = ok && iy >= 0 && iy < 2 * p.Hin && ix >= 0 && ix < 2 * p.Win;
           iy >>= 1; ix >>= 1;
+        } else if (p.mode == E4T_CONV_S2A) {  // stride 2, pad (0,1,0,1): the VAE encoder's Downsample2D(padding=0)
+          iy = 2 * a_oy[i] + ky; ix = 2 * a_ox[i] + kx;
+          ok = ok && iy < p.Hin && ix < p.Win;
         } else {  // E4T_CONV_S2T: transposed stride-2 (dgrad of S2); X is the (smaller) output-grad map
           const int sy = a_oy[i] + ky - 1, sx = a_ox[i] + kx - 1;
           ok = ok && sy >= 0 && sx >= 0 && !(sy & 1) && !(sx & 1);
@@ -351,12 +354,13 @@ extern "C" int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream) {
   E4T_REQUIRE(d && d->X && d->W && d->Y, "conv3x3: null operand");
   const int Cin = d->Cin, Cout = d->Cout, Hin = d->Hin, Win = d->Win, Hout = d->Hout, Wout = d->Wout, mode = d->mode;
   E4T_REQUIRE(Cin % BK == 0, "conv3x3: Cin=%d must be a multiple of 64 (pad the input channels)", Cin);
-  E4T_REQUIRE(mode >= E4T_CONV_S1 && mode <= E4T_CONV_S2T, "conv3x3: bad mode %d", mode);
+  E4T_REQUIRE(mode >= E4T_CONV_S1 && mode <= E4T_CONV_S2A, "conv3x3: bad mode %d", mode);
   E4T_REQUIRE(d->B > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && Cout > 0, "conv3x3: bad geometry");
   if (mode == E4T_CONV_S1) E4T_REQUIRE(Hout == Hin && Wout == Win, "conv3x3 S1: output must equal input size");
   if (mode == E4T_CONV_S2) E4T_REQUIRE(Hout == (Hin - 1) / 2 + 1 && Wout == (Win - 1) / 2 + 1, "conv3x3 S2: bad output size");
   if (mode == E4T_CONV_UP2) E4T_REQUIRE(Hout == 2 * Hin && Wout == 2 * Win, "conv3x3 UP2: output must be 2x input");
   if (mode == E4T_CONV_S2T) E4T_REQUIRE(Hin == (Hout - 1) / 2 + 1 && Win == (Wout - 1) / 2 + 1, "conv3x3 S2T: bad sizes");
+  if (mode == E4T_CONV_S2A) E4T_REQUIRE(Hout == (Hin - 2) / 2 + 1 && Wout == (Win - 2) / 2 + 1, "conv3x3 S2A: bad output size");
   GemmArgs p;
   memset(&p, 0, sizeof(p));
   p.A = (const bf16_t*)d->X; p.K1 = 9 * Cin; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;

@@ -78,6 +78,8 @@ SIGNATURES = {
     "e4t_spatial_mean_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "e4t_timestep_embedding": (i32, [vp, vp, i32, i32, vp]),
     "e4t_clip_preprocess": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "e4t_softmax_rows": (i32, [vp, i64, i32, i32, vp]),
+    "e4t_im2col3_rgb": (i32, [vp, vp, i32, i32, i32, vp]),
     "e4t_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "e4t_sumsq_partial": (i32, [vp, i64, vp, i32, vp]),
     "e4t_probe_mfma_layout": (i32, [vp, vp, vp]),
@@ -85,7 +87,7 @@ SIGNATURES = {
 
 # flag / enum mirrors of the header
 OUT_F32, RES_F32, ACT_GELU, ACCUM, REDUCE_BATCH = 1, 2, 4, 8, 16
-CONV_S1, CONV_S2, CONV_UP2, CONV_S2T = 1, 2, 3, 4
+CONV_S1, CONV_S2, CONV_UP2, CONV_S2T, CONV_S2A = 1, 2, 3, 4, 5
 WO_STORE_F32, WO_OFFSETS_ONLY = 1, 2
 OP_SILU, OP_SILU_BWD, OP_GELU, OP_GELU_BWD, OP_LRELU, OP_LRELU_BWD = range(6)
 

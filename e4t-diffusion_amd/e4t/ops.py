@@ -368,6 +368,22 @@ class HipBackend:
     def adamw(self, p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
         _C.check(self.lib.e4t_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, grad_scale, _stream()), "e4t_adamw")
 
+    def softmax_rows_(self, x):
+        """in-place softmax over the last dim of a bf16 matrix [..., L] with contiguous rows"""
+        L = x.shape[-1]
+        rows = x.numel() // L
+        assert x.is_contiguous()
+        _C.check(self.lib.e4t_softmax_rows(_ptr(x), rows, L, L, _stream()), "e4t_softmax_rows")
+        return x
+
+    def im2col3_rgb(self, pixels):
+        pixels = pixels.float().contiguous()
+        B, c, H, W = pixels.shape
+        assert c == 3
+        out = torch.empty((B * H * W, 32), dtype=bf16, device=pixels.device)
+        _C.check(self.lib.e4t_im2col3_rgb(_ptr(pixels), _ptr(out), B, H, W, _stream()), "e4t_im2col3_rgb")
+        return out
+
     def sumsq(self, g):
         nb = 1024
         part = torch.empty(nb, dtype=f32, device=g.device)

@@ -96,6 +96,8 @@ class EmuBackend:
             y = F.conv2d(xi, wk, stride=2, padding=1)
         elif mode == CONV_UP2:
             y = F.conv2d(F.interpolate(xi, scale_factor=2.0, mode="nearest"), wk, padding=1)
+        elif mode == 5:  # CONV_S2A: stride 2, pad (0,1,0,1)
+            y = F.conv2d(F.pad(xi, (0, 1, 0, 1)), wk, stride=2)
         else:  # CONV_S2T: zero-stuffed x (to Hout x Wout) then stride-1 conv
             z = torch.zeros(B, Cin, Hout, Wout, dtype=f32, device=x.device)
             z[:, :, ::2, ::2] = xi
@@ -283,6 +285,18 @@ class EmuBackend:
         v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
         bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
         p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+
+    def softmax_rows_(self, x):
+        x.copy_(torch.softmax(x.float(), dim=-1).to(x.dtype))
+        return x
+
+    def im2col3_rgb(self, pixels):
+        B, c, H, W = pixels.shape
+        cols = F.unfold(pixels.float(), 3, padding=1)                      # [B, c*9, H*W] with index c*9 + (ky*3+kx)
+        cols = cols.view(B, 3, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 27)   # -> (ky*3+kx)*3 + c
+        out = torch.zeros((B * H * W, 32), dtype=f32, device=pixels.device)
+        out[:, :27] = cols
+        return self._act(out)
 
     def sumsq(self, g):
         return (g.float() ** 2).sum()

@@ -96,7 +96,7 @@ def check_conv(hip, emu, dev):
         (3, 16, 16, 64, 128, CONV_S2, 8, 8, 0, 0), (2, 9, 9, 64, 64, CONV_S2, 5, 5, 0, 0),
         (2, 8, 8, 64, 64, CONV_UP2, 16, 16, 0, 0), (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 0, 0),
         (2, 5, 5, 64, 64, CONV_S2T, 9, 9, 0, 0), (4, 32, 32, 320, 320, CONV_S1, 32, 32, 128, 1),
-        (2, 16, 16, 64, 4, CONV_S1, 16, 16, 0, 0),
+        (2, 16, 16, 64, 4, CONV_S1, 16, 16, 0, 0), (2, 16, 16, 128, 128, 5, 8, 8, 0, 0), (1, 64, 64, 128, 128, 5, 32, 32, 0, 0),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
         g = gen(50 + i, dev)
@@ -238,6 +238,16 @@ def check_streaming(hip, emu, dev):
     emu.adamw(p2, gr, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3, 0.5)
     out += [("adamw p", rel(p, p2), TOLF), ("adamw m", rel(m, m2), TOLF), ("adamw v", rel(v, v2), TOLF)]
     out.append(("sumsq", rel(hip.sumsq(gr), emu.sumsq(gr)), 1e-4))
+    sc = rnd(g, 3, 100, 4096, scale=2.0, dev=dev)
+    out.append(("softmax_rows 4096", rel(hip.softmax_rows_(sc.clone()), emu.softmax_rows_(sc.clone())), TOL1))
+    sc = rnd(g, 77, 64, scale=3.0, dev=dev)
+    out.append(("softmax_rows 64", rel(hip.softmax_rows_(sc.clone()), emu.softmax_rows_(sc.clone())), TOL1))
+    px = torch.rand(2, 3, 40, 24, generator=g, device=dev) * 2 - 1
+    out.append(("im2col3_rgb", rel(hip.im2col3_rgb(px), emu.im2col3_rgb(px)), 0.0))
+    big = rnd(g, 2 * 4096, 320, dev=dev)
+    o1 = torch.zeros(2, 320, dtype=f32, device=dev); o2 = torch.zeros_like(o1)
+    hip.spatial_mean(big, 2, 4096, o1, 0); emu.spatial_mean(big, 2, 4096, o2, 0)
+    out.append(("spatial_mean 4096x320", rel(o1, o2), TOLF * 5))
     return out
 
 

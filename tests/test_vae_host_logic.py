@@ -1,0 +1,34 @@
+"""CPU: the kernel-driven VAE encoder (e4t/vae.py) vs its stock-torch twin (e4t/frozen.py) and vs the oracle's VAE,
+same parameters, through the fp32 op emulation."""
+import torch
+
+import e4t_oracle as orc
+from test_unet_host_logic import emu_fp32  # noqa: F401
+
+
+def to_oracle_keys(sd):
+    out = {}
+    for k, v in sd.items():
+        k2 = k
+        if k.startswith("encoder."):
+            k2 = k[len("encoder."):]
+            k2 = k2.replace("down_blocks.", "down.").replace("downsamplers.0.", "downsampler.")
+            k2 = k2.replace("mid_block.resnets.0.", "mid_res1.").replace("mid_block.resnets.1.", "mid_res2.").replace("mid_block.attentions.0.", "mid_attn.")
+        out[k2] = v
+    return out
+
+
+def test_native_vae_matches_torch_and_oracle(emu_fp32):
+    from e4t.vae import VAEEncoder
+    torch.manual_seed(0)
+    boc = (64, 128, 128)
+    nat = VAEEncoder(block_out_channels=boc).requires_grad_(False)
+    ref = orc.VAEEncoder(block_out_channels=boc)
+    ref.load_state_dict(to_oracle_keys(nat.state_dict()))
+    x = torch.rand(2, 3, 32, 32) * 2 - 1
+    eps = torch.randn(2, 4, 8, 8)
+    z_nat = nat.encode_sample(x, eps)
+    z_torch = super(VAEEncoder, nat).encode_sample(x, eps)
+    z_ref = ref.encode_sample(x, eps)
+    torch.testing.assert_close(z_torch, z_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(z_nat, z_ref, rtol=2e-4, atol=2e-5)
