@@ -27,6 +27,7 @@
 // e4t/models/unet_2d_condition.py:106-108,285-287 ; [3P open_clip] ViT linears (e4t/encoder.py:154).
 #include "common.h"
 #include "../../include/e4t_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -60,6 +61,7 @@ struct GemmArgs {
   int ktiles_per_split;
   int splitk;       // splits per batch entry (grid.z = batch * splitk)
   int reduce_batch; // partials of all (batch, split) pairs are summed into ONE C
+  int fast_epi;     // bf16 C, 16-byte aligned rows: LDS-staged vectorised epilogue
   long long strideA, strideB, strideC, strideBias;
 };
 
@@ -83,6 +85,80 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int r
   }
 }
 
+// Write one wave's WM x WN accumulator tile (origin mw, nw) with the fused epilogue.
+template <int WM, int WN, int FM, int FN>
+__device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][FN], bf16_t* smem, int wave, int lane, int mw, int nw) {
+  const int frow = lane & 31, fhi = lane >> 5;
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  const bool partial = p.ws != nullptr;
+  if (!partial && p.fast_epi) {
+    // bf16 output: stage the wave's WM x WN tile through LDS (the operand tiles are dead after the loop's final
+    // barrier) so that C is written — and the residual read — as 16-byte chunks, 128 B contiguous per row.
+    // alpha, bias, row bias and GELU are applied in fp32 before the bf16 rounding; the residual is added to the
+    // rounded value in fp32 and rounded again, which is exactly what a bf16 linear followed by a bf16 add does.
+    constexpr int ELD = WN + 8;
+    bf16_t* stage = smem + wave * (WM * ELD);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int cl = j * 32 + frow;
+        const int col = nw + cl;
+        const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+          float v = acc[i][j][r] * p.alpha + bv;
+          if (p.rowbias) {
+            const int row = mw + rl;
+            if (row < p.M && col < p.N) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.N + col];
+          }
+          if (p.flags & E4T_ACT_GELU) v = gelu_f(v);
+          stage[rl * ELD + cl] = f2bf(v);
+        }
+      }
+    __syncthreads();                     // (a wave only reads back its own region; the barrier orders the LDS traffic)
+    constexpr int CPR = WN / 8;          // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;        // rows per wave-instruction
+    const int cch = lane % CPR, rsub = lane / CPR;
+    const int col = nw + cch * 8;
+    bf16_t* Cb = (bf16_t*)p.C;
+    const bf16_t* Rb = (const bf16_t*)p.residual;
+#pragma unroll
+    for (int it = 0; it < WM / RPI; ++it) {
+      const int rl = it * RPI + rsub;
+      const int row = mw + rl;
+      if (row < p.M && col < p.N) {
+        uint4 v = *(const uint4*)(stage + rl * ELD + cch * 8);
+        if (Rb) {
+          float a[8], b[8];
+          unpack8(v, a);
+          unpack8(*(const uint4*)(Rb + (size_t)row * p.ldr + col), b);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a[k] += b[k];
+          v = pack8(a);
+        }
+        *(uint4*)(Cb + (size_t)row * p.ldc + col) = v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = nw + j * 32 + frow;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+        if (row >= p.M) continue;
+        if (partial) p.ws[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[i][j][r];  // z = batch*splitk + split
+        else epilogue_store(p, acc[i][j][r], row, col);
+      }
+    }
+}
+
 // MODE 0: dense A.  MODE 1: implicit 3x3 conv over NHWC A.
 template <int BM, int BN, int WGM, int WGN, int MODE>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
@@ -93,8 +169,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   static_assert(WGM * WGN == 4, "4 waves per workgroup");
   static_assert(NA >= 1 && NB >= 1, "tile too small");
 
-  __shared__ __attribute__((aligned(16))) bf16_t As[BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[BN * LDS_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[(BM + BN) * LDS_LD];
+  bf16_t* const As = smem;
+  bf16_t* const Bs = smem + BM * LDS_LD;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -235,22 +312,224 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  const bool partial = p.ws != nullptr;
+  write_tile<WM, WN, FM, FN>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (the default): operand tiles go HBM -> LDS with global_load_lds_dwordx4, never
+// through VGPRs or ds_write (the register-staged kernel above is LDS-write bound: 32 KB of
+// ds_write_b128 per K-tile cost about as many LDS cycles as the tile's MFMAs take).
+//   * one wave-instruction moves 8 rows x 128 B = 1 KiB, landing lane-linear in LDS, so tiles are
+//     UNPADDED [rows][64] bf16; bank conflicts on the ds_read_b128 fragment reads are removed by an XOR
+//     swizzle applied on the SOURCE side: LDS chunk slot p of row r holds logical 16-B chunk
+//     p ^ ((r >> 1) & 7); fragment reads apply the same involution (16 rows distinct mod 16 -> 16
+//     distinct 16-B slots per lane group);
+//   * two LDS buffers, ONE barrier per K-tile: the DMA of tile t+1 is issued right after the barrier
+//     that publishes tile t and flies under tile t's MFMAs;
+//   * out-of-range rows / conv padding / K tail: the lane's source pointer is redirected to a 16-byte
+//     zero word in global memory (DMA cannot synthesise zeros).
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void dma16(const bf16_t* src, bf16_t* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WGM, int WGN, int MODE, int NSTAGE>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int FM = WM / 32, FN = WN / 32;
+  constexpr int NW = WGM * WGN;                       // waves per workgroup (4 or 8)
+  constexpr int NA = BM / 8 / NW, NB = BN / 8 / NW;   // 1-KiB DMA pieces (8 rows) per wave per K-tile
+  constexpr int LOOK = NSTAGE - 1;                    // K-tiles in flight
+  constexpr int TILE = (BM + BN) * BK;          // elements per LDS buffer
+  static_assert(NA >= 1 && NB >= 1 && (NW == 4 || NW == 8) && (NSTAGE == 2 || NSTAGE == 3), "bad tile configuration");
+
+  __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * TILE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  const int nkt = (p.K + BK - 1) / BK;
+  const int bz = blockIdx.z / p.splitk, sz = blockIdx.z - bz * p.splitk;
+  p.A += bz * p.strideA;
+  if (p.A2) p.A2 += bz * p.strideA;
+  p.B += bz * p.strideB;
+  if (p.bias) p.bias += bz * p.strideBias;
+  if (!p.reduce_batch) {
+    if (p.flags & E4T_OUT_F32) p.C = (float*)p.C + bz * p.strideC;
+    else p.C = (bf16_t*)p.C + bz * p.strideC;
+  }
+  const int kt_begin = sz * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nkt) kt_end = nkt;
+
+  const bf16_t* const zero = (const bf16_t*)&g_zero16;
+  const int lrow = lane >> 3, lslot = lane & 7;   // position of this lane inside a 1-KiB piece
+
+  // rows this lane feeds: piece q = wave*NA + i covers tile rows q*8 .. q*8+7
+  long long a_base[NA];
+  int a_oy[NA], a_ox[NA], a_kc[NA];
+  bool a_ok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int r = (wave * NA + i) * 8 + lrow;
+    const int gr = m0 + r;
+    a_ok[i] = gr < p.M;
+    a_kc[i] = (lslot ^ ((r >> 1) & 7)) * 8;       // logical k offset (elements) this lane fetches for that row
+    if (MODE == 0) {
+      a_base[i] = (long long)gr; a_oy[i] = a_ox[i] = 0;
+    } else {
+      const int hw = p.Hout * p.Wout;
+      const int b = gr / hw;
+      const int rem = gr - b * hw;
+      a_oy[i] = rem / p.Wout;
+      a_ox[i] = rem - a_oy[i] * p.Wout;
+      a_base[i] = (long long)b * p.Hin * p.Win;
+    }
+  }
+  const bf16_t* b_ptr[NB];
+  int b_kc[NB];
+  bool b_ok[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = (wave * NB + i) * 8 + lrow;
+    const int gn = n0 + r;
+    b_ok[i] = gn < p.N;
+    b_kc[i] = (lslot ^ ((r >> 1) & 7)) * 8;
+    b_ptr[i] = p.B + (size_t)(b_ok[i] ? gn : 0) * p.ldb;
+  }
+
+  // Source pointers are carried ACROSS K-tiles and advanced by 64 elements per tile; the full (64-bit, per-row)
+  // address computation runs only when the tile starts a new region: the first tile, a new 3x3 tap (conv), the
+  // switch to the second concat source (dense), or the ragged last tile.  (A per-tile recomputation costs ~1.2k
+  // issue cycles per wave per tile — measured: 3x the tile's MFMA issue time.)
+  const bf16_t* a_ptr[NA];
+  const bf16_t* bq_ptr[NB];
+  auto place_a = [&](int k0) {
+    if (MODE == 0) {
+      const bf16_t* src = p.A;
+      int ld = p.lda, koff = k0;
+      if (k0 >= p.K1) { src = p.A2; ld = p.lda2; koff = k0 - p.K1; }
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const bool ok = a_ok[i] && (k0 + a_kc[i] < p.K);
+        a_ptr[i] = ok ? src + a_base[i] * ld + koff + a_kc[i] : zero;
+      }
+    } else {
+      const int tap = k0 / p.Cin;
+      const int ci0 = k0 - tap * p.Cin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        int iy, ix;
+        bool ok = a_ok[i];
+        if (p.mode == E4T_CONV_S1) {
+          iy = a_oy[i] + ky - 1; ix = a_ox[i] + kx - 1;
+          ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        } else if (p.mode == E4T_CONV_S2) {
+          iy = 2 * a_oy[i] + ky - 1; ix = 2 * a_ox[i] + kx - 1;
+          ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        } else if (p.mode == E4T_CONV_UP2) {
+          iy = a_oy[i] + ky - 1; ix = a_ox[i] + kx - 1;
+          ok = ok && iy >= 0 && iy < 2 * p.Hin && ix >= 0 && ix < 2 * p.Win;
+          iy >>= 1; ix >>= 1;
+        } else if (p.mode == E4T_CONV_S2A) {
+          iy = 2 * a_oy[i] + ky; ix = 2 * a_ox[i] + kx;
+          ok = ok && iy < p.Hin && ix < p.Win;
+        } else {
+          const int sy = a_oy[i] + ky - 1, sx = a_ox[i] + kx - 1;
+          ok = ok && sy >= 0 && sx >= 0 && !(sy & 1) && !(sx & 1);
+          iy = sy >> 1; ix = sx >> 1;
+          ok = ok && iy < p.Hin && ix < p.Win;
+        }
+        a_ptr[i] = ok ? p.A + (a_base[i] + (long long)iy * p.Win + ix) * p.Cin + ci0 + a_kc[i] : zero;
+      }
+    }
+  };
+  auto place_b = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const bool ok = b_ok[i] && (k0 + b_kc[i] < p.K);
+      bq_ptr[i] = ok ? b_ptr[i] + k0 + b_kc[i] : zero;
+    }
+  };
+  auto issue_tile = [&](int kt, bf16_t* buf) {
+    const int k0 = kt * BK;
+    bf16_t* As = buf;
+    bf16_t* Bs = buf + BM * BK;
+    const bool ragged = k0 + BK > p.K;                                      // wave-uniform conditions
+    const bool fresh_a = kt == kt_begin || ragged || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0);
+    if (fresh_a) {
+      place_a(k0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a_ptr[i] += (a_ptr[i] != zero) ? BK : 0;
+    }
+    if (kt == kt_begin || ragged) {
+      place_b(k0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) bq_ptr[i] += (bq_ptr[i] != zero) ? BK : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dma16(a_ptr[i], As + (wave * NA + i) * 512);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) dma16(bq_ptr[i], Bs + (wave * NB + i) * 512);
+  };
+
+  f32x16 acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = n0 + wn * WN + j * 32 + frow;
-      if (col >= p.N) continue;
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-        if (row >= p.M) continue;
-        if (partial) p.ws[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[i][j][r];  // z = batch*splitk + split
-        else epilogue_store(p, acc[i][j][r], row, col);
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fhi = lane >> 5;
+  // prologue: LOOK tiles in flight
+#pragma unroll
+  for (int s = 0; s < LOOK; ++s)
+    if (kt_begin + s < kt_end) issue_tile(kt_begin + s, smem + s * TILE);
+  int cur = 0, nxt = LOOK;                             // ring slots of tile kt and of tile kt+LOOK
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    // this wave's pieces of tile kt have landed once at most the pieces of the (LOOK-1) newer tiles are outstanding
+    if (LOOK == 2 && kt + 1 < kt_end) wait_vmcnt<NA + NB>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                      // ... everyone's have; and everyone finished reading slot `nxt`
+    if (kt + LOOK < kt_end) issue_tile(kt + LOOK, smem + nxt * TILE);
+    const bf16_t* As = smem + cur * TILE;
+    const bf16_t* Bs = As + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int r = wm * WM + i * 32 + frow;
+        af[i] = *(const bf16x8*)(As + r * BK + (((ks * 2 + fhi) ^ ((r >> 1) & 7)) * 8));
       }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int r = wn * WN + j * 32 + frow;
+        bfr[j] = *(const bf16x8*)(Bs + r * BK + (((ks * 2 + fhi) ^ ((r >> 1) & 7)) * 8));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
+    cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+  }
+  __syncthreads();   // all fragment reads done before the epilogue reuses the LDS
+  write_tile<WM, WN, FM, FN>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
 }
 
 // sums `nz` consecutive partial slabs starting at slab blockIdx.y*nz, then runs the epilogue for batch entry blockIdx.y
@@ -275,11 +554,16 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   const int nkt = cdiv(p.K, BK);
   // --- tile selection: fill >= ~1.5 waves of the 256 CUs with 128x128 tiles, else drop to 64x64 ---
   int tile = tile_hint;
-  if (tile != 64 && tile != 128) {
+  static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
+  static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
+  if (tile != 64 && tile != 128 && tile != 256) {
+    const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch;
     const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
-    tile = (t128 >= 384) ? 128 : 64;
+    tile = (allow256 && auto256 && t256 >= 256) ? 256 : (t128 >= 384) ? 128 : 64;
   }
-  const int gx = cdiv(p.N, tile), gy = cdiv(p.M, tile);
+  if (tile == 256 && !allow256) tile = 128;
+  const int tm = tile, tn = tile == 256 ? 128 : tile;   // tile 256 means BM = 256, BN = 128
+  const int gx = cdiv(p.N, tn), gy = cdiv(p.M, tm);
   // --- split-K: only when the grid underfills the chip and K is long ---
   int splitk = splitk_req;
   if (splitk <= 0) {
@@ -304,8 +588,23 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   }
   if (!(splitk > 1 || p.reduce_batch)) p.ws = nullptr;
   p.splitk = splitk;
+  p.fast_epi = !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
+               (p.strideC % 8 == 0) && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
   dim3 grid(gx, gy, splitk * batch), block(256);
-  if (tile == 128) {
+  static const bool use_dma = getenv("E4T_GEMM_REGSTAGE") == nullptr;   // A/B switch: register-staged reference kernel
+  if (use_dma) {
+    if (tile == 256) {
+      block = dim3(512);
+      if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 0, 3>), grid, block, 0, st, p);
+    } else if (tile == 128) {
+      if (conv) hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 2, 2, 1, 2>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 2, 2, 0, 2>), grid, block, 0, st, p);
+    } else {
+      if (conv) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 1, 2>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 0, 2>), grid, block, 0, st, p);
+    }
+  } else if (tile == 128) {
     if (conv) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 1>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 0>), grid, block, 0, st, p);
   } else {
@@ -318,7 +617,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     const int nz = p.reduce_batch ? splitk * batch : splitk;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, p.reduce_batch ? 1 : batch), block, 0, st, p, nz);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, p.reduce_batch ? 1 : batch), dim3(256), 0, st, p, nz);
     E4T_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return 0;

@@ -16,55 +16,91 @@
 
 namespace {
 
-constexpr int GN_MAXQ = 3;  // channel quads (4 ch) per thread: C <= 3*256*4 = 3072
+// Thread mapping shared by all GroupNorm kernels: a pixel row of C channels is QW = C/8 chunks of 16 bytes.
+//   QW <= 256: the block's 256 threads form PG = 256/QW pixel groups x QW chunk lanes (every thread busy);
+//   QW  > 256: one pixel group, each thread owns chunks tid and tid+256 (C <= 4096).
+constexpr int GN_MAXS = 2;
 
 struct GNSrc {
   const bf16_t* x1; const bf16_t* x2; int C1, C2;
 };
-__device__ __forceinline__ uint2 gn_load4(const GNSrc& s, size_t pix, int c) {
-  if (c < s.C1) return *(const uint2*)(s.x1 + pix * s.C1 + c);
-  return *(const uint2*)(s.x2 + pix * s.C2 + (c - s.C1));
+__device__ __forceinline__ uint4 gn_load8(const GNSrc& s, size_t pix, int c) {
+  if (c < s.C1) return *(const uint4*)(s.x1 + pix * s.C1 + c);
+  return *(const uint4*)(s.x2 + pix * s.C2 + (c - s.C1));
+}
+struct GNMap {
+  int QW, PG, pg, nslot;
+  int ch[GN_MAXS];      // chunk index per slot, -1 = inactive
+  __device__ GNMap(int C) {
+    QW = C >> 3;
+    const int tid = threadIdx.x;
+    if (QW <= 256) {
+      PG = 256 / QW; nslot = 1; pg = tid / QW;
+      ch[0] = (tid < PG * QW) ? tid - pg * QW : -1; ch[1] = -1;
+      if (ch[0] < 0) pg = 0;
+    } else {
+      PG = 1; nslot = 2; pg = 0;
+      ch[0] = tid; ch[1] = (tid + 256 < QW) ? tid + 256 : -1;
+    }
+  }
+};
+
+// Reduce per-thread per-channel pairs (a[s][j], b[s][j]) over the block's pixel groups, then over each group's
+// channels.  lds: [PG][C][2] scratch followed by [C][2] channel totals.  Fixed order -> deterministic.
+__device__ __forceinline__ void gn_block_reduce(const GNMap& m, int C, int G, float (*a)[8], float (*b)[8], float* lds,
+                                                 const float* gamma_or_null, float* group_out, float* chan_out) {
+  float* chs = lds + (size_t)m.PG * C * 2;
+#pragma unroll
+  for (int s = 0; s < GN_MAXS; ++s)
+    if (m.ch[s] >= 0)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = m.ch[s] * 8 + j;
+        lds[((size_t)m.pg * C + c) * 2] = a[s][j];
+        lds[((size_t)m.pg * C + c) * 2 + 1] = b[s][j];
+      }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float ta = 0.f, tb = 0.f;
+    for (int g = 0; g < m.PG; ++g) { ta += lds[((size_t)g * C + c) * 2]; tb += lds[((size_t)g * C + c) * 2 + 1]; }
+    if (chan_out) { chan_out[c * 2] = ta; chan_out[c * 2 + 1] = tb; }
+    if (gamma_or_null) { ta *= gamma_or_null[c]; tb *= gamma_or_null[c]; }
+    chs[c * 2] = ta; chs[c * 2 + 1] = tb;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int cpg = C / G;
+    float ta = 0.f, tb = 0.f;
+    for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { ta += chs[c * 2]; tb += chs[c * 2 + 1]; }
+    group_out[threadIdx.x * 2] = ta; group_out[threadIdx.x * 2 + 1] = tb;
+  }
 }
 
 // partial[b][chunk][g][2] = (sum, sumsq) of x over this chunk's pixels and group g's channels
 __global__ __launch_bounds__(256) void gn_stats_kernel(GNSrc s, int HW, int G, int pix_per_chunk, float* partial) {
-  extern __shared__ float lds[];  // [C][2]
-  const int C = s.C1 + s.C2, nq = C >> 2, cpg = C / G;
-  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  extern __shared__ float lds[];
+  const int C = s.C1 + s.C2;
+  const GNMap m(C);
+  const int b = blockIdx.y, chunk = blockIdx.x;
   const int p0 = chunk * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
-  float sm[GN_MAXQ][4], sq[GN_MAXQ][4];
+  float sm[GN_MAXS][8], sq[GN_MAXS][8];
 #pragma unroll
-  for (int i = 0; i < GN_MAXQ; ++i)
+  for (int i = 0; i < GN_MAXS; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) sm[i][j] = sq[i][j] = 0.f;
-  for (int p = p0; p < p1; ++p) {
+    for (int j = 0; j < 8; ++j) sm[i][j] = sq[i][j] = 0.f;
+  for (int p = p0 + m.pg; p < p1; p += m.PG) {
     const size_t pix = (size_t)b * HW + p;
 #pragma unroll
-    for (int i = 0; i < GN_MAXQ; ++i) {
-      const int q = tid + i * 256;
-      if (q < nq) {
-        float f[4];
-        unpack4(gn_load4(s, pix, q * 4), f);
+    for (int i = 0; i < GN_MAXS; ++i)
+      if (m.ch[i] >= 0) {
+        float f[8];
+        unpack8(gn_load8(s, pix, m.ch[i] * 8), f);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { sm[i][j] += f[j]; sq[i][j] += f[j] * f[j]; }
+        for (int j = 0; j < 8; ++j) { sm[i][j] += f[j]; sq[i][j] += f[j] * f[j]; }
       }
-    }
   }
-#pragma unroll
-  for (int i = 0; i < GN_MAXQ; ++i) {
-    const int q = tid + i * 256;
-    if (q < nq)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { lds[(q * 4 + j) * 2] = sm[i][j]; lds[(q * 4 + j) * 2 + 1] = sq[i][j]; }
-  }
-  __syncthreads();
-  if (tid < G) {
-    float a = 0.f, c2 = 0.f;
-    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += lds[c * 2]; c2 += lds[c * 2 + 1]; }
-    float* o = partial + (((size_t)b * gridDim.x + chunk) * G + tid) * 2;
-    o[0] = a; o[1] = c2;
-  }
+  gn_block_reduce(m, C, G, sm, sq, lds, nullptr, partial + ((size_t)b * gridDim.x + chunk) * G * 2, nullptr);
 }
 
 // mean_rstd[b][g] = (mean, rstd)
@@ -87,41 +123,38 @@ __global__ void gn_finalize_kernel(const float* partial, int nchunk, int G, int 
 // y = act(gamma * (x - mean) * rstd + beta), written as one contiguous (B*HW, C) bf16 matrix
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNSrc s, const float* mean_rstd, const float* gamma, const float* beta,
                                                        bf16_t* y, int HW, int G, int pix_per_chunk, int silu) {
-  const int C = s.C1 + s.C2, nq = C >> 2, cpg = C / G;
-  const int b = blockIdx.y, tid = threadIdx.x;
+  const int C = s.C1 + s.C2, cpg = C / G;
+  const GNMap m(C);
+  const int b = blockIdx.y;
   const int p0 = blockIdx.x * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
-  float sc[GN_MAXQ][4], sh[GN_MAXQ][4];
+  float sc[GN_MAXS][8], sh[GN_MAXS][8];
 #pragma unroll
-  for (int i = 0; i < GN_MAXQ; ++i) {
-    const int q = tid + i * 256;
+  for (int i = 0; i < GN_MAXS; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
       sc[i][j] = 0.f; sh[i][j] = 0.f;
-      if (q < nq) {
-        const int c = q * 4 + j, g = c / cpg;
+      if (m.ch[i] >= 0) {
+        const int c = m.ch[i] * 8 + j, g = c / cpg;
         const float mean = mean_rstd[((size_t)b * G + g) * 2], rstd = mean_rstd[((size_t)b * G + g) * 2 + 1];
         sc[i][j] = rstd * gamma[c];
         sh[i][j] = beta[c] - mean * sc[i][j];
       }
     }
-  }
-  for (int p = p0; p < p1; ++p) {
+  for (int p = p0 + m.pg; p < p1; p += m.PG) {
     const size_t pix = (size_t)b * HW + p;
 #pragma unroll
-    for (int i = 0; i < GN_MAXQ; ++i) {
-      const int q = tid + i * 256;
-      if (q < nq) {
-        float f[4];
-        unpack4(gn_load4(s, pix, q * 4), f);
+    for (int i = 0; i < GN_MAXS; ++i)
+      if (m.ch[i] >= 0) {
+        float f[8];
+        unpack8(gn_load8(s, pix, m.ch[i] * 8), f);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float z = f[j] * sc[i][j] + sh[i][j];
+        for (int j = 0; j < 8; ++j) {
+          const float z = f[j] * sc[i][j] + sh[i][j];
           f[j] = silu ? silu_f(z) : z;
         }
-        *(uint2*)(y + pix * C + q * 4) = pack4(f);
+        *(uint4*)(y + pix * C + m.ch[i] * 8) = pack8(f);
       }
-    }
   }
 }
 
@@ -131,65 +164,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNSrc s, const float* mea
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(GNSrc s, const bf16_t* dy, const float* mean_rstd, const float* gamma,
                                                            const float* beta, int HW, int G, int pix_per_chunk, int silu,
                                                            float* partial, float* chan_partial) {
-  extern __shared__ float lds[];  // [C][2]
-  const int C = s.C1 + s.C2, nq = C >> 2, cpg = C / G;
-  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  extern __shared__ float lds[];
+  const int C = s.C1 + s.C2, cpg = C / G;
+  const GNMap m(C);
+  const int b = blockIdx.y, chunk = blockIdx.x;
   const int p0 = chunk * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
-  float s1[GN_MAXQ][4], s2[GN_MAXQ][4], mu[GN_MAXQ][4], rs[GN_MAXQ][4], ga[GN_MAXQ][4], be[GN_MAXQ][4];
+  float s1[GN_MAXS][8], s2[GN_MAXS][8], mu[GN_MAXS][8], rs[GN_MAXS][8], ga[GN_MAXS][8], be[GN_MAXS][8];
 #pragma unroll
-  for (int i = 0; i < GN_MAXQ; ++i) {
-    const int q = tid + i * 256;
+  for (int i = 0; i < GN_MAXS; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s1[i][j] = s2[i][j] = 0.f; mu[i][j] = 0.f; rs[i][j] = 0.f; ga[i][j] = 0.f; be[i][j] = 0.f;
-      if (q < nq) {
-        const int c = q * 4 + j, g = c / cpg;
+    for (int j = 0; j < 8; ++j) {
+      s1[i][j] = s2[i][j] = 0.f; mu[i][j] = rs[i][j] = ga[i][j] = be[i][j] = 0.f;
+      if (m.ch[i] >= 0) {
+        const int c = m.ch[i] * 8 + j, g = c / cpg;
         mu[i][j] = mean_rstd[((size_t)b * G + g) * 2]; rs[i][j] = mean_rstd[((size_t)b * G + g) * 2 + 1];
         ga[i][j] = gamma[c]; be[i][j] = beta[c];
       }
     }
-  }
-  for (int p = p0; p < p1; ++p) {
+  for (int p = p0 + m.pg; p < p1; p += m.PG) {
     const size_t pix = (size_t)b * HW + p;
 #pragma unroll
-    for (int i = 0; i < GN_MAXQ; ++i) {
-      const int q = tid + i * 256;
-      if (q < nq) {
-        float f[4], d[4];
-        unpack4(gn_load4(s, pix, q * 4), f);
-        unpack4(*(const uint2*)(dy + pix * C + q * 4), d);
+    for (int i = 0; i < GN_MAXS; ++i)
+      if (m.ch[i] >= 0) {
+        float f[8], d[8];
+        unpack8(gn_load8(s, pix, m.ch[i] * 8), f);
+        unpack8(*(const uint4*)(dy + pix * C + m.ch[i] * 8), d);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
           const float xh = (f[j] - mu[i][j]) * rs[i][j];
           float dz = d[j];
           if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
           s1[i][j] += dz; s2[i][j] += dz * xh;
         }
       }
-    }
   }
-#pragma unroll
-  for (int i = 0; i < GN_MAXQ; ++i) {
-    const int q = tid + i * 256;
-    if (q < nq)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = q * 4 + j;
-        lds[c * 2] = s1[i][j] * ga[i][j]; lds[c * 2 + 1] = s2[i][j] * ga[i][j];
-        if (chan_partial) {
-          float* o = chan_partial + (((size_t)b * gridDim.x + chunk) * C + c) * 2;
-          o[0] = s1[i][j]; o[1] = s2[i][j];
-        }
-      }
-  }
-  __syncthreads();
-  if (tid < G) {
-    float a = 0.f, c2 = 0.f;
-    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += lds[c * 2]; c2 += lds[c * 2 + 1]; }
-    float* o = partial + (((size_t)b * gridDim.x + chunk) * G + tid) * 2;
-    o[0] = a; o[1] = c2;
-  }
+  gn_block_reduce(m, C, G, s1, s2, lds, gamma, partial + ((size_t)b * gridDim.x + chunk) * G * 2,
+                  chan_partial ? chan_partial + ((size_t)b * gridDim.x + chunk) * C * 2 : nullptr);
 }
 
 // gsum[b][g] = (S1, S2) summed over chunks
@@ -210,48 +221,51 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t
                                                            const float* gamma, const float* beta, const bf16_t* add,
                                                            bf16_t* dx1, bf16_t* dx2, int HW, int G, int pix_per_chunk, int silu,
                                                            float inv_n) {
-  const int C = s.C1 + s.C2, nq = C >> 2, cpg = C / G;
-  const int b = blockIdx.y, tid = threadIdx.x;
+  const int C = s.C1 + s.C2, cpg = C / G;
+  const GNMap m(C);
+  const int b = blockIdx.y;
   const int p0 = blockIdx.x * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
-  float mu[GN_MAXQ][4], rs[GN_MAXQ][4], ga[GN_MAXQ][4], be[GN_MAXQ][4], g1[GN_MAXQ][4], g2[GN_MAXQ][4];
+  float mu[GN_MAXS][8], rs[GN_MAXS][8], ga[GN_MAXS][8], be[GN_MAXS][8], g1[GN_MAXS][8], g2[GN_MAXS][8];
 #pragma unroll
-  for (int i = 0; i < GN_MAXQ; ++i) {
-    const int q = tid + i * 256;
+  for (int i = 0; i < GN_MAXS; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
       mu[i][j] = rs[i][j] = ga[i][j] = be[i][j] = g1[i][j] = g2[i][j] = 0.f;
-      if (q < nq) {
-        const int c = q * 4 + j, g = c / cpg;
+      if (m.ch[i] >= 0) {
+        const int c = m.ch[i] * 8 + j, g = c / cpg;
         mu[i][j] = mean_rstd[((size_t)b * G + g) * 2]; rs[i][j] = mean_rstd[((size_t)b * G + g) * 2 + 1];
         ga[i][j] = gamma[c]; be[i][j] = beta[c];
         g1[i][j] = gsum[((size_t)b * G + g) * 2] * inv_n; g2[i][j] = gsum[((size_t)b * G + g) * 2 + 1] * inv_n;
       }
     }
-  }
-  for (int p = p0; p < p1; ++p) {
+  for (int p = p0 + m.pg; p < p1; p += m.PG) {
     const size_t pix = (size_t)b * HW + p;
 #pragma unroll
-    for (int i = 0; i < GN_MAXQ; ++i) {
-      const int q = tid + i * 256;
-      if (q < nq) {
-        float f[4], d[4], a[4] = {0.f, 0.f, 0.f, 0.f};
-        unpack4(gn_load4(s, pix, q * 4), f);
-        unpack4(*(const uint2*)(dy + pix * C + q * 4), d);
-        if (add) unpack4(*(const uint2*)(add + pix * C + q * 4), a);
+    for (int i = 0; i < GN_MAXS; ++i)
+      if (m.ch[i] >= 0) {
+        const int c = m.ch[i] * 8;
+        float f[8], d[8], a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        unpack8(gn_load8(s, pix, c), f);
+        unpack8(*(const uint4*)(dy + pix * C + c), d);
+        if (add) unpack8(*(const uint4*)(add + pix * C + c), a);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
           const float xh = (f[j] - mu[i][j]) * rs[i][j];
           float dz = d[j];
           if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
           f[j] = rs[i][j] * (dz * ga[i][j] - g1[i][j] - xh * g2[i][j]) + a[j];
         }
-        const int c = q * 4;
-        if (c < s.C1) *(uint2*)(dx1 + pix * s.C1 + c) = pack4(f);
-        else *(uint2*)(dx2 + pix * s.C2 + (c - s.C1)) = pack4(f);
+        if (c < s.C1) *(uint4*)(dx1 + pix * s.C1 + c) = pack8(f);
+        else *(uint4*)(dx2 + pix * s.C2 + (c - s.C1)) = pack8(f);
       }
-    }
   }
+}
+
+size_t gn_lds_bytes(int C) {
+  const int QW = C / 8;
+  const int PG = QW <= 256 ? 256 / QW : 1;
+  return ((size_t)PG * C * 2 + (size_t)C * 2) * sizeof(float);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,8 +391,8 @@ static int gn_check(const void* x1, int C1, const void* x2, int C2, int Bn, int 
   const int C = C1 + C2;
   E4T_REQUIRE(x1 && C1 > 0 && Bn > 0 && HW > 0 && G > 0, "groupnorm: bad arguments");
   E4T_REQUIRE((x2 != nullptr) == (C2 > 0), "groupnorm: x2/C2 mismatch");
-  E4T_REQUIRE(C % G == 0 && C1 % 4 == 0 && C2 % 4 == 0, "groupnorm: C=%d must divide into G=%d groups, C1/C2 %% 4 == 0", C, G);
-  E4T_REQUIRE(C <= GN_MAXQ * 256 * 4 && G <= 256, "groupnorm: C=%d too large", C);
+  E4T_REQUIRE(C % G == 0 && C1 % 8 == 0 && C2 % 8 == 0, "groupnorm: C=%d must divide into G=%d groups, C1/C2 %% 8 == 0", C, G);
+  E4T_REQUIRE(C <= GN_MAXS * 256 * 8 && G <= 256, "groupnorm: C=%d too large", C);
   return 0;
 }
 
@@ -389,7 +403,7 @@ extern "C" int e4t_groupnorm_stats(const void* x1, int C1, const void* x2, int C
   E4T_REQUIRE(workspace && ws_bytes >= (size_t)Bn * ch * G * 2 * sizeof(float), "groupnorm_stats: workspace too small");
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(ch, Bn), dim3(256), (size_t)C * 2 * sizeof(float), st, s, HW, G, ppc, (float*)workspace);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
   E4T_CHECK_LAUNCH("gn_stats_kernel");
   const int BG = Bn * G;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(BG, 256)), dim3(256), 0, st, (const float*)workspace, ch, G, BG,
@@ -422,7 +436,7 @@ extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2,
   float* gsum = partial + (size_t)Bn * ch * G * 2;
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ch, Bn), dim3(256), (size_t)C * 2 * sizeof(float), st, s, (const bf16_t*)dy, mean_rstd,
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, (const bf16_t*)dy, mean_rstd,
                      gamma, beta, HW, G, ppc, silu, partial, dgamma_dbeta_partial);
   E4T_CHECK_LAUNCH("gn_bwd_stats_kernel");
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(BG, 256)), dim3(256), 0, st, (const float*)partial, ch, G, BG, gsum);

@@ -34,7 +34,8 @@ class PreparedLinear:
 
     def get(self):
         wt = self.weight
-        key = (wt._version, ops.weights_epoch(), wt.data_ptr(), wt.device)
+        # frozen weights are cast exactly once; trainable ones also watch the epoch our raw-pointer AdamW bumps
+        key = (wt._version, ops.weights_epoch() if wt.requires_grad else -1, wt.data_ptr(), wt.device)
         if key != self.key:
             W = wt.detach().reshape(wt.shape[0], -1)
             N, K = W.shape
@@ -61,7 +62,8 @@ class PreparedConv:
 
     def get(self):
         wt = self.weight
-        key = (wt._version, ops.weights_epoch(), wt.data_ptr(), wt.device)
+        # frozen weights are cast exactly once; trainable ones also watch the epoch our raw-pointer AdamW bumps
+        key = (wt._version, ops.weights_epoch() if wt.requires_grad else -1, wt.data_ptr(), wt.device)
         if key != self.key:
             self.wf, self.wd = ops.backend().conv_weight_prepare(wt.detach())
             self.key = key

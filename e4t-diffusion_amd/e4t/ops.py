@@ -55,9 +55,9 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch):
     """Mirror of launch_gemm()'s tile / split-K heuristic (csrc/gemm.hip) -> workspace bytes it will want."""
     cd = lambda a, b: (a + b - 1) // b
     nkt = cd(K, 64)
-    if tile not in (64, 128):
+    if tile not in (64, 128, 256):
         tile = 128 if cd(M, 128) * cd(N, 128) * nb >= 384 else 64
-    tiles = cd(N, tile) * cd(M, tile) * nb
+    tiles = cd(N, 128 if tile == 256 else tile) * cd(M, tile) * nb
     if splitk <= 0:
         splitk = 1
         if tiles < 256 and nkt >= 16:
@@ -122,7 +122,7 @@ class HipBackend:
 
     @staticmethod
     def _tile(M, N, nb, tile):
-        if tile in (64, 128):
+        if tile in (64, 128, 256):
             return tile
         cd = lambda a, b: (a + b - 1) // b
         return 128 if cd(M, 128) * cd(N, 128) * nb >= 384 else 64

@@ -23,7 +23,7 @@ class VAEEncoder(_TorchVAEEncoder):
 
     # ---- one-time (frozen) weight preparation ------------------------------------------------------
     def _prepare(self):
-        key = (self.quant_conv.weight.data_ptr(), self.quant_conv.weight._version, ops.weights_epoch())
+        key = (self.quant_conv.weight.data_ptr(), self.quant_conv.weight._version)     # frozen: prepared once
         if self._cache is not None and self._cache["key"] == key:
             return self._cache
         be = ops.backend()

@@ -50,7 +50,8 @@ def check_gemm(hip, emu, dev):
     out = []
     cases = [  # M, N, K, tile, splitk
         (256, 256, 128, 0, 0), (200, 72, 64, 0, 0), (1000, 320, 320, 128, 1), (130, 200, 1032, 64, 3),
-        (16, 1280, 1280, 0, 0), (4096, 640, 2560, 0, 0), (64, 64, 4096, 0, 0),
+        (16, 1280, 1280, 0, 0), (4096, 640, 2560, 0, 0), (64, 64, 4096, 0, 0), (1000, 200, 328, 256, 1), (2048, 256, 64, 256, 1),
+        (700, 320, 1280, 256, 2),
     ]
     for i, (M, N, K, tile, sk) in enumerate(cases):
         g = gen(10 + i, dev)
@@ -96,7 +97,7 @@ def check_conv(hip, emu, dev):
         (3, 16, 16, 64, 128, CONV_S2, 8, 8, 0, 0), (2, 9, 9, 64, 64, CONV_S2, 5, 5, 0, 0),
         (2, 8, 8, 64, 64, CONV_UP2, 16, 16, 0, 0), (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 0, 0),
         (2, 5, 5, 64, 64, CONV_S2T, 9, 9, 0, 0), (4, 32, 32, 320, 320, CONV_S1, 32, 32, 128, 1),
-        (2, 16, 16, 64, 4, CONV_S1, 16, 16, 0, 0), (2, 16, 16, 128, 128, 5, 8, 8, 0, 0), (1, 64, 64, 128, 128, 5, 32, 32, 0, 0),
+        (2, 16, 16, 64, 4, CONV_S1, 16, 16, 0, 0), (3, 24, 24, 64, 192, CONV_S1, 24, 24, 256, 1), (2, 16, 16, 128, 128, 5, 8, 8, 0, 0), (1, 64, 64, 128, 128, 5, 32, 32, 0, 0),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
         g = gen(50 + i, dev)
