@@ -46,7 +46,9 @@ struct Cfg {
   static constexpr int NKS = DK / 16;
   static constexpr int NDT = DV / 32;
   static constexpr int KLD = DK + 8;   // LDS row stride (elements) of row-major tiles: 16-B aligned, conflict-free b128
-  static constexpr int TLD = 64 + 4;   // LDS row stride of transposed tiles [d][64 rows]: 8-B aligned, conflict-free b64
+  static constexpr int TLD = 64 + 8;   // LDS row stride of transposed tiles [d][64 rows]: 144 B, conflict-free b128
+  static constexpr int NCH = DH / 8;   // 16-byte chunks per source row
+  static constexpr int NIT = (32 * NCH + 255) / 256;   // (row pair, chunk) items per thread per 64-row tile
 };
 
 union Frag {
@@ -56,34 +58,74 @@ union Frag {
   uint32_t w[4];
 };
 
-// rows [r0, r0+64) x DH of a row-major global matrix -> lds[64][KLD]; rows >= R and pad columns are zero
-template <int DH>
-__device__ __forceinline__ void stage_rows(const bf16_t* g, int ld, int r0, int R, bf16_t* lds) {
-  constexpr int NCH = Cfg<DH>::DK / 8, KLD = Cfg<DH>::KLD;
-  for (int c = threadIdx.x; c < 64 * NCH; c += 256) {
-    const int row = c / NCH, ch = c - row * NCH;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r0 + row < R && ch < DH / 8) v = *(const uint4*)(g + (long long)(r0 + row) * ld + ch * 8);
-    *(uint4*)(lds + row * KLD + ch * 8) = v;
-  }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Column permutation of transposed tiles: inside every 16-column block the 4-groups [4,8) and [8,12) are swapped,
+// so that the 8 rows a 32x32 accumulator half holds for one MFMA k-step ({4hi..4hi+3} u {4hi+8..4hi+11}) sit in
+// 8 CONSECUTIVE columns -> one ds_read_b128 per A fragment.
+__device__ __forceinline__ int tcol(int c) {
+  const int j = c & 15;
+  return (c & ~15) | ((j >= 4 && j < 12) ? (j ^ 12) : j);     // 4..7 <-> 8..11
 }
-// the same rows, transposed: ldsT[d][TLD] with column = row - r0 (rows >= R are zero)
+
+// One 64-row x DH tile of a row-major global matrix, held in registers between its global load and its LDS
+// stores so that the load of tile t+1 is in flight while tile t is being consumed.  Item = (row pair, 16-B chunk).
 template <int DH>
-__device__ __forceinline__ void stage_rows_T(const bf16_t* g, int ld, int r0, int R, bf16_t* ldsT) {
-  constexpr int NCH = DH / 8, TLD = Cfg<DH>::TLD;
-  for (int it = threadIdx.x; it < 32 * NCH; it += 256) {
-    const int kp = it / NCH, ch = it - kp * NCH;
-    const int k0 = r0 + 2 * kp;
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
-    if (k0 < R) v0 = *(const uint4*)(g + (long long)k0 * ld + ch * 8);
-    if (k0 + 1 < R) v1 = *(const uint4*)(g + (long long)(k0 + 1) * ld + ch * 8);
-    const uint32_t a[4] = {v0.x, v0.y, v0.z, v0.w}, b[4] = {v1.x, v1.y, v1.z, v1.w};
+struct TileRegs {
+  using C = Cfg<DH>;
+  uint4 v[C::NIT][2];
+  __device__ __forceinline__ void load(const bf16_t* g, int ld, int r0, int R) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *(uint32_t*)(ldsT + (ch * 8 + 2 * j) * TLD + 2 * kp) = (a[j] & 0xffffu) | (b[j] << 16);
-      *(uint32_t*)(ldsT + (ch * 8 + 2 * j + 1) * TLD + 2 * kp) = (a[j] >> 16) | (b[j] & 0xffff0000u);
+    for (int it = 0; it < C::NIT; ++it) {
+      const int item = threadIdx.x + it * 256;
+      const int kp = item / C::NCH, ch = item - kp * C::NCH;
+      const int k0 = r0 + 2 * kp;
+      v[it][0] = make_uint4(0, 0, 0, 0); v[it][1] = make_uint4(0, 0, 0, 0);
+      if (item < 32 * C::NCH) {
+        if (k0 < R) v[it][0] = *(const uint4*)(g + (long long)k0 * ld + ch * 8);
+        if (k0 + 1 < R) v[it][1] = *(const uint4*)(g + (long long)(k0 + 1) * ld + ch * 8);
+      }
     }
   }
+  // row-major image lds[64][KLD]
+  __device__ __forceinline__ void store_rows(bf16_t* lds) const {
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int item = threadIdx.x + it * 256;
+      const int kp = item / C::NCH, ch = item - kp * C::NCH;
+      if (item < 32 * C::NCH) {
+        *(uint4*)(lds + (2 * kp) * C::KLD + ch * 8) = v[it][0];
+        *(uint4*)(lds + (2 * kp + 1) * C::KLD + ch * 8) = v[it][1];
+      }
+    }
+  }
+  // transposed image ldsT[d][TLD], column = tcol(row - r0)
+  __device__ __forceinline__ void store_T(bf16_t* ldsT) const {
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int item = threadIdx.x + it * 256;
+      const int kp = item / C::NCH, ch = item - kp * C::NCH;
+      if (item < 32 * C::NCH) {
+        const uint32_t a[4] = {v[it][0].x, v[it][0].y, v[it][0].z, v[it][0].w};
+        const uint32_t b[4] = {v[it][1].x, v[it][1].y, v[it][1].z, v[it][1].w};
+        const int col = tcol(2 * kp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          *(uint32_t*)(ldsT + (ch * 8 + 2 * j) * C::TLD + col) = (a[j] & 0xffffu) | (b[j] << 16);
+          *(uint32_t*)(ldsT + (ch * 8 + 2 * j + 1) * C::TLD + col) = (a[j] >> 16) | (b[j] & 0xffff0000u);
+        }
+      }
+    }
+  }
+};
+
+// the zero pad columns [DH, DK) of a row-major LDS tile are written once (the tile stores never touch them)
+template <int DH>
+__device__ __forceinline__ void zero_pad_cols(bf16_t* lds) {
+  constexpr int PADC = (Cfg<DH>::DK - DH) / 8;
+  if (PADC > 0)
+    for (int i = threadIdx.x; i < 64 * PADC; i += 256)
+      *(uint4*)(lds + (i / PADC) * Cfg<DH>::KLD + DH + (i % PADC) * 8) = make_uint4(0, 0, 0, 0);
 }
 
 // B-operand fragments of a row held in registers: 8 consecutive d starting at ks*16 + hi*8 (zero beyond DH / R)
@@ -99,14 +141,10 @@ __device__ __forceinline__ void load_row_frags(const bf16_t* g, int ld, int row,
   }
 }
 
-// A-operand from a transposed tile: row d, the 8 slots of MFMA k-step k2 of 32-row sub-tile `sub`:
-// columns sub*32 + k2*16 + 4*hi + {0..3} and + 8 + {0..3}  (= the order the 32x32 accumulator holds its rows)
+// A-operand from a transposed tile: row d, the 8 slots of MFMA k-step k2 of 32-row sub-tile `sub`
+// (= the order the 32x32 accumulator holds its rows; contiguous thanks to tcol())
 __device__ __forceinline__ bf16x8 load_T_frag(const bf16_t* ldsT, int TLD, int d, int sub, int k2, int hi) {
-  Frag t;
-  const bf16_t* p = ldsT + d * TLD + sub * 32 + k2 * 16 + 4 * hi;
-  t.h[0] = *(const uint2*)p;
-  t.h[1] = *(const uint2*)(p + 8);
-  return t.v;
+  return *(const bf16x8*)(ldsT + d * TLD + sub * 32 + k2 * 16 + 8 * hi);
 }
 // accumulator registers [8*k2, 8*k2+8) -> bf16 B-operand
 __device__ __forceinline__ bf16x8 pack_acc(const float* p, int k2) {
@@ -161,11 +199,19 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_fwd_kernel(AttnA
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = -INFINITY, l = 0.f;
 
+  TileRegs<DH> kr, vr;
+  kr.load(Kb, p.ldk, 0, p.S);
+  vr.load(Vb, p.ldv, 0, p.S);
+  zero_pad_cols<DH>(Ks);
   for (int kv0 = 0; kv0 < p.S; kv0 += 64) {
+    __syncthreads();                       // everyone finished reading the previous tile
+    kr.store_rows(Ks);
+    vr.store_T(Vt);
     __syncthreads();
-    stage_rows<DH>(Kb, p.ldk, kv0, p.S, Ks);
-    stage_rows_T<DH>(Vb, p.ldv, kv0, p.S, Vt);
-    __syncthreads();
+    if (kv0 + 64 < p.S) {                  // next tile's loads fly under this tile's MFMAs
+      kr.load(Kb, p.ldk, kv0 + 64, p.S);
+      vr.load(Vb, p.ldv, kv0 + 64, p.S);
+    }
     const int nsub = (p.S - kv0 > 32) ? 2 : 1;
     for (int sub = 0; sub < nsub; ++sub) {
       f32x16 s;
@@ -186,10 +232,10 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_fwd_kernel(AttnA
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);
-      const float alpha = exp2f(m - mn);
+      const float alpha = fast_exp2(m - mn);
       float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { pr[r] = exp2f(pr[r] - mn); rs += pr[r]; }
+      for (int r = 0; r < 16; ++r) { pr[r] = fast_exp2(pr[r] - mn); rs += pr[r]; }
       rs += __shfl_xor(rs, 32, 64);
       l = l * alpha + rs;
       m = mn;
@@ -261,12 +307,21 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(At
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
 
+  TileRegs<DH> kr, vr;
+  kr.load(Kb, p.ldk, 0, p.S);
+  vr.load(Vb, p.ldv, 0, p.S);
+  zero_pad_cols<DH>(Ks);
+  zero_pad_cols<DH>(Vs);
   for (int kv0 = 0; kv0 < p.S; kv0 += 64) {
     __syncthreads();
-    stage_rows<DH>(Kb, p.ldk, kv0, p.S, Ks);
-    stage_rows<DH>(Vb, p.ldv, kv0, p.S, Vs);
-    stage_rows_T<DH>(Kb, p.ldk, kv0, p.S, Kt);
+    kr.store_rows(Ks);
+    kr.store_T(Kt);
+    vr.store_rows(Vs);
     __syncthreads();
+    if (kv0 + 64 < p.S) {
+      kr.load(Kb, p.ldk, kv0 + 64, p.S);
+      vr.load(Vb, p.ldv, kv0 + 64, p.S);
+    }
     const int nsub = (p.S - kv0 > 32) ? 2 : 1;
     for (int sub = 0; sub < nsub; ++sub) {
       f32x16 s, dp;
@@ -283,7 +338,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(At
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kv0 + sub * 32 + acc_row(r, hi);
-        const float pv = key < p.S ? exp2f(s[r] * p.scale2 - Lq) : 0.f;
+        const float pv = key < p.S ? fast_exp2(s[r] * p.scale2 - Lq) : 0.f;
         ds[r] = pv * (dp[r] - Dq);
       }
       const bf16x8 f0 = pack_acc(ds, 0), f1 = pack_acc(ds, 1);
@@ -301,7 +356,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(At
 // backward dK, dV: one wave = 32 keys, loop over query tiles
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * C::KLD];
   __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * C::KLD];
@@ -325,18 +380,41 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_kernel(A
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dvt[dt][r] = 0.f; dkt[dt][r] = 0.f; }
 
-  for (int q0 = 0; q0 < p.T; q0 += 64) {
-    __syncthreads();
-    stage_rows<DH>(Qb, p.ldq, q0, p.T, Qs);
-    stage_rows<DH>(dOb, p.ldo, q0, p.T, dOs);
-    stage_rows_T<DH>(Qb, p.ldq, q0, p.T, Qt);
-    stage_rows_T<DH>(dOb, p.ldo, q0, p.T, dOt);
+  TileRegs<DH> qr, dor;
+  float l_next = 0.f, d_next = 0.f;
+  auto load_stats = [&](int q0) {
     if (threadIdx.x < 64) {
       const int qq = q0 + threadIdx.x;
-      Ls[threadIdx.x] = qq < p.T ? p.L[((long long)b * p.H + h) * p.T + qq] : 0.f;
-      Dls[threadIdx.x] = qq < p.T ? p.Delta[((long long)b * p.H + h) * p.T + qq] : 0.f;
+      l_next = qq < p.T ? p.L[((long long)b * p.H + h) * p.T + qq] : 0.f;
+      d_next = qq < p.T ? p.Delta[((long long)b * p.H + h) * p.T + qq] : 0.f;
+    }
+  };
+  constexpr bool PF = DH <= 80;            // register prefetch of the next tile (dh=160 would spill: load in place)
+  if (PF) {
+    qr.load(Qb, p.ldq, 0, p.T);
+    dor.load(dOb, p.ldo, 0, p.T);
+    load_stats(0);
+  }
+  zero_pad_cols<DH>(Qs);
+  zero_pad_cols<DH>(dOs);
+  for (int q0 = 0; q0 < p.T; q0 += 64) {
+    if (!PF) {
+      qr.load(Qb, p.ldq, q0, p.T);
+      dor.load(dOb, p.ldo, q0, p.T);
+      load_stats(q0);
     }
     __syncthreads();
+    qr.store_rows(Qs);
+    qr.store_T(Qt);
+    dor.store_rows(dOs);
+    dor.store_T(dOt);
+    if (threadIdx.x < 64) { Ls[threadIdx.x] = l_next; Dls[threadIdx.x] = d_next; }
+    __syncthreads();
+    if (PF && q0 + 64 < p.T) {
+      qr.load(Qb, p.ldq, q0 + 64, p.T);
+      dor.load(dOb, p.ldo, q0 + 64, p.T);
+      load_stats(q0 + 64);
+    }
     const int nsub = (p.T - q0 > 32) ? 2 : 1;
     for (int sub = 0; sub < nsub; ++sub) {
       f32x16 s, dp;
@@ -354,7 +432,7 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dkv_kernel(A
       for (int r = 0; r < 16; ++r) {
         const int ql = sub * 32 + acc_row(r, hi);
         const bool ok = (q0 + ql < p.T) && (key < p.S);
-        pr[r] = ok ? exp2f(s[r] * p.scale2 - Ls[ql]) : 0.f;
+        pr[r] = ok ? fast_exp2(s[r] * p.scale2 - Ls[ql]) : 0.f;
         ds[r] = pr[r] * (dp[r] - Dls[ql]);
       }
       const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);

@@ -557,9 +557,11 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
   if (tile != 64 && tile != 128 && tile != 256) {
+    // measured on MI355X (tools/sweep_small.py): 128x128 wins from one full round of the 256 CUs, and already from
+    // a quarter round when K is long (3x3 convs at the 16x16 / 8x8 levels) if split-K fills the chip
     const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch;
     const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
-    tile = (allow256 && auto256 && t256 >= 256) ? 256 : (t128 >= 384) ? 128 : 64;
+    tile = (allow256 && auto256 && t256 >= 256) ? 256 : (t128 >= 256 || (nkt >= 32 && t128 >= 64)) ? 128 : 64;
   }
   if (tile == 256 && !allow256) tile = 128;
   const int tm = tile, tn = tile == 256 ? 128 : tile;   // tile 256 means BM = 256, BN = 128
@@ -569,11 +571,14 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   if (splitk <= 0) {
     splitk = 1;
     const long long tiles = (long long)gx * gy * batch;
-    if (tiles < 256 && nkt >= 16) {
+    if (tile >= 128 && tiles < 256 && nkt >= 32) {
+      splitk = (int)((320 + tiles - 1) / tiles);
+      if (splitk > nkt / 8) splitk = nkt / 8;
+    } else if (tile == 64 && tiles < 256 && nkt >= 64) {
       splitk = (int)((512 + tiles - 1) / tiles);
-      if (splitk > nkt / 4) splitk = nkt / 4;
-      if (splitk < 1) splitk = 1;
+      if (splitk > nkt / 16) splitk = nkt / 16;
     }
+    if (splitk < 1) splitk = 1;
   }
   if (splitk > nkt) splitk = nkt;
   p.ktiles_per_split = cdiv(nkt, splitk);

@@ -56,12 +56,16 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch):
     cd = lambda a, b: (a + b - 1) // b
     nkt = cd(K, 64)
     if tile not in (64, 128, 256):
-        tile = 128 if cd(M, 128) * cd(N, 128) * nb >= 384 else 64
+        t128 = cd(M, 128) * cd(N, 128) * nb
+        tile = 128 if (t128 >= 256 or (nkt >= 32 and t128 >= 64)) else 64
     tiles = cd(N, 128 if tile == 256 else tile) * cd(M, tile) * nb
     if splitk <= 0:
         splitk = 1
-        if tiles < 256 and nkt >= 16:
-            splitk = max(1, min(cd(512, tiles), nkt // 4))
+        if tile >= 128 and tiles < 256 and nkt >= 32:
+            splitk = min(cd(320, tiles), nkt // 8)
+        elif tile == 64 and tiles < 256 and nkt >= 64:
+            splitk = min(cd(512, tiles), nkt // 16)
+        splitk = max(splitk, 1)
     splitk = min(splitk, nkt)
     splitk = cd(nkt, cd(nkt, splitk))
     return 4 * splitk * nb * M * N if (splitk > 1 or reduce_batch) else 0
@@ -125,7 +129,7 @@ class HipBackend:
         if tile in (64, 128, 256):
             return tile
         cd = lambda a, b: (a + b - 1) // b
-        return 128 if cd(M, 128) * cd(N, 128) * nb >= 384 else 64
+        return 128 if cd(M, 128) * cd(N, 128) * nb >= 256 else 64     # (long-K promotion needs K: bench keys are approximate)
 
     # ------------------------------------------------------------------ workspaces
     def workspace(self, nbytes: int, device) -> torch.Tensor:
