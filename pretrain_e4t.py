@@ -1,0 +1,157 @@
+"""E4T pre-training on MI355X — same command-line surface as the reference's pretrain_e4t.py (:66-122), driving the
+native modules (e4t-diffusion_amd/e4t) and trainer.  One process per GPU:
+
+    python pretrain_e4t.py --synthetic_data --train_batch_size 16 --max_train_steps 100 --output_dir out
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 pretrain_e4t.py --synthetic_data ...
+    accelerate launch pretrain_e4t.py ...        # LOCAL_RANK / WORLD_SIZE from the launcher are honoured
+
+Without network access there are no pretrained weights: `--pretrained_model_name_or_path` may point at a local directory
+holding `unet.pt` / `vae.pt` / `text_encoder.pt` state dicts (SD key names); otherwise weights are randomly initialised.
+Artefacts keep the reference's names: `{output_dir}/{step}/config.json`, `weight_offsets.pt`, `encoder.pt` (:515-528).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "e4t-diffusion_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# the reference's prompt templates are data, not code: a few generic ones suffice for synthetic runs (:36-62)
+TEMPLATES = {
+    "normal": ["a photo of {placeholder_token}", "a rendering of {placeholder_token}", "a cropped photo of {placeholder_token}",
+               "a close-up photo of {placeholder_token}", "a bright photo of {placeholder_token}", "a good photo of {placeholder_token}"],
+    "art": ["a painting in the style of {placeholder_token}", "a rendering in the style of {placeholder_token}",
+            "a picture in the style of {placeholder_token}", "the painting in the style of {placeholder_token}"],
+}
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description="E4T pre-training (MI355X-native)")
+    p.add_argument("--pretrained_model_name_or_path", type=str, default=None)
+    p.add_argument("--clip_model_name_or_path", type=str, default="ViT-H-14::laion2b_s32b_b79k")
+    p.add_argument("--domain_class_token", type=str, default="art")
+    p.add_argument("--domain_embed_scale", type=float, default=0.1)
+    p.add_argument("--placeholder_token", type=str, default="*s")
+    p.add_argument("--reg_lambda", type=float, default=0.01)
+    p.add_argument("--prompt_template", type=str, default="art", choices=sorted(TEMPLATES))
+    p.add_argument("--unfreeze_clip_vision", action="store_true")
+    p.add_argument("--train_image_dataset", type=str, default=None)
+    p.add_argument("--webdataset", action="store_true")
+    p.add_argument("--iterable_dataset", action="store_true")
+    p.add_argument("--resolution", type=int, default=512)
+    p.add_argument("--train_batch_size", type=int, default=16)
+    p.add_argument("--learning_rate", type=float, default=1e-6)
+    p.add_argument("--scale_lr", action="store_true")
+    p.add_argument("--lr_scheduler", type=str, default="constant")
+    p.add_argument("--lr_warmup_steps", type=int, default=0)
+    p.add_argument("--gradient_accumulation_steps", type=int, default=1)
+    p.add_argument("--max_train_steps", type=int, default=30000)
+    p.add_argument("--dataloader_num_workers", type=int, default=0)
+    p.add_argument("--output_dir", type=str, default="e4t-model")
+    p.add_argument("--seed", type=int, default=None)
+    p.add_argument("--use_8bit_adam", action="store_true")
+    p.add_argument("--mixed_precision", type=str, default="bf16", choices=["no", "fp16", "bf16"])
+    p.add_argument("--enable_xformers_memory_efficient_attention", action="store_true")
+    p.add_argument("--checkpointing_steps", type=int, default=10000)
+    p.add_argument("--log_steps", type=int, default=10 ** 9)
+    p.add_argument("--report_to", type=str, default="none")
+    p.add_argument("--local_rank", type=int, default=-1)
+    p.add_argument("--resume_from_checkpoint", type=str, default=None)
+    p.add_argument("--prediction_type", type=str, default="epsilon", choices=["epsilon", "v_prediction"])
+    # extensions
+    p.add_argument("--synthetic_data", action="store_true", help="device-resident random images/tokens (benchmarking, CI)")
+    p.add_argument("--unet_variant", type=str, default="sd14", choices=["sd14", "sd21"])
+    args = p.parse_args()
+    if args.use_8bit_adam:
+        p.error("--use_8bit_adam (bitsandbytes) is CUDA-only and not part of the MI355X path; the fused fp32 AdamW kernel is used")
+    if args.mixed_precision == "fp16":
+        p.error("the native kernels compute in bf16 with fp32 accumulation; use --mixed_precision bf16")
+    if args.gradient_accumulation_steps != 1:
+        p.error("gradient accumulation > 1 is not wired into this script yet")
+    env_rank = int(os.environ.get("LOCAL_RANK", -1))
+    if env_rank != -1:
+        args.local_rank = env_rank
+    return args
+
+
+def synthetic_batches(args, dev, rank, world):
+    g = torch.Generator(device=dev)
+    step = 0
+    while True:
+        g.manual_seed((args.seed or 0) * 100003 + step * world + rank)
+        px = torch.rand((args.train_batch_size, 3, args.resolution, args.resolution), generator=g, device=dev) * 2 - 1
+        ids = torch.randint(1000, 40000, (args.train_batch_size, 77), generator=g, device=dev)
+        pidx = torch.randint(1, 12, (args.train_batch_size,), generator=g, device=dev)
+        yield px, ids, pidx
+        step += 1
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = max(args.local_rank, 0)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
+        random.seed(args.seed)
+
+    from bench import build_models                               # same model factory as the benchmark
+    from e4t.trainer import E4TTrainer
+    from e4t.utils import save_config, save_e4t_encoder, save_e4t_unet
+    unet, enc, text, vae = build_models(dev, args.unet_variant, seed=args.seed or 0)
+    if args.pretrained_model_name_or_path and os.path.isdir(args.pretrained_model_name_or_path):
+        for name, mod in (("unet", unet), ("vae", vae), ("text_encoder", text)):
+            f = os.path.join(args.pretrained_model_name_or_path, f"{name}.pt")
+            if os.path.exists(f):
+                mod.load_state_dict(torch.load(f, map_location="cpu"), strict=False)
+    if args.unfreeze_clip_vision:
+        enc.clip_vision.requires_grad_(True)
+    if args.enable_xformers_memory_efficient_attention:
+        unet.enable_xformers_memory_efficient_attention()        # selects the native flash-attention processor
+    lr = args.learning_rate * (args.train_batch_size * world if args.scale_lr else 1)
+    tr = E4TTrainer(unet, enc, text, vae, lr=lr, domain_embed_scale=args.domain_embed_scale, reg_lambda=args.reg_lambda,
+                    prediction_type=args.prediction_type, class_token_id=1125, device=dev)
+    if not args.synthetic_data:
+        raise SystemExit("only --synthetic_data is available in this build: the reference's HF-streaming / webdataset / "
+                         "albumentations loaders (pretrain_e4t.py:137-352) are host-side I/O outside the hot-path scope")
+    data = synthetic_batches(args, dev, rank, world)
+
+    def save(step):
+        if rank != 0:
+            return
+        d = os.path.join(args.output_dir, str(step))
+        save_config(vars(args), d)
+        save_e4t_unet(unet, d)
+        save_e4t_encoder(enc, d)
+
+    t0 = time.perf_counter()
+    for step in range(1, args.max_train_steps + 1):
+        loss, ld, lr_ = tr.train_step(*next(data))
+        if step % 10 == 0 or step == 1:
+            torch.cuda.synchronize()
+            if rank == 0:
+                dt = time.perf_counter() - t0
+                print(f"step {step}: train/loss {float(loss):.5f} loss_diff {float(ld):.5f} loss_reg {float(lr_):.5f} "
+                      f"lr {lr:.3e}  {args.train_batch_size * world * step / dt:.1f} img/s", flush=True)
+        if step % args.checkpointing_steps == 0:
+            save(step)
+    if world > 1:
+        dist.barrier()
+    save(args.max_train_steps)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""CPU, world_size 2 over gloo: the data-parallel path of the trainer (one process per rank, all-reduce of the flat
+gradient buffer, 1/N folded into AdamW) gives every rank the same parameters, equal to a single-process step that
+accumulates both ranks' batches."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup_paths():
+    for p in (os.path.join(ROOT, "e4t-diffusion_amd"), ROOT, HERE, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _build():
+    from test_train_step_host_logic import build
+    from e4t import ops
+    from emu_backend import EmuBackend
+    ops.set_backend(EmuBackend(round_bf16=False))
+    ops.ACT = torch.float32
+    return build()
+
+
+def _batch(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    B = 1
+    return dict(pixels=torch.rand(B, 3, 64, 64, generator=g) * 2 - 1, latents=torch.randn(B, 4, 16, 16, generator=g) * 0.18215,
+                noise=torch.randn(B, 4, 16, 16, generator=g), t=torch.randint(0, 1000, (B,), generator=g), ids=torch.randint(1, 99, (B, 9), generator=g),
+                pidx=torch.tensor([3]))
+
+
+def _worker(rank, world, port, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from e4t.trainer import E4TTrainer
+    _, _, n_unet, n_enc, text = _build()
+    tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"))
+    assert tr.world == world
+    b = _batch(rank)
+    tr.train_step(b["pixels"], b["ids"], b["pidx"], noise=b["noise"], timesteps=b["t"], latents=b["latents"])
+    torch.save(tr.flat.data.clone(), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_accumulated_single_process(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    p0, p1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(p0, p1), "ranks diverged after the all-reduced step"
+    # single process: accumulate both batches' gradients, average inside AdamW
+    _setup_paths()
+    from e4t import ops
+    old_b, old_act = ops._backend, ops.ACT
+    try:
+        from e4t.trainer import E4TTrainer
+        _, _, n_unet, n_enc, text = _build()
+        tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"))
+        for r in range(world):
+            b = _batch(r)
+            loss, _, _ = tr.losses(b["pixels"], b["latents"], b["noise"], b["t"], b["ids"], b["pidx"])
+            loss.backward()
+        tr.world = world
+        tr.optimizer_step()
+        # Adam's first step moves a coordinate by ~lr*g/|g|: where g is at rounding-noise level the summation order
+        # (all-reduce vs in-place accumulation) may flip it.  Everything else must agree to fp32 rounding.
+        diff = (p0 - tr.flat.data).abs()
+        assert float(diff.max()) <= 2.2e-3
+        assert float((diff > 3e-6).float().mean()) < 1e-4
+    finally:
+        ops.set_backend(old_b)
+        ops.ACT = old_act
