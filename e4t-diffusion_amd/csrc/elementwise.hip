@@ -372,10 +372,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* x, int L, int
   __shared__ float red[16];
   bf16_t* row = x + (long long)blockIdx.x * ld;
   const int nch = L >> 3;
-  float v[4][8];
+  float v[8][8];
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const int c = threadIdx.x + i * 256;
     if (c < nch) {
       unpack8(*(const uint4*)(row + c * 8), v[i]);
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* x, int L, int
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const int c = threadIdx.x + i * 256;
     if (c < nch)
 #pragma unroll
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* x, int L, int
   s = block_sum(s, red + 8);
   const float inv = 1.f / s;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
     const int c = threadIdx.x + i * 256;
     if (c < nch) {
 #pragma unroll
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void im2col3_kernel(const float* px, bf16_t* o
 }  // namespace
 
 extern "C" int e4t_softmax_rows(void* x, long long rows, int L, int ld, e4t_stream s) {
-  E4T_REQUIRE(x && rows > 0 && L > 0 && L % 8 == 0 && L <= 8192 && ld >= L && ld % 8 == 0, "softmax_rows: bad arguments");
+  E4T_REQUIRE(x && rows > 0 && L > 0 && L % 8 == 0 && L <= 16384 && ld >= L && ld % 8 == 0, "softmax_rows: bad arguments");
   E4T_REQUIRE(rows <= 0x7fffffffLL, "softmax_rows: too many rows");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)s, (bf16_t*)x, L, ld);
   E4T_CHECK_LAUNCH("softmax_rows_kernel");
