@@ -445,3 +445,64 @@ extern "C" int e4t_im2col3_rgb(const float* pixels_nchw, void* out, int Bn, int 
   E4T_CHECK_LAUNCH("im2col3_kernel");
   return 0;
 }
+
+// ---- im2col-transpose for 3x3 conv weight gradients (tuning mode: every UNet conv weight trains) ----
+// out[(tap*C + c)][m] = X[b][iy][ix][c] (zero outside), m = (b, oy, ox) over the conv's OUTPUT pixels, row stride ldo.
+// With dY^T this turns dW[co][tap][ci] = sum_m dY[m][co] * X[src(m,tap)][ci] into one NT GEMM whose contraction
+// runs over the pixels.  mode: E4T_CONV_S1 / _S2 / _UP2 (same gather rules as the forward conv).
+namespace {
+__global__ __launch_bounds__(256) void im2col_T_kernel(const bf16_t* x, bf16_t* out, int Hin, int Win, int C, int Hout, int Wout,
+                                                       long long Mpix, int ldo, int mode) {
+  __shared__ bf16_t tile[64][66];
+  const int tap = blockIdx.z, ky = tap / 3, kx = tap - ky * 3;
+  const long long m0 = (long long)blockIdx.y * 64;
+  const int c0 = blockIdx.x * 64;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int rl = ty * 4 + k;
+    const long long m = m0 + rl;
+    bool ok = m < Mpix;
+    long long src = 0;
+    if (ok) {
+      const int hw = Hout * Wout;
+      const int b = (int)(m / hw);
+      const int rem = (int)(m - (long long)b * hw);
+      const int oy = rem / Wout, ox = rem - oy * Wout;
+      int iy, ix;
+      if (mode == E4T_CONV_S1) { iy = oy + ky - 1; ix = ox + kx - 1; ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win; }
+      else if (mode == E4T_CONV_S2) { iy = 2 * oy + ky - 1; ix = 2 * ox + kx - 1; ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win; }
+      else { iy = oy + ky - 1; ix = ox + kx - 1; ok = iy >= 0 && iy < 2 * Hin && ix >= 0 && ix < 2 * Win; iy >>= 1; ix >>= 1; }
+      src = (((long long)b * Hin + iy) * Win + ix) * C;
+    }
+    const int c = c0 + tx * 4;
+    uint2 v = make_uint2(0, 0);
+    if (ok && c < C) v = *(const uint2*)(x + src + c);      // C % 4 == 0
+    tile[rl][tx * 4 + 0] = (bf16_t)(v.x & 0xffff); tile[rl][tx * 4 + 1] = (bf16_t)(v.x >> 16);
+    tile[rl][tx * 4 + 2] = (bf16_t)(v.y & 0xffff); tile[rl][tx * 4 + 3] = (bf16_t)(v.y >> 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cl = ty * 4 + k, c = c0 + cl;
+    const long long m = m0 + tx * 4;
+    if (c < C && m < ldo) {                                   // ldo % 4 == 0; columns in [Mpix, ldo) receive the zero fill
+      uint2 o;
+      o.x = (uint32_t)tile[tx * 4 + 0][cl] | ((uint32_t)tile[tx * 4 + 1][cl] << 16);
+      o.y = (uint32_t)tile[tx * 4 + 2][cl] | ((uint32_t)tile[tx * 4 + 3][cl] << 16);
+      *(uint2*)(out + ((long long)tap * C + c) * ldo + m) = o;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int e4t_im2col_T(const void* x, void* out, int Bn, int Hin, int Win, int C, int Hout, int Wout, int ldo, int mode, e4t_stream s) {
+  E4T_REQUIRE(x && out && Bn > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "im2col_T: bad arguments");
+  E4T_REQUIRE(C % 4 == 0 && ldo % 4 == 0 && (long long)ldo >= (long long)Bn * Hout * Wout, "im2col_T: C, ldo must be multiples of 4, ldo >= B*Hout*Wout");
+  E4T_REQUIRE(mode == E4T_CONV_S1 || mode == E4T_CONV_S2 || mode == E4T_CONV_UP2, "im2col_T: mode must be S1, S2 or UP2");
+  const long long Mpix = (long long)Bn * Hout * Wout;
+  hipLaunchKernelGGL(im2col_T_kernel, dim3(cdiv(C, 64), (unsigned)((ldo + 63) / 64), 9), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)out,
+                     Hin, Win, C, Hout, Wout, Mpix, ldo, mode);
+  E4T_CHECK_LAUNCH("im2col_T_kernel");
+  return 0;
+}

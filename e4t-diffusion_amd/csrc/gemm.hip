@@ -119,16 +119,14 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][
       }
     __syncthreads();                     // (a wave only reads back its own region; the barrier orders the LDS traffic)
     constexpr int CPR = WN / 8;          // 16-byte chunks per row
-    constexpr int RPI = 64 / CPR;        // rows per wave-instruction
-    const int cch = lane % CPR, rsub = lane / CPR;
-    const int col = nw + cch * 8;
     bf16_t* Cb = (bf16_t*)p.C;
     const bf16_t* Rb = (const bf16_t*)p.residual;
 #pragma unroll
-    for (int it = 0; it < WM / RPI; ++it) {
-      const int rl = it * RPI + rsub;
-      const int row = mw + rl;
-      if (row < p.M && col < p.N) {
+    for (int it = 0; it < (WM * CPR + 63) / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int rl = idx / CPR, cch = idx - rl * CPR;
+      const int row = mw + rl, col = nw + cch * 8;
+      if (idx < WM * CPR && row < p.M && col < p.N) {
         uint4 v = *(const uint4*)(stage + rl * ELD + cch * 8);
         if (Rb) {
           float a[8], b[8];
@@ -556,15 +554,19 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   int tile = tile_hint;
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
-  if (tile != 64 && tile != 128 && tile != 256) {
+  if (tile != 64 && tile != 128 && tile != 256 && tile != 160) {
     // measured on MI355X (tools/sweep_small.py): 128x128 wins from one full round of the 256 CUs, and already from
     // a quarter round when K is long (3x3 convs at the 16x16 / 8x8 levels) if split-K fills the chip
     const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch;
     const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
     tile = (allow256 && auto256 && t256 >= 256) ? 256 : (t128 >= 256 || (nkt >= 32 && t128 >= 64)) ? 128 : 64;
+    // every channel count of the SD UNets is a multiple of 160 but 320 / 640 / 960 are not multiples of 128: a 128x160
+    // tile has no N padding there (conv 640->640 @32x32: 863 vs 589 TF)
+    if (allow256 && tile == 128 && p.N % 160 == 0 && p.N <= 960 && (long long)cdiv(p.M, 128) * (p.N / 160) * batch >= 128) tile = 160;
   }
   if (tile == 256 && !allow256) tile = 128;
-  const int tm = tile, tn = tile == 256 ? 128 : tile;   // tile 256 means BM = 256, BN = 128
+  if (tile == 160 && !allow256) tile = 128;
+  const int tm = tile == 160 ? 128 : tile, tn = tile == 256 ? 128 : tile;   // 256 = 256x128, 160 = 128x160
   const int gx = cdiv(p.N, tn), gy = cdiv(p.M, tm);
   // --- split-K: only when the grid underfills the chip and K is long ---
   int splitk = splitk_req;
@@ -602,6 +604,9 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 0, 3>), grid, block, 0, st, p);
+    } else if (tile == 160) {
+      if (conv) hipLaunchKernelGGL((gemm_dma_kernel<128, 160, 4, 1, 1, 2>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<128, 160, 4, 1, 0, 2>), grid, block, 0, st, p);
     } else if (tile == 128) {
       if (conv) hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 2, 2, 1, 2>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 2, 2, 0, 2>), grid, block, 0, st, p);

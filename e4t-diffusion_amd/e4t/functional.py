@@ -220,13 +220,11 @@ class ConvFn(torch.autograd.Function):
         ctx.cin = x.shape[1]
         ctx.has = (bias is not None, rowbias is not None, residual is not None)
         ctx.res_dtype = residual.dtype if residual is not None else None
+        ctx.save_for_backward(x if weight.requires_grad else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        if ctx.needs_input_grad[1]:
-            raise NotImplementedError("ConvFn: 3x3 weight gradients (tuning mode) are not built yet; "
-                                      "freeze the conv weights (pretrain never reads their gradients)")
         be = ops.backend()
         B, Hin, Win, Hout, Wout = ctx.geom
         has_bias, has_rb, has_res = ctx.has
@@ -252,6 +250,16 @@ class ConvFn(torch.autograd.Function):
                 dx = be.sumpool2(up, B, Hin, Win)
             if dx.shape[1] != ctx.cin:
                 dx = dx[:, : ctx.cin].contiguous()
+        dw = None
+        if ctx.needs_input_grad[1]:
+            # dW[co][tap][ci] = sum_pixels dY[m][co] * X[src(m, tap)][ci]: gather-transpose of X, transpose of dY, one
+            # split-K NT GEMM contracting over the pixels (tuning mode only; pre-training freezes these weights)
+            (x,) = ctx.saved_tensors
+            wshape = ctx.prep.weight.shape
+            xcolT = be.im2col_T(x, B, Hin, Win, Hout, Wout, ctx.mode)
+            dyT = be.transpose(dyb, pad_to=xcolT.shape[1])
+            dwk = be.gemm(dyT, xcolT, out_dtype=f32)                       # [Cout, 9 * Cx]
+            dw = dwk.view(wshape[0], 9, ctx.cin)[:, :, : wshape[1]].permute(0, 2, 1).reshape(wshape).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(0)
         if has_rb and ctx.needs_input_grad[3]:
@@ -260,7 +268,7 @@ class ConvFn(torch.autograd.Function):
             drb = drb * float(Hout * Wout)
         if has_res and ctx.needs_input_grad[4]:
             dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
-        return dx, None, db, drb, dres, None, None, None, None
+        return dx, dw, db, drb, dres, None, None, None, None
 
 
 def conv3x3(x, weight, bias, prep, geom, mode=_C.CONV_S1, rowbias=None, residual=None, out_f32=False):

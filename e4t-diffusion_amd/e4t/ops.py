@@ -55,10 +55,12 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch):
     """Mirror of launch_gemm()'s tile / split-K heuristic (csrc/gemm.hip) -> workspace bytes it will want."""
     cd = lambda a, b: (a + b - 1) // b
     nkt = cd(K, 64)
-    if tile not in (64, 128, 256):
+    if tile not in (64, 128, 256, 160):
         t128 = cd(M, 128) * cd(N, 128) * nb
         tile = 128 if (t128 >= 256 or (nkt >= 32 and t128 >= 64)) else 64
-    tiles = cd(N, 128 if tile == 256 else tile) * cd(M, tile) * nb
+        if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
+            tile = 160
+    tiles = cd(N, 128 if tile == 256 else tile) * cd(M, 128 if tile == 160 else tile) * nb
     if splitk <= 0:
         splitk = 1
         if tile >= 128 and tiles < 256 and nkt >= 32:
@@ -126,7 +128,7 @@ class HipBackend:
 
     @staticmethod
     def _tile(M, N, nb, tile):
-        if tile in (64, 128, 256):
+        if tile in (64, 128, 256, 160):
             return tile
         cd = lambda a, b: (a + b - 1) // b
         return 128 if cd(M, 128) * cd(N, 128) * nb >= 256 else 64     # (long-K promotion needs K: bench keys are approximate)
@@ -371,6 +373,15 @@ class HipBackend:
 
     def adamw(self, p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
         _C.check(self.lib.e4t_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, grad_scale, _stream()), "e4t_adamw")
+
+    def im2col_T(self, x, B, Hin, Win, Hout, Wout, mode):
+        """bf16 [B*Hin*Win, C] -> [9*C, ld] with ld = B*Hout*Wout rounded up to 8 (zero padded): B operand of the wgrad GEMM"""
+        assert x.is_contiguous()
+        Cn = x.shape[1]
+        ld = (B * Hout * Wout + 7) // 8 * 8
+        out = torch.empty((9 * Cn, ld), dtype=bf16, device=x.device)
+        _C.check(self.lib.e4t_im2col_T(_ptr(x), _ptr(out), B, Hin, Win, Cn, Hout, Wout, ld, mode, _stream()), "e4t_im2col_T")
+        return out
 
     def softmax_rows_(self, x):
         """in-place softmax over the last dim of a bf16 matrix [..., L] with contiguous rows"""

@@ -30,12 +30,14 @@ def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012, device=None)
     return torch.cumprod(1.0 - betas, dim=0)
 
 
-def select_trainable(unet, encoder):
-    """pretrain_e4t.py:274-278; every other UNet parameter is frozen (the reference never reads their grads)."""
+def select_trainable(unet, encoder, tuning=False):
+    """pre-training (pretrain_e4t.py:274-278): encoder params with requires_grad + UNet params whose name contains "wo";
+    every other UNet parameter is frozen (the reference never reads their grads).
+    domain tuning (tuning_e4t.py:139-147): the whole UNet + the encoder's trainable parameters."""
     for n, p in unet.named_parameters():
-        p.requires_grad_("wo" in n)
+        p.requires_grad_(tuning or "wo" in n)
     named = [(f"e4t_encoder.{n}", p) for n, p in encoder.named_parameters() if p.requires_grad]
-    named += [(f"unet.{n}", p) for n, p in unet.named_parameters() if "wo" in n]
+    named += [(f"unet.{n}", p) for n, p in unet.named_parameters() if tuning or "wo" in n]
     return named
 
 
@@ -65,7 +67,8 @@ class FlatParams:
 class E4TTrainer:
     def __init__(self, unet, e4t_encoder, text_encoder, vae, *, lr=1e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                  domain_embed_scale=0.1, reg_lambda=0.01, prediction_type="epsilon", class_token_id=0,
-                 empty_prompt_ids: Optional[torch.Tensor] = None, process_group=None, device=None):
+                 empty_prompt_ids: Optional[torch.Tensor] = None, process_group=None, device=None, tuning=False,
+                 max_grad_norm: Optional[float] = None):
         self.unet, self.encoder, self.text_encoder, self.vae = unet, e4t_encoder, text_encoder, vae
         self.device = device or next(unet.parameters()).device
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -74,7 +77,8 @@ class E4TTrainer:
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         self.step_count = 0
         self.acp = ddpm_alphas_cumprod(device=self.device)
-        named = select_trainable(unet, e4t_encoder)
+        self.max_grad_norm = max_grad_norm
+        named = select_trainable(unet, e4t_encoder, tuning=tuning)
         # order: the stacked first_linears weights, then their biases (contiguous stacks), then the rest
         fl_w = [p for n, p in named if ".first_linears." in n and n.endswith(".weight")]
         fl_b = [p for n, p in named if ".first_linears." in n and n.endswith(".bias")]
@@ -143,6 +147,14 @@ class E4TTrainer:
         for o in range(0, g.numel(), bucket):
             torch.distributed.all_reduce(g[o:o + bucket], group=self.pg)
 
+    def clip_grad_norm(self):
+        """tuning_e4t.py:329-335 — global L2 norm over the flat gradient (one reduction kernel), scale folded on the device
+        (no host sync).  Under DP the gradient is the SUM over ranks here, so the norm is taken of sum/world."""
+        if self.max_grad_norm is None:
+            return
+        norm = ops.backend().sumsq(self.flat.grad).sqrt() / self.world
+        self.flat.grad.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))
+
     def optimizer_step(self):
         self.step_count += 1
         ops.backend().adamw(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
@@ -168,6 +180,7 @@ class E4TTrainer:
         loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
         loss.backward()
         self.all_reduce_grads()
+        self.clip_grad_norm()
         self.optimizer_step()
         self.zero_grad()
         return loss.detach(), loss_diff.detach(), loss_reg.detach()

@@ -286,6 +286,19 @@ class EmuBackend:
         bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
         p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
 
+    def im2col_T(self, x, B, Hin, Win, Hout, Wout, mode):
+        Cn = x.shape[1]
+        xi = x.float().reshape(B, Hin, Win, Cn).permute(0, 3, 1, 2)
+        if mode == CONV_UP2:
+            xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+        cols = F.unfold(xi, 3, padding=1, stride=2 if mode == CONV_S2 else 1)        # [B, C*9, Ho*Wo], index c*9 + tap
+        assert cols.shape[2] == Hout * Wout
+        cols = cols.view(B, Cn, 9, Hout * Wout).permute(2, 1, 0, 3).reshape(9 * Cn, B * Hout * Wout)   # (tap*C + c, m)
+        ld = (B * Hout * Wout + 7) // 8 * 8
+        out = torch.zeros((9 * Cn, ld), dtype=f32, device=x.device)
+        out[:, : B * Hout * Wout] = cols
+        return self._act(out)
+
     def softmax_rows_(self, x):
         x.copy_(torch.softmax(x.float(), dim=-1).to(x.dtype))
         return x

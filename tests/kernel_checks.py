@@ -51,7 +51,7 @@ def check_gemm(hip, emu, dev):
     cases = [  # M, N, K, tile, splitk
         (256, 256, 128, 0, 0), (200, 72, 64, 0, 0), (1000, 320, 320, 128, 1), (130, 200, 1032, 64, 3),
         (16, 1280, 1280, 0, 0), (4096, 640, 2560, 0, 0), (64, 64, 4096, 0, 0), (1000, 200, 328, 256, 1), (2048, 256, 64, 256, 1),
-        (700, 320, 1280, 256, 2),
+        (700, 320, 1280, 256, 2), (900, 320, 384, 160, 1), (300, 480, 128, 160, 2), (513, 200, 72, 160, 1),
     ]
     for i, (M, N, K, tile, sk) in enumerate(cases):
         g = gen(10 + i, dev)
@@ -97,7 +97,7 @@ def check_conv(hip, emu, dev):
         (3, 16, 16, 64, 128, CONV_S2, 8, 8, 0, 0), (2, 9, 9, 64, 64, CONV_S2, 5, 5, 0, 0),
         (2, 8, 8, 64, 64, CONV_UP2, 16, 16, 0, 0), (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 0, 0),
         (2, 5, 5, 64, 64, CONV_S2T, 9, 9, 0, 0), (4, 32, 32, 320, 320, CONV_S1, 32, 32, 128, 1),
-        (2, 16, 16, 64, 4, CONV_S1, 16, 16, 0, 0), (3, 24, 24, 64, 192, CONV_S1, 24, 24, 256, 1), (2, 16, 16, 128, 128, 5, 8, 8, 0, 0), (1, 64, 64, 128, 128, 5, 32, 32, 0, 0),
+        (2, 16, 16, 64, 4, CONV_S1, 16, 16, 0, 0), (3, 24, 24, 64, 192, CONV_S1, 24, 24, 256, 1), (3, 24, 24, 64, 320, CONV_S1, 24, 24, 160, 1), (2, 16, 16, 128, 128, 5, 8, 8, 0, 0), (1, 64, 64, 128, 128, 5, 32, 32, 0, 0),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
         g = gen(50 + i, dev)
@@ -239,6 +239,9 @@ def check_streaming(hip, emu, dev):
     emu.adamw(p2, gr, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3, 0.5)
     out += [("adamw p", rel(p, p2), TOLF), ("adamw m", rel(m, m2), TOLF), ("adamw v", rel(v, v2), TOLF)]
     out.append(("sumsq", rel(hip.sumsq(gr), emu.sumsq(gr)), 1e-4))
+    for mode, (Bn, Hin, Hout) in ((1, (2, 12, 12)), (2, (3, 9, 5)), (3, (2, 6, 12))):
+        xi = rnd(g, Bn * Hin * Hin, 72, dev=dev)
+        out.append((f"im2col_T mode{mode}", rel(hip.im2col_T(xi, Bn, Hin, Hin, Hout, Hout, mode), emu.im2col_T(xi, Bn, Hin, Hin, Hout, Hout, mode)), 0.0))
     sc = rnd(g, 3, 100, 4096, scale=2.0, dev=dev)
     out.append(("softmax_rows 4096", rel(hip.softmax_rows_(sc.clone()), emu.softmax_rows_(sc.clone())), TOL1))
     sc = rnd(g, 77, 64, scale=3.0, dev=dev)

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_symbols():
     src = open(os.path.join(ROOT, "include", "e4t_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return set(re.findall(r"\b(e4t_[a-z0-9_]+)\s*\(", src))
+    return set(re.findall(r"\b(e4t_[A-Za-z0-9_]+)\s*\(", src))
 
 
 def test_library_exports_every_declared_symbol():

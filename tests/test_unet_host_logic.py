@@ -104,3 +104,25 @@ def test_standalone_weightoffsets_module(emu_fp32):
     torch.testing.assert_close(o_n, o_r, rtol=1e-5, atol=1e-6)
     for (n, a), (_, b) in zip(nat.named_parameters(), ref.named_parameters()):
         torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-5, msg=lambda m, n=n: f"{n}: {m}")
+
+
+def test_tuning_mode_all_unet_gradients(emu_fp32):
+    """tuning_e4t.py:139-147: every UNet parameter trains — conv weight gradients (gather-transpose + GEMM), GN/LN affine
+    gradients, plain linear weight/bias gradients, and dW = dW_eff o (1 + offsets) for the modulated projections."""
+    cfg = orc.tiny_unet_config(ctx_dim=64)
+    ref, nat = build_pair(cfg, seed=4)
+    g = torch.Generator().manual_seed(9)
+    B = 2
+    x = torch.randn(B, 4, 16, 16, generator=g)
+    t = torch.tensor([500, 20])
+    ctx = torch.randn(B, 6, 64, generator=g)
+    w = torch.randn(B, 4, 16, 16, generator=g)
+    (ref(x, t, ctx) * w).sum().backward()
+    (nat(x, t, ctx).sample * w).sum().backward()
+    gr = dict(ref.named_parameters())
+    n = 0
+    for name, p in nat.named_parameters():
+        assert p.grad is not None, name
+        torch.testing.assert_close(p.grad, gr[name].grad, rtol=5e-3, atol=3e-4, msg=lambda m, name=name: f"{name}: {m}")
+        n += 1
+    assert n == len(gr)
