@@ -28,6 +28,7 @@
 #include "common.h"
 #include "../../include/e4t_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -491,40 +492,66 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int frow = lane & 31, fhi = lane >> 5;
+  // fragment offsets inside a stage (elements), one per (fragment, k-step): computed once; the stage base is a
+  // compile-time constant of the unrolled loop below, so every ds_read_b128 is "vgpr + immediate"
+  int a_off[FM][BK / 16], b_off[FN][BK / 16];
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int r = wm * WM + i * 32 + frow;
+      a_off[i][ks] = r * BK + (((ks * 2 + fhi) ^ ((r >> 1) & 7)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int r = wn * WN + j * 32 + frow;
+      b_off[j][ks] = BM * BK + r * BK + (((ks * 2 + fhi) ^ ((r >> 1) & 7)) * 8);
+    }
+  }
   // prologue: LOOK tiles in flight
 #pragma unroll
   for (int s = 0; s < LOOK; ++s)
     if (kt_begin + s < kt_end) issue_tile(kt_begin + s, smem + s * TILE);
-  int cur = 0, nxt = LOOK;                             // ring slots of tile kt and of tile kt+LOOK
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+
+  auto body = [&](auto CURc, int kt) {
+    constexpr int CUR = decltype(CURc)::value;
+    constexpr int NXT = (CUR + LOOK) % NSTAGE;
     // this wave's pieces of tile kt have landed once at most the pieces of the (LOOK-1) newer tiles are outstanding
     if (LOOK == 2 && kt + 1 < kt_end) wait_vmcnt<NA + NB>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                      // ... everyone's have; and everyone finished reading slot `nxt`
-    if (kt + LOOK < kt_end) issue_tile(kt + LOOK, smem + nxt * TILE);
-    const bf16_t* As = smem + cur * TILE;
-    const bf16_t* Bs = As + BM * BK;
+    __builtin_amdgcn_s_barrier();                      // ... everyone's have; and everyone finished reading slot NXT
+    const bf16_t* st = smem + CUR * TILE;
+    bf16x8 af[2][FM], bfr[2][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[0][i] = *(const bf16x8*)(st + a_off[i][0]);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bfr[0][j] = *(const bf16x8*)(st + b_off[j][0]);
+    if (kt + LOOK < kt_end) issue_tile(kt + LOOK, smem + NXT * TILE);   // after the first fragment reads are in flight
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 af[FM], bfr[FN];
+      const int c = ks & 1, n = c ^ 1;
+      if (ks + 1 < BK / 16) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int r = wm * WM + i * 32 + frow;
-        af[i] = *(const bf16x8*)(As + r * BK + (((ks * 2 + fhi) ^ ((r >> 1) & 7)) * 8));
-      }
+        for (int i = 0; i < FM; ++i) af[n][i] = *(const bf16x8*)(st + a_off[i][ks + 1]);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int r = wn * WN + j * 32 + frow;
-        bfr[j] = *(const bf16x8*)(Bs + r * BK + (((ks * 2 + fhi) ^ ((r >> 1) & 7)) * 8));
+        for (int j = 0; j < FN; ++j) bfr[n][j] = *(const bf16x8*)(st + b_off[j][ks + 1]);
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c][i], bfr[c][j], acc[i][j], 0, 0, 0);
     }
-    cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-    nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+  };
+  {
+    int kt = kt_begin;
+    for (; kt + NSTAGE <= kt_end; kt += NSTAGE) {
+      body(std::integral_constant<int, 0>{}, kt);
+      body(std::integral_constant<int, 1>{}, kt + 1);
+      if (NSTAGE == 3) body(std::integral_constant<int, 2 % NSTAGE>{}, kt + 2);
+    }
+    if (kt < kt_end) { body(std::integral_constant<int, 0>{}, kt); ++kt; }
+    if (kt < kt_end) { body(std::integral_constant<int, 1>{}, kt); ++kt; }
   }
   __syncthreads();   // all fragment reads done before the epilogue reuses the LDS
   write_tile<WM, WN, FM, FN>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
