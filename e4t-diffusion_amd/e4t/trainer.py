@@ -78,6 +78,8 @@ class E4TTrainer:
         self.step_count = 0
         self.acp = ddpm_alphas_cumprod(device=self.device)
         self.max_grad_norm = max_grad_norm
+        self.tuning = tuning
+        self._armed = False
         named = select_trainable(unet, e4t_encoder, tuning=tuning)
         # order: the stacked first_linears weights, then their biases (contiguous stacks), then the rest
         fl_w = [p for n, p in named if ".first_linears." in n and n.endswith(".weight")]
@@ -93,6 +95,7 @@ class E4TTrainer:
             st = lambda buf, o, shape: buf[o:o + math.prod(shape)].view(shape)
             e4t_encoder.adopt_stacks(st(self.flat.data, o_w, (n, hid, hid)), st(self.flat.data, o_b, (n, hid)),
                                      st(self.flat.grad, o_w, (n, hid, hid)), st(self.flat.grad, o_b, (n, hid)))
+        self._setup_overlap(named, n)
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         ops.bump_weights_epoch()
@@ -138,14 +141,70 @@ class E4TTrainer:
         w = next(self.vae.parameters())
         return self.vae.encode_sample(pixel_values.to(w.dtype), vae_eps).float()
 
+    # ---- data-parallel gradient averaging, overlapped with the backward ---------------------------------------------
+    # The flat gradient is laid out [E4T head | mid/down weight offsets | up weight offsets].  In the backward the up-block
+    # offsets are final first (their bank's node fires when the full-pass backward leaves the up blocks), the head next
+    # (before the encoder-pass backward starts), the mid/down offsets last.  Each region's all-reduce is enqueued on RCCL's
+    # stream the moment it is final (async_op), in 256 MB buckets; the step only waits for them before AdamW.
+    def _setup_overlap(self, named, n_first):
+        self._works, self._done = [], set()
+        self.regions = None
+        if self.world <= 1 or self.tuning:
+            return
+        params = self.flat.params
+        idx_unet = next((i for i, (n, _) in enumerate(named) if n.startswith("unet.")), None)
+        names = [n for n, _ in named]
+        # `named` order == flat order only after the first_linears re-ordering: recompute from the flat list
+        pid = {id(p): n for n, p in named}
+        flat_names = [pid[id(p)] for p in params]
+        first_unet = next(i for i, n in enumerate(flat_names) if n.startswith("unet."))
+        first_up = next(i for i, n in enumerate(flat_names) if n.startswith("unet.up_blocks."))
+        assert all(n.startswith("unet.up_blocks.") for n in flat_names[first_up:]) and all(not n.startswith("unet.") for n in flat_names[:first_unet])
+        o = self.flat.offsets
+        self.regions = dict(H=(0, o[first_unet]), D=(o[first_unet], o[first_up]), U=(o[first_up], self.flat.numel))
+        up_bank, md_bank = self.unet.wo_banks
+        up_bank.on_backward_done = lambda b: self._reduce_region("U")
+        md_bank.on_backward_done = lambda b: self._reduce_region("D")
+        enc = self.encoder
+        if not any(p.requires_grad for p in enc.clip_vision.parameters()):
+            # the last head gradients to be accumulated are those of unet_feature_embedder.0 (deepest head layer)
+            last = [enc.unet_feature_embedder[0].weight, enc.unet_feature_embedder[0].bias]
+            self._head_pending = 0
+
+            def hook(_p):
+                self._head_pending -= 1
+                if self._head_pending == 0:
+                    self._reduce_region("H")
+            for p in last:
+                p.register_post_accumulate_grad_hook(hook)
+            self._head_last = len(last)
+        else:
+            self._head_last = 0
+
+    def _reduce_region(self, key):
+        if self.regions is None or key in self._done or not self._armed:
+            return
+        self._done.add(key)
+        a, b = self.regions[key]
+        g = self.flat.grad
+        bucket = 64 << 20          # 256 MB fp32: xGMI rings are per-link bound, large buckets run them at rate
+        for o in range(a, b, bucket):
+            self._works.append(torch.distributed.all_reduce(g[o:min(o + bucket, b)], group=self.pg, async_op=True))
+
     def all_reduce_grads(self):
         if self.world <= 1:
             return
-        # finalisation order = flat order reversed is not guaranteed; v1: bucketed all-reduce after backward
-        g = self.flat.grad
-        bucket = 64 << 20   # 256 MB fp32 buckets: large enough to run the xGMI links at rate
-        for o in range(0, g.numel(), bucket):
-            torch.distributed.all_reduce(g[o:o + bucket], group=self.pg)
+        if self.regions is None:
+            g = self.flat.grad
+            bucket = 64 << 20
+            for o in range(0, g.numel(), bucket):
+                torch.distributed.all_reduce(g[o:o + bucket], group=self.pg)
+            return
+        for key in ("U", "H", "D"):           # whatever was not triggered during the backward
+            self._reduce_region(key)
+        for w in self._works:
+            w.wait()
+        self._works, self._done = [], set()
 
     def clip_grad_norm(self):
         """tuning_e4t.py:329-335 — global L2 norm over the flat gradient (one reduction kernel), scale folded on the device
@@ -178,7 +237,10 @@ class E4TTrainer:
         if timesteps is None:
             timesteps = torch.randint(0, self.acp.shape[0], (B,), device=dev).long()
         loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
+        self._armed = True
+        self._head_pending = getattr(self, "_head_last", 0)
         loss.backward()
+        self._armed = False
         self.all_reduce_grads()
         self.clip_grad_norm()
         self.optimizer_step()

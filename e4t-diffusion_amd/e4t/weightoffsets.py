@@ -79,6 +79,7 @@ class WOBank:
         self._token_used = False
         self._key = None
         self._root = None
+        self.on_backward_done = None
 
     # -- construction -----------------------------------------------------------------------
     def add(self, linears: List[nn.Linear], wos: List[WeightOffsets]) -> int:
@@ -186,3 +187,5 @@ class WOBank:
                 e._lin.weight.grad = e.g_W
         for s in self.slots:
             s.dweff_valid = False
+        if self.on_backward_done is not None:
+            self.on_backward_done(self)          # e.g. the trainer launches this bank's gradient all-reduce now
