@@ -35,14 +35,22 @@ extern "C" void e4t_set_error(const char* msg);
 
 // ---- bf16 <-> f32 -------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (NaN kept quiet)
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even.  Written as native __bf16 conversions so that hipcc emits gfx950's
+// v_cvt_pk_bf16_f32 (ONE VALU op per pair) instead of ~10 integer ops of a hand-rolled rounding.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_native;
+typedef __attribute__((ext_vector_type(2))) float f32x2_native;
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  const __bf16 b = (__bf16)f;
+  bf16_t u;
+  __builtin_memcpy(&u, &b, 2);
+  return u;
 }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32x2_native f = {lo, hi};
+  const bf16x2_native v = __builtin_convertvector(f, bf16x2_native);
+  uint32_t u;
+  __builtin_memcpy(&u, &v, 4);
+  return u;
 }
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
