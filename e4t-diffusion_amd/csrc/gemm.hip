@@ -335,6 +335,23 @@ __device__ __forceinline__ void dma16(const bf16_t* src, bf16_t* lds_wave_base) 
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Workgroup -> output-tile mapping.  The dispatcher deals consecutive workgroups (x fastest) round-robin over the 8 XCDs,
+// each with its own 4-MiB L2: with the plain blockIdx mapping the tiles sharing an A row panel (and, for the 3x3 convs,
+// the neighbouring image rows of the halo) sit in 8 different L2s and every panel is fetched 8 times.  Re-deal so that
+// the workgroups of one XCD own one CONTIGUOUS chunk of the tile raster, and walk that chunk in groups of 8 row panels
+// so the ~64 tiles in flight on an XCD form a compact 8 x 8 block of the output.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
+  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
+  const int lin = blockIdx.y * gx + blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, v = lin & 7;
+  const int lin2 = (v < r ? v * (q + 1) : r * (q + 1) + (v - r) * q) + (lin >> 3);
+  constexpr int GM = 8;
+  const int per = GM * gx, grp = lin2 / per, l = lin2 - grp * per;
+  const int first = grp * GM, gsz = min(gy - first, GM);
+  bx = l / gsz;
+  by = first + (l - bx * gsz);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -354,7 +371,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  int tile_x, tile_y;
+  xcd_tile(tile_x, tile_y);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
 
   const int nkt = (p.K + BK - 1) / BK;
   const int bz = blockIdx.z / p.splitk, sz = blockIdx.z - bz * p.splitk;
