@@ -132,12 +132,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # synthetic input batches are generated up front and sit in HBM when the timed region starts (a pool of distinct
+    # batches, cycled): the timed region is the training step, not torch's RNG
+    pool = [batch(s) for s in range(min(4, args.warmup + args.steps))]
     for s in range(args.warmup):
-        tr.train_step(*batch(s))
+        tr.train_step(*pool[s % len(pool)])
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        loss, _, _ = tr.train_step(*batch(args.warmup + s))
+        loss, _, _ = tr.train_step(*pool[(args.warmup + s) % len(pool)])
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev)
@@ -159,8 +162,11 @@ def main():
         hip.prof = None
         dom = max(agg, key=lambda k: agg[k][1])
         fl, sec, n = agg[dom]
-        names = {"conv128": "gemm_kernel<128,128,2,2,1> (implicit-GEMM 3x3 conv)", "conv64": "gemm_kernel<64,64,2,2,1> (implicit-GEMM 3x3 conv)",
-                 "gemm128": "gemm_kernel<128,128,2,2,0>", "gemm64": "gemm_kernel<64,64,2,2,0>"}
+        names = {"conv128": "gemm_dma_kernel<128,128,4,2,conv,2> (implicit-GEMM 3x3 conv, 8 waves)",
+                 "conv160": "gemm_dma_kernel<128,160,4,1,conv,2> (implicit-GEMM 3x3 conv)",
+                 "conv64": "gemm_dma_kernel<64,64,2,2,conv,2> (implicit-GEMM 3x3 conv)",
+                 "gemm128": "gemm_dma_kernel<128,128,4,2,dense,2>", "gemm160": "gemm_dma_kernel<128,160,4,1,dense,2>",
+                 "gemm64": "gemm_dma_kernel<64,64,2,2,dense,2>"}
         roof = dict(bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / sec / MFMA_PEAK, traffic=None,
                     kernel=names.get(dom, dom), launches_per_step=n, avg_launch_ms=sec / n * 1e3,
                     per_kernel={k: dict(tflops=v[0] / v[1] / 1e12, ms_per_step=v[1] * 1e3, launches=v[2]) for k, v in sorted(agg.items())},

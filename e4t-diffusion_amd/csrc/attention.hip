@@ -26,6 +26,10 @@
 
 namespace {
 
+#ifndef DKV_WAVES
+#define DKV_WAVES 2
+#endif
+
 struct AttnArgs {
   const bf16_t *Q, *K, *V, *dO;
   const bf16_t* O;
@@ -69,7 +73,10 @@ __device__ __forceinline__ int tcol(int c) {
 }
 
 // One 64-row x DH tile of a row-major global matrix, held in registers between its global load and its LDS
-// stores so that the load of tile t+1 is in flight while tile t is being consumed.  Item = (row pair, 16-B chunk).
+// stores so that the load of tile t+1 is in flight while tile t is being consumed.  Item = (row pair, 16-B chunk),
+// lanes running along the row pairs: the 32 lanes of a ds_write_b32 group of the transposed store then hit 32
+// different columns of ONE d row = 32 different banks (chunk-major lanes were 5-way conflicted at dh=40: rows 8 apart
+// are 288 dwords apart = the same bank; PMC: a third of all LDS cycles were those conflicts).
 template <int DH>
 struct TileRegs {
   using C = Cfg<DH>;
@@ -78,7 +85,7 @@ struct TileRegs {
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
       const int item = threadIdx.x + it * 256;
-      const int kp = item / C::NCH, ch = item - kp * C::NCH;
+      const int ch = item >> 5, kp = item & 31;
       const int k0 = r0 + 2 * kp;
       v[it][0] = make_uint4(0, 0, 0, 0); v[it][1] = make_uint4(0, 0, 0, 0);
       if (item < 32 * C::NCH) {
@@ -92,7 +99,7 @@ struct TileRegs {
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
       const int item = threadIdx.x + it * 256;
-      const int kp = item / C::NCH, ch = item - kp * C::NCH;
+      const int ch = item >> 5, kp = item & 31;
       if (item < 32 * C::NCH) {
         *(uint4*)(lds + (2 * kp) * C::KLD + ch * 8) = v[it][0];
         *(uint4*)(lds + (2 * kp + 1) * C::KLD + ch * 8) = v[it][1];
@@ -104,7 +111,7 @@ struct TileRegs {
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
       const int item = threadIdx.x + it * 256;
-      const int kp = item / C::NCH, ch = item - kp * C::NCH;
+      const int ch = item >> 5, kp = item & 31;
       if (item < 32 * C::NCH) {
         const uint32_t a[4] = {v[it][0].x, v[it][0].y, v[it][0].z, v[it][0].w};
         const uint32_t b[4] = {v[it][1].x, v[it][1].y, v[it][1].z, v[it][1].w};
@@ -177,7 +184,7 @@ __device__ __forceinline__ void store_T_acc(const f32x16* acc, float mul, bf16_t
 // forward
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vt[C::DV * C::TLD];
@@ -224,11 +231,19 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_fwd_kernel(AttnA
       }
       float pr[16];
       float mx = -INFINITY;
+      if (kv0 + 64 > p.S) {                // ragged last tile only: keys beyond S get -inf
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + sub * 32 + acc_row(r, hi);
-        pr[r] = key < p.S ? s[r] * p.scale2 : -INFINITY;
-        mx = fmaxf(mx, pr[r]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + sub * 32 + acc_row(r, hi);
+          pr[r] = key < p.S ? s[r] * p.scale2 : -INFINITY;
+          mx = fmaxf(mx, pr[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pr[r] = s[r] * p.scale2;
+          mx = fmaxf(mx, pr[r]);
+        }
       }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m, mx);
@@ -283,7 +298,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p, int Bn) {
 // backward dQ: one wave = 32 queries, loop over key tiles
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * C::KLD];
@@ -335,11 +350,16 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(At
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dof[ks], dp, 0, 0, 0);
       }
       float ds[16];
+      if (kv0 + 64 > p.S) {                // ragged last tile only
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kv0 + sub * 32 + acc_row(r, hi);
-        const float pv = key < p.S ? fast_exp2(s[r] * p.scale2 - Lq) : 0.f;
-        ds[r] = pv * (dp[r] - Dq);
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + sub * 32 + acc_row(r, hi);
+          const float pv = key < p.S ? fast_exp2(s[r] * p.scale2 - Lq) : 0.f;
+          ds[r] = pv * (dp[r] - Dq);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] * p.scale2 - Lq) * (dp[r] - Dq);
       }
       const bf16x8 f0 = pack_acc(ds, 0), f1 = pack_acc(ds, 1);
 #pragma unroll
@@ -356,13 +376,13 @@ __global__ __launch_bounds__(256, (DH <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(At
 // backward dK, dV: one wave = 32 keys, loop over query tiles
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * C::KLD];
   __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * C::KLD];
   __shared__ __attribute__((aligned(16))) bf16_t Qt[C::DV * C::TLD];
   __shared__ __attribute__((aligned(16))) bf16_t dOt[C::DV * C::TLD];
-  __shared__ float Ls[64], Dls[64];
+  __shared__ __attribute__((aligned(16))) float Ls[64], Dls[64];
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, hi = lane >> 5;
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
   auto load_stats = [&](int q0) {
     if (threadIdx.x < 64) {
       const int qq = q0 + threadIdx.x;
-      l_next = qq < p.T ? p.L[((long long)b * p.H + h) * p.T + qq] : 0.f;
+      l_next = qq < p.T ? p.L[((long long)b * p.H + h) * p.T + qq] : INFINITY;
       d_next = qq < p.T ? p.Delta[((long long)b * p.H + h) * p.T + qq] : 0.f;
     }
   };
@@ -427,13 +447,20 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(A
         const bf16x8 a2 = *(const bf16x8*)(dOs + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vf[ks], dp, 0, 0, 0);
       }
+      // No masks: a query row beyond T carries L = +inf (-> p = 0 exactly, dO row = 0 keeps dp finite), and a key lane
+      // beyond S only pollutes its own accumulator column, which is never stored.
       float pr[16], ds[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = sub * 32 + acc_row(r, hi);
-        const bool ok = (q0 + ql < p.T) && (key < p.S);
-        pr[r] = ok ? fast_exp2(s[r] * p.scale2 - Ls[ql]) : 0.f;
-        ds[r] = pr[r] * (dp[r] - Dls[ql]);
+      for (int g = 0; g < 4; ++g) {
+        const float4 l4 = *(const float4*)(Ls + sub * 32 + 8 * g + 4 * hi);     // acc rows 4g..4g+3 = 4 consecutive queries
+        const float4 d4 = *(const float4*)(Dls + sub * 32 + 8 * g + 4 * hi);
+        const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * g + j;
+          pr[r] = fast_exp2(s[r] * p.scale2 - lq[j]);
+          ds[r] = pr[r] * (dp[r] - dq[j]);
+        }
       }
       const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);
       const bf16x8 sf0 = pack_acc(ds, 0), sf1 = pack_acc(ds, 1);

@@ -61,6 +61,7 @@ struct GemmArgs {
   float* ws;
   int ktiles_per_split;
   int splitk;       // splits per batch entry (grid.z = batch * splitk)
+  int group_m;      // row panels per raster group (xcd_tile)
   int reduce_batch; // partials of all (batch, split) pairs are summed into ONE C
   int fast_epi;     // bf16 C, 16-byte aligned rows: LDS-staged vectorised epilogue
   long long strideA, strideB, strideC, strideBias;
@@ -340,12 +341,11 @@ __device__ __forceinline__ void dma16(const bf16_t* src, bf16_t* lds_wave_base) 
 // the neighbouring image rows of the halo) sit in 8 different L2s and every panel is fetched 8 times.  Re-deal so that
 // the workgroups of one XCD own one CONTIGUOUS chunk of the tile raster, and walk that chunk in groups of 8 row panels
 // so the ~64 tiles in flight on an XCD form a compact 8 x 8 block of the output.
-__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int GM) {
   const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
   const int lin = blockIdx.y * gx + blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, v = lin & 7;
   const int lin2 = (v < r ? v * (q + 1) : r * (q + 1) + (v - r) * q) + (lin >> 3);
-  constexpr int GM = 8;
   const int per = GM * gx, grp = lin2 / per, l = lin2 - grp * per;
   const int first = grp * GM, gsz = min(gy - first, GM);
   bx = l / gsz;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   int tile_x, tile_y;
-  xcd_tile(tile_x, tile_y);
+  xcd_tile(tile_x, tile_y, p.group_m);
   const int m0 = tile_y * BM, n0 = tile_x * BN;
 
   const int nkt = (p.K + BK - 1) / BK;
@@ -643,6 +643,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   }
   if (!(splitk > 1 || p.reduce_batch)) p.ws = nullptr;
   p.splitk = splitk;
+  static const int gm_env = getenv("E4T_GEMM_GM") ? atoi(getenv("E4T_GEMM_GM")) : 8;
+  p.group_m = gm_env;
   p.fast_epi = !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                (p.strideC % 8 == 0) && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
   dim3 grid(gx, gy, splitk * batch), block(256);

@@ -127,11 +127,16 @@ class HipBackend:
         return r
 
     @staticmethod
-    def _tile(M, N, nb, tile):
+    def _tile(M, N, K, nb, tile):
+        """Mirror of launch_gemm()'s tile choice (csrc/gemm.hip), used only to label bench.py's per-kernel timings."""
         if tile in (64, 128, 256, 160):
             return tile
         cd = lambda a, b: (a + b - 1) // b
-        return 128 if cd(M, 128) * cd(N, 128) * nb >= 256 else 64     # (long-K promotion needs K: bench keys are approximate)
+        t128 = cd(M, 128) * cd(N, 128) * nb
+        tile = 128 if (t128 >= 256 or (cd(K, 64) >= 32 and t128 >= 64)) else 64
+        if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
+            tile = 160
+        return tile
 
     # ------------------------------------------------------------------ workspaces
     def workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -188,7 +193,7 @@ class HipBackend:
         ws = self.workspace(need, a.device) if need else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
-        self._timed(f"gemm{self._tile(M, N, nb, tile)}", 2.0 * M * N * K * nb,
+        self._timed(f"gemm{self._tile(M, N, K, nb, tile)}", 2.0 * M * N * K * nb,
                     lambda: _C.check(self.lib.e4t_gemm_nt(C.byref(d), st), "e4t_gemm_nt"))
         return out
 
@@ -215,7 +220,7 @@ class HipBackend:
         ws = self.workspace(need, x.device) if need else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
-        self._timed(f"conv{self._tile(M, Cout, 1, tile)}", 2.0 * M * Cout * 9 * Cin,
+        self._timed(f"conv{self._tile(M, Cout, 9 * Cin, 1, tile)}", 2.0 * M * Cout * 9 * Cin,
                     lambda: _C.check(self.lib.e4t_conv3x3(C.byref(d), st), "e4t_conv3x3"))
         return out
 
