@@ -578,6 +578,286 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   write_tile<WM, WN, FM, FN>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 "ping-pong" variant for the big, K-deep shapes (VAE / 1280-channel convs, FF GEMMs).
+//
+// The 128-wide tiles above need ~64 B/clk/CU of L2->LDS traffic at MFMA peak and hide latency by occupancy
+// (2 workgroups x 8 waves); they top out near 1 PFLOP/s.  This one halves the operand traffic per flop and
+// schedules explicitly instead:
+//   * 8 waves = 2 groups (wr) x 4 column slices (wc), wave tile 128 x 64 (4 x 2 accumulators of 32x32);
+//     wave w and w+4 share a SIMD, one from each group;
+//   * a K-tile is consumed in 4 PHASES of 8 MFMAs: (rows 0-63 | 64-127 of the wave tile) x (k 0-31 | 32-63).
+//     Each phase = [L: fragment ds_reads + one 16-KiB operand quarter DMA issue + counted vmcnt] barrier
+//     [M: 8 MFMAs at raised priority] barrier.  Group 1 runs one barrier interval behind group 0, so on every
+//     SIMD one wave is in its MFMA segment while the other does its LDS/DMA segment;
+//   * the operand stream is cut in QUARTERS (A|B) x (k-lo|k-hi), 256 rows x 32 k = 16 KiB each, two buffers of four:
+//     a quarter slot is re-staged exactly 2 phases after its last ds_read and first read >= 5 phases after its
+//     issue, so the DMA has > 2500 clk of flight time and vmcnt never drains to 0 inside the loop
+//     (each phase issues 2 DMA instructions per wave; vmcnt(8) after the issue = everything older than the 4
+//     newest quarters has landed; a quarter is read one phase after the wait + barrier that retires it);
+//   * quarter rows are 64 B: LDS slot p of row r holds logical 16-B chunk p ^ ((r >> 2) & 3) (source-side swizzle,
+//     conflict-free ds_read_b128 for the 32x32x16 fragment lane groups).
+// Requires K % 64 == 0 (no ragged K-tile); M / N edges are handled by zero rows and the bounds-checked epilogue.
+// ------------------------------------------------------------------------------------------------
+#ifdef PP_TRACE     // debug builds only (tools/pp_trace.sh): cycle stamps of one wave per group
+__device__ unsigned long long g_pp_trace[2 * 6 * 64];
+#ifdef PP_TRACE_MIN
+#define PP_STAMP(slot) do { if ((slot) == 0 && tracing && tr_n < 64) tr[wr][tr_n * 6] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PP_STAMP(slot) do { if (tracing && tr_n < 64) tr[wr][tr_n * 6 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#endif
+#else
+#define PP_STAMP(slot) do { } while (0)
+#endif
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, HK = 32;
+  constexpr int QUART = 256 * HK;                        // elements per quarter
+  constexpr int EPI = 8 * 64 * (64 + 8);                 // write_tile staging: 8 waves x 64 x 72
+  constexpr int SMEM = EPI > 8 * QUART ? EPI : 8 * QUART;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+#ifdef PP_TRACE
+  __shared__ unsigned long long tr[2][6 * 64];
+  const bool tracing = blockIdx.x == 1 && blockIdx.y == 1 && blockIdx.z == 0 && wc == 0 && lane == 0;
+  int tr_n = -32;       // skip the first 32 phases
+#endif
+  int tile_x, tile_y;
+  xcd_tile(tile_x, tile_y, p.group_m);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+
+  const int nkt = p.K / BK;
+  const int bz = blockIdx.z / p.splitk, sz = blockIdx.z - bz * p.splitk;
+  p.A += bz * p.strideA;
+  if (p.A2) p.A2 += bz * p.strideA;
+  p.B += bz * p.strideB;
+  if (p.bias) p.bias += bz * p.strideBias;
+  if (!p.reduce_batch) {
+    if (p.flags & E4T_OUT_F32) p.C = (float*)p.C + bz * p.strideC;
+    else p.C = (bf16_t*)p.C + bz * p.strideC;
+  }
+  const int kt_begin = sz * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nkt) kt_end = nkt;
+
+  const bf16_t* const zero = (const bf16_t*)&g_zero16;
+  // DMA: one wave-instruction = 16 rows x 64 B; wave w feeds quarter rows 32w + 16j + (lane >> 2), j = 0, 1
+  const int drow = lane >> 2, dslot = lane & 3;
+  long long a_base[2];
+  int a_oy[2], a_ox[2], a_kc[2];
+  bool a_ok[2];
+  const bf16_t* b_row[2];
+  int b_kc[2];
+  bool b_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = wave * 32 + j * 16 + drow;
+    const int kc = (dslot ^ ((r >> 2) & 3)) * 8;
+    const int gr = m0 + r;
+    a_ok[j] = gr < p.M;
+    a_kc[j] = kc;
+    if (MODE == 0) {
+      a_base[j] = (long long)gr; a_oy[j] = a_ox[j] = 0;
+    } else {
+      const int hw = p.Hout * p.Wout;
+      const int b = gr / hw;
+      const int rem = gr - b * hw;
+      a_oy[j] = rem / p.Wout;
+      a_ox[j] = rem - a_oy[j] * p.Wout;
+      a_base[j] = (long long)b * p.Hin * p.Win;
+    }
+    const int gn = n0 + r;
+    b_ok[j] = gn < p.N;
+    b_kc[j] = kc;
+    b_row[j] = p.B + (size_t)(b_ok[j] ? gn : 0) * p.ldb;
+  }
+  const bf16_t* a_ptr[2];
+  const bf16_t* b_ptr[2];
+  auto place_a = [&](int k0) {
+    if (MODE == 0) {
+      const bf16_t* src = p.A;
+      int ld = p.lda, koff = k0;
+      if (k0 >= p.K1) { src = p.A2; ld = p.lda2; koff = k0 - p.K1; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) a_ptr[j] = a_ok[j] ? src + a_base[j] * ld + koff + a_kc[j] : zero;
+    } else {
+      const int tap = k0 / p.Cin;
+      const int ci0 = k0 - tap * p.Cin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int iy, ix;
+        bool ok = a_ok[j];
+        if (p.mode == E4T_CONV_S1) {
+          iy = a_oy[j] + ky - 1; ix = a_ox[j] + kx - 1;
+          ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        } else if (p.mode == E4T_CONV_S2) {
+          iy = 2 * a_oy[j] + ky - 1; ix = 2 * a_ox[j] + kx - 1;
+          ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        } else if (p.mode == E4T_CONV_UP2) {
+          iy = a_oy[j] + ky - 1; ix = a_ox[j] + kx - 1;
+          ok = ok && iy >= 0 && iy < 2 * p.Hin && ix >= 0 && ix < 2 * p.Win;
+          iy >>= 1; ix >>= 1;
+        } else if (p.mode == E4T_CONV_S2A) {
+          iy = 2 * a_oy[j] + ky; ix = 2 * a_ox[j] + kx;
+          ok = ok && iy < p.Hin && ix < p.Win;
+        } else {
+          const int sy = a_oy[j] + ky - 1, sx = a_ox[j] + kx - 1;
+          ok = ok && sy >= 0 && sx >= 0 && !(sy & 1) && !(sx & 1);
+          iy = sy >> 1; ix = sx >> 1;
+          ok = ok && iy < p.Hin && ix < p.Win;
+        }
+        a_ptr[j] = ok ? p.A + (a_base[j] + (long long)iy * p.Win + ix) * p.Cin + ci0 + a_kc[j] : zero;
+      }
+    }
+  };
+  // The A and B streams are each issued in increasing k (lo(t), hi(t), lo(t+1), ...): one pointer per row, +32 per quarter.
+  auto issue_a = [&](int kt, bool hi, bf16_t* dst) {
+    const int k0 = kt * BK;
+    const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
+    if (fresh) {
+      place_a(k0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) a_ptr[j] += (a_ptr[j] != zero) ? HK : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(a_ptr[j], dst + (wave * 32 + j * 16) * HK);
+  };
+  auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
+    if (!hi && kt == kt_begin) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b_ptr[j] = b_ok[j] ? b_row[j] + kt * BK + b_kc[j] : zero;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b_ptr[j] += (b_ptr[j] != zero) ? HK : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) dma16(b_ptr[j], dst + (wave * 32 + j * 16) * HK);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fhi = lane >> 5;
+  int a_off[4][2], b_off[2][2];     // fragment offsets inside a quarter (elements), [block][k-step of the half]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wr * 128 + i * 32 + frow;
+      a_off[i][ks] = r * HK + (((ks * 2 + fhi) ^ ((r >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = wc * 64 + j * 32 + frow;
+      b_off[j][ks] = r * HK + (((ks * 2 + fhi) ^ ((r >> 2) & 3)) * 8);
+    }
+  }
+  // quarter slots of buffer b: lo-A, lo-B, hi-A, hi-B at (4b + 0..3) * QUART
+  issue_b(kt_begin, false, smem + 1 * QUART);
+  issue_a(kt_begin, false, smem + 0 * QUART);
+  issue_b(kt_begin, true, smem + 3 * QUART);
+  issue_a(kt_begin, true, smem + 2 * QUART);
+  if (kt_begin + 1 < kt_end) {
+    issue_b(kt_begin + 1, false, smem + 5 * QUART);
+    issue_a(kt_begin + 1, false, smem + 4 * QUART);
+    wait_vmcnt<8>();               // 12 issued: the two lo quarters of the first K-tile have landed
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[2][2], bfr[2][2];
+  auto phase = [&](auto Bc, auto Pc, int kt) {
+    constexpr int b = decltype(Bc)::value, ph = decltype(Pc)::value;
+    constexpr int kh = ph >> 1, mh = ph & 1;
+    bf16_t* const buf = smem + b * 4 * QUART;
+    bf16_t* const other = smem + (b ^ 1) * 4 * QUART;
+    const bf16_t* const qa = buf + (kh * 2) * QUART;
+    const bf16_t* const qb = qa + QUART;
+    // ---- L segment ----
+    PP_STAMP(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(qa + a_off[mh * 2 + i][ks]);
+    if (mh == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = *(const bf16x8*)(qb + b_off[j][ks]);
+    }
+    bool staged;
+    if (ph == 0)      { staged = kt + 1 < kt_end; if (staged) issue_b(kt + 1, true, other + 3 * QUART); }
+    else if (ph == 1) { staged = kt + 1 < kt_end; if (staged) issue_a(kt + 1, true, other + 2 * QUART); }
+    else if (ph == 2) { staged = kt + 2 < kt_end; if (staged) issue_b(kt + 2, false, buf + 1 * QUART); }
+    else              { staged = kt + 2 < kt_end; if (staged) issue_a(kt + 2, false, buf + 0 * QUART); }
+    PP_STAMP(1);
+    if (staged) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    PP_STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP(3);
+    // ---- M segment ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[mh * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[mh * 2 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    PP_STAMP(4);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP(5);
+#ifdef PP_TRACE
+    if (tracing || tr_n < 0) ++tr_n;
+#endif
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+  if (wr == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier interval behind group 0
+  {
+    int kt = kt_begin;
+    for (; kt + 2 <= kt_end; kt += 2) {
+      phase(I0{}, I0{}, kt); phase(I0{}, I1{}, kt); phase(I0{}, I2{}, kt); phase(I0{}, I3{}, kt);
+      phase(I1{}, I0{}, kt + 1); phase(I1{}, I1{}, kt + 1); phase(I1{}, I2{}, kt + 1); phase(I1{}, I3{}, kt + 1);
+    }
+    if (kt < kt_end) { phase(I0{}, I0{}, kt); phase(I0{}, I1{}, kt); phase(I0{}, I2{}, kt); phase(I0{}, I3{}, kt); }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  __syncthreads();   // every fragment read and every DMA is done before the epilogue reuses the LDS
+#ifdef PP_TRACE
+  if (tracing) for (int i = 0; i < 6 * 64; ++i) g_pp_trace[wr * 6 * 64 + i] = tr[wr][i];
+#endif
+  // two 64-row halves: keeps the (fully unrolled) epilogue at the size of the 128-wide kernels'
+  write_tile<64, 64, 2, 2>(p, *(f32x16(*)[2][2])(acc + 0), smem, wave, lane, m0 + wr * 128, n0 + wc * 64);
+  __syncthreads();
+  write_tile<64, 64, 2, 2>(p, *(f32x16(*)[2][2])(acc + 2), smem, wave, lane, m0 + wr * 128 + 64, n0 + wc * 64);
+}
+
+#ifdef PP_TRACE
+}  // namespace
+extern "C" int e4t_debug_pp_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_trace), sizeof(g_pp_trace));
+}
+namespace {
+#endif
+
 // sums `nz` consecutive partial slabs starting at slab blockIdx.y*nz, then runs the epilogue for batch entry blockIdx.y
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p, int nz) {
   const size_t total = (size_t)p.M * p.N;
@@ -602,7 +882,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   int tile = tile_hint;
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
-  if (tile != 64 && tile != 128 && tile != 256 && tile != 160) {
+  if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512) {
     // measured on MI355X (tools/sweep_small.py): 128x128 wins from one full round of the 256 CUs, and already from
     // a quarter round when K is long (3x3 convs at the 16x16 / 8x8 levels) if split-K fills the chip
     const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch;
@@ -614,7 +894,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   }
   if (tile == 256 && !allow256) tile = 128;
   if (tile == 160 && !allow256) tile = 128;
-  const int tm = tile == 160 ? 128 : tile, tn = tile == 256 ? 128 : tile;   // 256 = 256x128, 160 = 128x160
+  if (tile == 512 && (!allow256 || p.K % BK != 0 || (p.A2 && p.K1 % BK != 0))) tile = 128;   // ping-pong kernel: whole K-tiles only
+  const int tm = tile == 160 ? 128 : (tile == 512 ? 256 : tile), tn = tile == 256 ? 128 : (tile == 512 ? 256 : tile);   // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong
   const int gx = cdiv(p.N, tn), gy = cdiv(p.M, tm);
   // --- split-K: only when the grid underfills the chip and K is long ---
   int splitk = splitk_req;
@@ -650,7 +931,11 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   dim3 grid(gx, gy, splitk * batch), block(256);
   static const bool use_dma = getenv("E4T_GEMM_REGSTAGE") == nullptr;   // A/B switch: register-staged reference kernel
   if (use_dma) {
-    if (tile == 256) {
+    if (tile == 512) {
+      block = dim3(512);
+      if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_pp_kernel<0>), grid, block, 0, st, p);
+    } else if (tile == 256) {
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 0, 3>), grid, block, 0, st, p);

@@ -103,21 +103,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNSrc s, int HW, int G, i
   gn_block_reduce(m, C, G, sm, sq, lds, nullptr, partial + ((size_t)b * gridDim.x + chunk) * G * 2, nullptr);
 }
 
-// mean_rstd[b][g] = (mean, rstd)
-__global__ void gn_finalize_kernel(const float* partial, int nchunk, int G, int BG, float inv_n, float eps, float* mean_rstd) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// mean_rstd[b][g] = (mean, rstd).  One wave per (b, g): lane c sums chunks c, c+64, ... in double, then a fixed-order
+// butterfly (a single thread walking the 64 chunk partials was a 13-us chain of dependent loads, 110 times per step).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, int nchunk, int G, int BG, float inv_n, float eps,
+                                                          float* mean_rstd) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= BG) return;
   const int b = i / G, g = i - b * G;
   double s = 0.0, q = 0.0;
-  for (int c = 0; c < nchunk; ++c) {
-    const float* pp = partial + (((size_t)b * nchunk + c) * G + g) * 2;
-    s += pp[0]; q += pp[1];
+  for (int c = lane; c < nchunk; c += 64) {
+    const float2 pp = *(const float2*)(partial + (((size_t)b * nchunk + c) * G + g) * 2);
+    s += pp.x; q += pp.y;
   }
-  const double mean = s * inv_n;
-  double var = q * inv_n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  mean_rstd[i * 2] = (float)mean;
-  mean_rstd[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  s = wave_sum_f64(s); q = wave_sum_f64(q);
+  if (lane == 0) {
+    const double mean = s * inv_n;
+    double var = q * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mean_rstd[i * 2] = (float)mean;
+    mean_rstd[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // y = act(gamma * (x - mean) * rstd + beta), written as one contiguous (B*HW, C) bf16 matrix
@@ -203,17 +213,18 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(GNSrc s, const bf16_t
                   chan_partial ? chan_partial + ((size_t)b * gridDim.x + chunk) * C * 2 : nullptr);
 }
 
-// gsum[b][g] = (S1, S2) summed over chunks
-__global__ void gn_bwd_finalize_kernel(const float* partial, int nchunk, int G, int BG, float* gsum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// gsum[b][g] = (S1, S2) summed over chunks (one wave per (b, g), as gn_finalize_kernel)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* partial, int nchunk, int G, int BG, float* gsum) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= BG) return;
   const int b = i / G, g = i - b * G;
   double s = 0.0, q = 0.0;
-  for (int c = 0; c < nchunk; ++c) {
-    const float* pp = partial + (((size_t)b * nchunk + c) * G + g) * 2;
-    s += pp[0]; q += pp[1];
+  for (int c = lane; c < nchunk; c += 64) {
+    const float2 pp = *(const float2*)(partial + (((size_t)b * nchunk + c) * G + g) * 2);
+    s += pp.x; q += pp.y;
   }
-  gsum[i * 2] = (float)s; gsum[i * 2 + 1] = (float)q;
+  s = wave_sum_f64(s); q = wave_sum_f64(q);
+  if (lane == 0) { gsum[i * 2] = (float)s; gsum[i * 2 + 1] = (float)q; }
 }
 
 // Backward pass 2: dx = rstd * (dz*gamma - (S1 + xhat*S2)/n) (+ add), split into dx1 | dx2 along C
@@ -406,7 +417,7 @@ extern "C" int e4t_groupnorm_stats(const void* x1, int C1, const void* x2, int C
   hipLaunchKernelGGL(gn_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
   E4T_CHECK_LAUNCH("gn_stats_kernel");
   const int BG = Bn * G;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(BG, 256)), dim3(256), 0, st, (const float*)workspace, ch, G, BG,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(BG, 4)), dim3(256), 0, st, (const float*)workspace, ch, G, BG,
                      1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
   E4T_CHECK_LAUNCH("gn_finalize_kernel");
   return 0;
@@ -439,7 +450,7 @@ extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2,
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, (const bf16_t*)dy, mean_rstd,
                      gamma, beta, HW, G, ppc, silu, partial, dgamma_dbeta_partial);
   E4T_CHECK_LAUNCH("gn_bwd_stats_kernel");
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(BG, 256)), dim3(256), 0, st, (const float*)partial, ch, G, BG, gsum);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(BG, 4)), dim3(256), 0, st, (const float*)partial, ch, G, BG, gsum);
   E4T_CHECK_LAUNCH("gn_bwd_finalize_kernel");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ch, Bn), dim3(256), 0, st, s, (const bf16_t*)dy, mean_rstd, (const float*)gsum, gamma, beta,
                      (const bf16_t*)add, (bf16_t*)dx1, (bf16_t*)dx2, HW, G, ppc, silu, 1.f / ((float)(C / G) * (float)HW));

@@ -55,12 +55,15 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch):
     """Mirror of launch_gemm()'s tile / split-K heuristic (csrc/gemm.hip) -> workspace bytes it will want."""
     cd = lambda a, b: (a + b - 1) // b
     nkt = cd(K, 64)
-    if tile not in (64, 128, 256, 160):
+    if tile not in (64, 128, 256, 160, 512):
         t128 = cd(M, 128) * cd(N, 128) * nb
         tile = 128 if (t128 >= 256 or (nkt >= 32 and t128 >= 64)) else 64
         if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
             tile = 160
-    tiles = cd(N, 128 if tile == 256 else tile) * cd(M, 128 if tile == 160 else tile) * nb
+    if tile == 512 and K % 64:
+        tile = 128
+    tn, tm = {256: 128, 512: 256}.get(tile, tile), {160: 128, 512: 256}.get(tile, tile)
+    tiles = cd(N, tn) * cd(M, tm) * nb
     if splitk <= 0:
         splitk = 1
         if tile >= 128 and tiles < 256 and nkt >= 32:
@@ -129,7 +132,7 @@ class HipBackend:
     @staticmethod
     def _tile(M, N, K, nb, tile):
         """Mirror of launch_gemm()'s tile choice (csrc/gemm.hip), used only to label bench.py's per-kernel timings."""
-        if tile in (64, 128, 256, 160):
+        if tile in (64, 128, 256, 160, 512):
             return tile
         cd = lambda a, b: (a + b - 1) // b
         t128 = cd(M, 128) * cd(N, 128) * nb

@@ -37,7 +37,7 @@ def bench_gemm():
                     (4096, 1280, 1280), (4096, 10240, 1280), (4096, 1280, 5120), (4112, 3840, 1280), (4112, 5120, 1280), (4112, 1280, 5120),
                     (1232, 640, 768), (8192, 8192, 8192)]:
         a, b = r(M, K), r(N, K)
-        for tile in (160, 128):
+        for tile in (160, 128, 512):
             t = timeit(lambda: hip.gemm(a, b, tile=tile, splitk=1))
             print(f"  {M:6d} {N:6d} {K:6d} tile{tile:3d}: {t*1e6:9.1f} us  {2.0*M*N*K/t/1e12:7.1f} TF")
 
@@ -47,7 +47,7 @@ def bench_conv():
     for B, H, Cin, Cout in [(16, 64, 320, 320), (16, 64, 960, 320), (16, 64, 640, 320), (16, 32, 640, 640), (16, 32, 1920, 640), (16, 16, 1280, 1280),
                             (16, 16, 2560, 1280), (16, 8, 1280, 1280), (16, 8, 2560, 1280), (16, 512, 128, 128), (16, 256, 256, 256), (16, 128, 512, 512)]:
         x, w = r(B * H * H, Cin), r(Cout, 9 * Cin)
-        for tile in (160, 128):
+        for tile in (160, 128, 512):
             t = timeit(lambda: hip.conv3x3(x, w, B, H, H, H, H, 1, tile=tile, splitk=1), iters=5)
             print(f"  B{B} {H:3d}x{H:<3d} {Cin:5d}->{Cout:5d} tile{tile:3d}: {t*1e6:9.1f} us  {2.0*B*H*H*Cout*9*Cin/t/1e12:7.1f} TF")
 

@@ -52,6 +52,8 @@ def check_gemm(hip, emu, dev):
         (256, 256, 128, 0, 0), (200, 72, 64, 0, 0), (1000, 320, 320, 128, 1), (130, 200, 1032, 64, 3),
         (16, 1280, 1280, 0, 0), (4096, 640, 2560, 0, 0), (64, 64, 4096, 0, 0), (1000, 200, 328, 256, 1), (2048, 256, 64, 256, 1),
         (700, 320, 1280, 256, 2), (900, 320, 384, 160, 1), (300, 480, 128, 160, 2), (513, 200, 72, 160, 1),
+        (512, 512, 512, 512, 1), (700, 520, 256, 512, 1), (300, 256, 64, 512, 1), (1000, 300, 128, 512, 1), (513, 1000, 1152, 512, 2),
+        (2048, 1280, 1920, 512, 0), (257, 64, 192, 512, 1),
     ]
     for i, (M, N, K, tile, sk) in enumerate(cases):
         g = gen(10 + i, dev)
@@ -66,6 +68,9 @@ def check_gemm(hip, emu, dev):
     M, N, K1, K2 = 384, 192, 128, 64
     a1, a2, b = rnd(g, M, K1, dev=dev), rnd(g, M, K2, dev=dev), rnd(g, N, K1 + K2, scale=0.07, dev=dev)
     out.append(("gemm two-source A", rel(hip.gemm(a1, b, a2=a2), emu.gemm(a1, b, a2=a2)), TOL1))
+    out.append(("gemm two-source A t512", rel(hip.gemm(a1, b, a2=a2, tile=512), emu.gemm(a1, b, a2=a2)), TOL1))
+    out.append(("gemm gelu fp32-out t512", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32, tile=512),
+                                                emu.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32)), TOLF * 50))
     out.append(("gemm gelu", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
     c0 = rnd(g, M, N, dtype=f32, dev=dev)
     c1, c2 = c0.clone(), c0.clone()
@@ -98,6 +103,9 @@ def check_conv(hip, emu, dev):
         (2, 8, 8, 64, 64, CONV_UP2, 16, 16, 0, 0), (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 0, 0),
         (2, 5, 5, 64, 64, CONV_S2T, 9, 9, 0, 0), (4, 32, 32, 320, 320, CONV_S1, 32, 32, 128, 1),
         (2, 16, 16, 64, 4, CONV_S1, 16, 16, 0, 0), (3, 24, 24, 64, 192, CONV_S1, 24, 24, 256, 1), (3, 24, 24, 64, 320, CONV_S1, 24, 24, 160, 1), (2, 16, 16, 128, 128, 5, 8, 8, 0, 0), (1, 64, 64, 128, 128, 5, 32, 32, 0, 0),
+        (3, 24, 24, 64, 320, CONV_S1, 24, 24, 512, 1), (2, 32, 32, 128, 256, CONV_S1, 32, 32, 512, 1), (2, 16, 16, 256, 512, CONV_S1, 16, 16, 512, 2),
+        (3, 16, 16, 64, 128, CONV_S2, 8, 8, 512, 1), (2, 8, 8, 64, 64, CONV_UP2, 16, 16, 512, 1), (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 512, 1),
+        (1, 64, 64, 128, 128, 5, 32, 32, 512, 1),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
         g = gen(50 + i, dev)
