@@ -166,7 +166,8 @@ def main():
                  "conv160": "gemm_dma_kernel<128,160,4,1,conv,2> (implicit-GEMM 3x3 conv)",
                  "conv64": "gemm_dma_kernel<64,64,2,2,conv,2> (implicit-GEMM 3x3 conv)",
                  "gemm128": "gemm_dma_kernel<128,128,4,2,dense,2>", "gemm160": "gemm_dma_kernel<128,160,4,1,dense,2>",
-                 "gemm64": "gemm_dma_kernel<64,64,2,2,dense,2>"}
+                 "gemm64": "gemm_dma_kernel<64,64,2,2,dense,2>",
+                 "conv512": "gemm_pp_kernel<conv> (256x256 ping-pong implicit-GEMM 3x3 conv)", "gemm512": "gemm_pp_kernel<dense> (256x256 ping-pong)"}
         roof = dict(bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / sec / MFMA_PEAK, traffic=None,
                     kernel=names.get(dom, dom), launches_per_step=n, avg_launch_ms=sec / n * 1e3,
                     per_kernel={k: dict(tflops=v[0] / v[1] / 1e12, ms_per_step=v[1] * 1e3, launches=v[2]) for k, v in sorted(agg.items())},

@@ -609,6 +609,21 @@ __device__ unsigned long long g_pp_trace[2 * 6 * 64];
 #else
 #define PP_STAMP(slot) do { } while (0)
 #endif
+#ifdef PP_NOREAD
+#define PP_LDSREAD(ptr) bf16x8{}
+#else
+#define PP_LDSREAD(ptr) (*(const bf16x8*)(ptr))
+#endif
+#ifdef PP_NODMA      // timing ablations of the debug build (results are garbage)
+#define PP_DMA(src, dst) asm volatile("" ::"v"(src))
+#else
+#define PP_DMA(src, dst) dma16(src, dst)
+#endif
+#ifdef PP_DMA1
+#define PP_NJ 1
+#else
+#define PP_NJ 2
+#endif
 template <int MODE>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, HK = 32;
@@ -725,7 +740,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j) a_ptr[j] += (a_ptr[j] != zero) ? HK : 0;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma16(a_ptr[j], dst + (wave * 32 + j * 16) * HK);
+    for (int j = 0; j < PP_NJ; ++j) PP_DMA(a_ptr[j], dst + (wave * 32 + j * 16) * HK);
   };
   auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
     if (!hi && kt == kt_begin) {
@@ -736,7 +751,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
       for (int j = 0; j < 2; ++j) b_ptr[j] += (b_ptr[j] != zero) ? HK : 0;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma16(b_ptr[j], dst + (wave * 32 + j * 16) * HK);
+    for (int j = 0; j < PP_NJ; ++j) PP_DMA(b_ptr[j], dst + (wave * 32 + j * 16) * HK);
   };
 
   f32x16 acc[4][2];
@@ -789,12 +804,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(qa + a_off[mh * 2 + i][ks]);
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = PP_LDSREAD(qa + a_off[mh * 2 + i][ks]);
     if (mh == 0) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = *(const bf16x8*)(qb + b_off[j][ks]);
+        for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = PP_LDSREAD(qb + b_off[j][ks]);
     }
     bool staged;
     if (ph == 0)      { staged = kt + 1 < kt_end; if (staged) issue_b(kt + 1, true, other + 3 * QUART); }
@@ -802,7 +817,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     else if (ph == 2) { staged = kt + 2 < kt_end; if (staged) issue_b(kt + 2, false, buf + 1 * QUART); }
     else              { staged = kt + 2 < kt_end; if (staged) issue_a(kt + 2, false, buf + 0 * QUART); }
     PP_STAMP(1);
+#ifndef PP_NOWAIT
     if (staged) wait_vmcnt<8>(); else wait_vmcnt<0>();
+#endif
     PP_STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -891,6 +908,11 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     // every channel count of the SD UNets is a multiple of 160 but 320 / 640 / 960 are not multiples of 128: a 128x160
     // tile has no N padding there (conv 640->640 @32x32: 863 vs 589 TF)
     if (allow256 && tile == 128 && p.N % 160 == 0 && p.N <= 960 && (long long)cdiv(p.M, 128) * (p.N / 160) * batch >= 128) tile = 160;
+    // K-deep shapes whose N is a multiple of 256 and that fill the chip at least twice with 256x256 tiles (the VAE's 256-
+    // and 512-channel convs): the ping-pong kernel (conv 512->512 @128^2: 1075 vs 928 TF, 8192^3: 1173 vs 971 TF)
+    static const bool no_pp = getenv("E4T_GEMM_NOPP") != nullptr;     // A/B switch
+    if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && p.K % BK == 0 && nkt >= 32 && (!p.A2 || p.K1 % BK == 0) &&
+        (long long)cdiv(p.M, 256) * (p.N / 256) * batch >= 512) tile = 512;
   }
   if (tile == 256 && !allow256) tile = 128;
   if (tile == 160 && !allow256) tile = 128;

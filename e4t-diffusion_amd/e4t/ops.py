@@ -60,6 +60,8 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch):
         tile = 128 if (t128 >= 256 or (nkt >= 32 and t128 >= 64)) else 64
         if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
             tile = 160
+        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= 32 and cd(M, 256) * (N // 256) * nb >= 512:
+            tile = 512
     if tile == 512 and K % 64:
         tile = 128
     tn, tm = {256: 128, 512: 256}.get(tile, tile), {160: 128, 512: 256}.get(tile, tile)
@@ -139,6 +141,8 @@ class HipBackend:
         tile = 128 if (t128 >= 256 or (cd(K, 64) >= 32 and t128 >= 64)) else 64
         if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
             tile = 160
+        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= 32 and cd(M, 256) * (N // 256) * nb >= 512:
+            tile = 512
         return tile
 
     # ------------------------------------------------------------------ workspaces
