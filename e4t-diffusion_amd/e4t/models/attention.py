@@ -49,12 +49,18 @@ class BasicTransformerBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.norm3 = nn.LayerNorm(dim)
 
-    def forward(self, hidden_states, encoder_hidden_states=None, **unused):
-        """hidden_states: (B, T, dim) view of the token matrix; encoder_hidden_states: (B, S, ctx_dim) in ACT dtype."""
+    def forward(self, hidden_states, encoder_hidden_states=None, prefix=None, **unused):
+        """hidden_states: (B, T, dim) view of the token matrix; encoder_hidden_states: (B, S, ctx_dim) in ACT dtype.
+        ``prefix``: the UNet's shared-prefix cache (unet_2d_condition.py) — the self-attention half of the very first
+        block does not see the text context and is computed once for the two UNet passes of a step."""
         B, T, d = hidden_states.shape
-        h = hidden_states.reshape(B * T, d)
-        n = Fn.layer_norm(h, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        h = self.attn1(n.view(B, T, d), residual=h).reshape(B * T, d)
+
+        def self_attn_half():
+            h = hidden_states.reshape(B * T, d)
+            n = Fn.layer_norm(h, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            return self.attn1(n.view(B, T, d), residual=h).reshape(B * T, d)
+        shareable = prefix is not None and not getattr(self, "only_cross_attention", False)
+        h = prefix.reuse("block0.attn1", self_attn_half) if shareable else self_attn_half()
         n = Fn.layer_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         h = self.attn2(n.view(B, T, d), encoder_hidden_states=encoder_hidden_states, residual=h).reshape(B * T, d)
         n = Fn.layer_norm(h, self.norm3.weight, self.norm3.bias, self.norm3.eps)

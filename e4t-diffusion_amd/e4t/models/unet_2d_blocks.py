@@ -32,10 +32,14 @@ class CrossAttnDownBlock2D(nn.Module):
                                                use_linear_projection, only_cross_attention, upcast_attention) for _ in range(num_layers)])
         self.downsamplers = nn.ModuleList([Downsample2D(out_channels, name="op")]) if add_downsample else None
 
-    def forward_nhwc(self, m, temb_act, ctx):
+    def forward_nhwc(self, m, temb_act, ctx, prefix=None):
         outs = ()
-        for r, a in zip(self.resnets, self.attentions):
-            m = a.forward_nhwc(r.forward_nhwc(m, None, temb_act), ctx)
+        for i, (r, a) in enumerate(zip(self.resnets, self.attentions)):
+            if i == 0 and prefix is not None:      # shared prefix of the step's two UNet passes (unet_2d_condition.py)
+                m_in = m
+                m = a.forward_nhwc(prefix.reuse("res0", lambda: r.forward_nhwc(m_in, None, temb_act)), ctx, prefix)
+            else:
+                m = a.forward_nhwc(r.forward_nhwc(m, None, temb_act), ctx)
             outs += (m,)
         if self.downsamplers is not None:
             m = self.downsamplers[0].forward_nhwc(m)

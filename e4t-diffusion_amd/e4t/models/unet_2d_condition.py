@@ -42,6 +42,34 @@ class TimestepEmbedding(nn.Module):
         return Fn.linear(h, self.linear_2.weight, self.linear_2.bias, self._p2)
 
 
+class _SharedPrefix:
+    """Single-use record/replay store for the context-independent prefix of the UNet (see forward()).  A forward whose
+    key differs from the recorded one starts a new recording; a forward that replays a recording consumes it."""
+
+    def __init__(self):
+        self.key, self.store, self.active, self._replay = None, {}, False, False
+
+    def begin(self, key, enabled):
+        self.active = enabled
+        if not enabled:
+            self.key, self.store = None, {}
+            return
+        self._replay = key == self.key and len(self.store) > 0
+        if not self._replay:
+            self.key, self.store = key, {}
+
+    def reuse(self, name, fn):
+        if not self.active:
+            return fn()
+        if name not in self.store:
+            self.store[name] = fn()
+        return self.store[name]
+
+    def end(self):
+        if self._replay:                       # consumed: drop the references (and with them the graph, after backward)
+            self.key, self.store, self._replay = None, {}, False
+
+
 class UNet2DConditionModel(nn.Module):
     def __init__(self, sample_size: Optional[int] = None, in_channels: int = 4, out_channels: int = 4,
                  center_input_sample: bool = False, flip_sin_to_cos: bool = True, freq_shift: int = 0,
@@ -105,6 +133,8 @@ class UNet2DConditionModel(nn.Module):
         self._groups, self._eps, self._temb_in = norm_num_groups, norm_eps, boc[0]
         # Weight-offset banks in gradient-finalisation order: the up-block heads are final
         # first in the backward, the mid/down heads (shared by both UNet passes) last.
+        self._prefix = _SharedPrefix()
+        self.share_prefix = False          # enabled by `with unet.shared_prefix():` around the two passes of one step
         self.wo_banks = [WOBank("up"), WOBank("mid_down")]
         for mod in self.up_blocks.modules():
             if isinstance(mod, CrossAttention):
@@ -138,6 +168,23 @@ class UNet2DConditionModel(nn.Module):
     def set_use_memory_efficient_attention_xformers(self, valid: bool, attention_op=None):
         self.set_attn_processor(HipAttnProcessor())
 
+    def shared_prefix(self):
+        """Context manager: forwards issued inside it on the SAME (sample, timestep) tensors share the context-independent
+        prefix (see forward()).  Use it around the encoder pass + full pass of one training step, before the backward."""
+        unet = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                unet.share_prefix = True
+                unet._prefix.begin(None, False)
+                return unet
+
+            def __exit__(self_inner, *exc):
+                unet.share_prefix = False
+                unet._prefix.begin(None, False)      # drops every recorded tensor
+                return False
+        return _Ctx()
+
     # ---------------------------------------------------------------------- forward
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None, attention_mask=None,
                 cross_attention_kwargs=None, down_block_additional_residuals=None, mid_block_additional_residual=None,
@@ -158,18 +205,36 @@ class UNet2DConditionModel(nn.Module):
         elif t.dim() == 0:
             t = t[None].to(dev)
         t = t.expand(B)
-        emb = self.time_embedding(be.timestep_embedding(t, self._temb_in))
-        temb_act = Fn.silu(emb)      # every ResBlock consumes silu(emb): evaluate it once
-        # 2. conv_in: 4 latent channels zero-padded to one 64-wide K tile
-        x = torch.zeros((B * H * W, 64), dtype=act, device=dev)
-        x[:, :Cin] = sample.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
+        # Shared prefix (restructuring 3): the encoder pass and the full pass of one training step get the
+        # same noisy latents and timesteps (pretrain_e4t.py:624,636), so everything that does not see the text context —
+        # time embedding, conv_in, down_blocks.0.resnets.0, and attentions.0 up to and including its self-attention — is
+        # bit-identical in both.  The first pass records those tensors (with their autograd graph), the second one reuses
+        # them: gradients of both passes add at the shared nodes exactly as they add at the shared parameters.
+        prefix = self._prefix
+        key = (sample.data_ptr(), sample._version, tuple(sample.shape), timestep.data_ptr() if torch.is_tensor(timestep) else timestep,
+               timestep._version if torch.is_tensor(timestep) else 0, torch.is_grad_enabled(), ops.weights_epoch(), self.training)
+        prefix.begin(key, self.share_prefix and torch.is_tensor(timestep))
+        prefix.reuse("inputs", lambda: (sample, timestep))     # keeps them alive: the key's addresses cannot be recycled
+
+        def stem():
+            emb = self.time_embedding(be.timestep_embedding(t, self._temb_in))
+            temb_act = Fn.silu(emb)      # every ResBlock consumes silu(emb): evaluate it once
+            # 2. conv_in: 4 latent channels zero-padded to one 64-wide K tile
+            x = torch.zeros((B * H * W, 64), dtype=act, device=dev)
+            x[:, :Cin] = sample.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
+            return temb_act, Fn.conv3x3(x, self.conv_in.weight, self.conv_in.bias, self._pin, (B, H, W, H, W))
+        temb_act, x0 = prefix.reuse("stem", stem)
         ctx = encoder_hidden_states.to(act).contiguous()
-        m = FMap(Fn.conv3x3(x, self.conv_in.weight, self.conv_in.bias, self._pin, (B, H, W, H, W)), B, H, W)
+        m = FMap(x0, B, H, W)
         # 3. down
         skips = (m,)
-        for blk in self.down_blocks:
-            m, outs = blk.forward_nhwc(m, temb_act, ctx)
+        for i, blk in enumerate(self.down_blocks):
+            if i == 0 and prefix.active and blk.has_cross_attention:
+                m, outs = blk.forward_nhwc(m, temb_act, ctx, prefix)
+            else:
+                m, outs = blk.forward_nhwc(m, temb_act, ctx)
             skips += outs
+        prefix.end()
         # 4. mid
         m = self.mid_block.forward_nhwc(m, temb_act, ctx)
         if return_encoder_outputs:

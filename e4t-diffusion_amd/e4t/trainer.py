@@ -16,6 +16,8 @@ from __future__ import annotations
 import math
 from typing import List, Optional, Sequence
 
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -73,6 +75,7 @@ class E4TTrainer:
         self.device = device or next(unet.parameters()).device
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.scale, self.reg_lambda, self.pred_type = domain_embed_scale, reg_lambda, prediction_type
+        self.share_prefix = True     # compute the context-independent UNet prefix once for the step's two passes
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         self.step_count = 0
@@ -120,13 +123,16 @@ class E4TTrainer:
         with torch.no_grad():
             inputs_embeds = te.get_input_embeddings()(input_ids)
         noisy = self.add_noise(latents, noise, timesteps)
-        enc = self.unet(noisy, timesteps, self.ctx_for_e4t.expand(B, -1, -1), return_encoder_outputs=True)
-        domain = self.encoder(x=pixel_values, unet_down_block_samples=enc["down_block_samples"])
-        domain = self.class_embed[None, :].expand(B, -1) + self.scale * domain
-        emb = inputs_embeds.clone()
-        emb[torch.arange(B, device=emb.device), placeholder_idx] = domain.to(emb.dtype)
-        ctx = te(inputs_embeds=emb)[0]
-        pred = self.unet(noisy, timesteps, ctx).sample
+        # both UNet passes see the same (noisy, timesteps): the context-independent prefix is computed once
+        share = self.unet.shared_prefix() if (self.share_prefix and hasattr(self.unet, "shared_prefix")) else contextlib.nullcontext()
+        with share:
+            enc = self.unet(noisy, timesteps, self.ctx_for_e4t.expand(B, -1, -1), return_encoder_outputs=True)
+            domain = self.encoder(x=pixel_values, unet_down_block_samples=enc["down_block_samples"])
+            domain = self.class_embed[None, :].expand(B, -1) + self.scale * domain
+            emb = inputs_embeds.clone()
+            emb[torch.arange(B, device=emb.device), placeholder_idx] = domain.to(emb.dtype)
+            ctx = te(inputs_embeds=emb)[0]
+            pred = self.unet(noisy, timesteps, ctx).sample
         if self.pred_type == "epsilon":
             target = noise
         else:

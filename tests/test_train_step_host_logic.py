@@ -76,7 +76,6 @@ def test_one_step_matches_oracle(emu_fp32):
     for n, p in r_enc.named_parameters():
         if p.requires_grad:
             big = p.grad.abs() > 1e-6
-            d_r = (p.data - (p.data if False else p.data)).abs()  # placeholder to keep shapes
             torch.testing.assert_close(ne[n].data[big], p.data[big], rtol=0, atol=1e-4, msg=lambda m, n=n: f"{n}: {m}")
     # gradients were cleared in place and storage is still the flat buffer
     assert float(tr.flat.grad.abs().max()) == 0.0
@@ -84,3 +83,35 @@ def test_one_step_matches_oracle(emu_fp32):
     # a second step runs (weight-offset caches refresh through the weights epoch)
     loss2, _, _ = tr.train_step(pixels, ids, pidx, noise=noise, timesteps=t, latents=latents)
     assert torch.isfinite(loss2)
+
+
+def test_shared_prefix_is_result_preserving(emu_fp32):
+    """SURVEY §8a restructuring (3): computing the context-independent UNet prefix once for the two passes of a step
+    must leave the losses and every trainable gradient unchanged."""
+    from e4t.trainer import E4TTrainer
+    B = 2
+    g = torch.Generator().manual_seed(3)
+    pixels = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
+    latents = torch.randn(B, 4, 16, 16, generator=g) * 0.18215
+    noise = torch.randn(B, 4, 16, 16, generator=g)
+    t = torch.tensor([17, 912])
+    ids = torch.randint(1, 99, (B, 9), generator=g)
+    pidx = torch.tensor([1, 5])
+    res = []
+    for share in (False, True):
+        _, _, n_unet, n_enc, text = build()
+        tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long),
+                        device=torch.device("cpu"))
+        tr.share_prefix = share
+        calls = []
+        blk = n_unet.down_blocks[0].attentions[0].transformer_blocks[0]
+        orig = blk.attn1.forward
+        blk.attn1.forward = lambda *a, _o=orig, **k: (calls.append(1), _o(*a, **k))[1]
+        loss, ld, lr_ = tr.losses(pixels, latents, noise, t, ids, pidx)
+        loss.backward()
+        assert len(calls) == (1 if share else 2)          # the first self-attention really ran once / twice
+        assert n_unet._prefix.store == {} and not n_unet.share_prefix
+        res.append((ld.detach().clone(), lr_.detach().clone(), tr.flat.grad.detach().clone()))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-4, atol=1e-7)
