@@ -924,9 +924,13 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   if (splitk <= 0) {
     splitk = 1;
     const long long tiles = (long long)gx * gy * batch;
-    if (tile >= 128 && tiles < 256 && nkt >= 32) {
-      splitk = (int)((320 + tiles - 1) / tiles);
-      if (splitk > nkt / 8) splitk = nkt / 8;
+    if (tile >= 128 && tiles < 512 && nkt >= 32) {
+      // 2 workgroups/CU = 512 slots: aim at one full round (<= 256 tiles) or two (measured, tools/sweep_sk.py: 8x8 convs
+      // 80 tiles -> 6 splits -16..19 %, 16x16 convs 320 tiles -> 3 splits -10..17 %), keeping >= 16 K-tiles per split
+      splitk = (int)((tiles <= 256 ? 512 : 1024) / tiles);
+      if (splitk > 8) splitk = 8;
+      if (splitk > nkt / 16) splitk = nkt / 16;
+      if (tiles > 256 && nkt < 128) splitk = 1;      // the second round only pays on long K (4096x1280x5120: 3 splits +4 %)
     } else if (tile == 64 && tiles < 256 && nkt >= 64) {
       splitk = (int)((512 + tiles - 1) / tiles);
       if (splitk > nkt / 16) splitk = nkt / 16;

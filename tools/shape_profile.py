@@ -36,5 +36,5 @@ for k, fl, e0, e1 in rec:
     a = agg[k]; a[0] += fl; a[1] += e0.elapsed_time(e1); a[2] += 1
 tot = sum(v[1] for v in agg.values())
 print(f"total gemm+conv ms {tot:.1f}")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:110]:
     print(f"{v[1]:7.2f} ms {v[2]:4d}x  {v[0]/v[1]/1e9:7.1f} TF  {k}")
