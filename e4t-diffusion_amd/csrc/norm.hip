@@ -229,9 +229,9 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* parti
 
 // Backward pass 2: dx = rstd * (dz*gamma - (S1 + xhat*S2)/n) (+ add), split into dx1 | dx2 along C
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t* dy, const float* mean_rstd, const float* gsum,
-                                                           const float* gamma, const float* beta, const bf16_t* add,
-                                                           bf16_t* dx1, bf16_t* dx2, int HW, int G, int pix_per_chunk, int silu,
-                                                           float inv_n) {
+                                                           const float* gamma, const float* beta, const bf16_t* add1,
+                                                           const bf16_t* add2, bf16_t* dx1, bf16_t* dx2, int HW, int G,
+                                                           int pix_per_chunk, int silu, float inv_n) {
   const int C = s.C1 + s.C2, cpg = C / G;
   const GNMap m(C);
   const int b = blockIdx.y;
@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t
         float f[8], d[8], a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         unpack8(gn_load8(s, pix, c), f);
         unpack8(*(const uint4*)(dy + pix * C + c), d);
-        if (add) unpack8(*(const uint4*)(add + pix * C + c), a);
+        if (c < s.C1) { if (add1) unpack8(*(const uint4*)(add1 + pix * s.C1 + c), a); }
+        else if (add2) unpack8(*(const uint4*)(add2 + pix * s.C2 + (c - s.C1)), a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = (f[j] - mu[i][j]) * rs[i][j];
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const floa
 
 // dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* mean_rstd,
-                                                     bf16_t* dx, int M, int D) {
+                                                     const bf16_t* add, bf16_t* dx, int M, int D) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const int nc = D >> 3;
@@ -352,9 +353,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, const bf16
   for (int i = 0; i < LN_MAXC; ++i) {
     const int c = lane + i * 64;
     if (c < nc) {
-      float o[8];
+      float o[8], a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (add) unpack8(*(const uint4*)(add + (size_t)row * D + c * 8), a);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = rstd * (dg[i][j] - s1 - xh[i][j] * s2);
+      for (int j = 0; j < 8; ++j) o[j] = rstd * (dg[i][j] - s1 - xh[i][j] * s2) + a[j];
       *(uint4*)(dx + (size_t)row * D + c * 8) = pack8(o);
     }
   }
@@ -435,11 +437,11 @@ extern "C" int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C
 }
 
 extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, const float* mean_rstd,
-                                 const float* gamma, const float* beta, const void* add, void* dx1, void* dx2,
+                                 const float* gamma, const float* beta, const void* add1, const void* add2, void* dx1, void* dx2,
                                  float* dgamma_dbeta_partial, int Bn, int HW, int G, int silu, void* workspace,
                                  size_t ws_bytes, e4t_stream stream) {
   if (int e = gn_check(x1, C1, x2, C2, Bn, HW, G)) return e;
-  E4T_REQUIRE(dy && mean_rstd && gamma && beta && dx1 && ((dx2 != nullptr) == (C2 > 0)), "groupnorm_bwd: null argument");
+  E4T_REQUIRE(dy && mean_rstd && gamma && beta && dx1 && ((dx2 != nullptr) == (C2 > 0)) && (!add2 || C2 > 0), "groupnorm_bwd: null argument");
   const int C = C1 + C2, ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch), BG = Bn * G;
   const size_t need = ((size_t)Bn * ch * G * 2 + (size_t)BG * 2) * sizeof(float);
   E4T_REQUIRE(workspace && ws_bytes >= need, "groupnorm_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -453,7 +455,7 @@ extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2,
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(BG, 4)), dim3(256), 0, st, (const float*)partial, ch, G, BG, gsum);
   E4T_CHECK_LAUNCH("gn_bwd_finalize_kernel");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ch, Bn), dim3(256), 0, st, s, (const bf16_t*)dy, mean_rstd, (const float*)gsum, gamma, beta,
-                     (const bf16_t*)add, (bf16_t*)dx1, (bf16_t*)dx2, HW, G, ppc, silu, 1.f / ((float)(C / G) * (float)HW));
+                     (const bf16_t*)add1, (const bf16_t*)add2, (bf16_t*)dx1, (bf16_t*)dx2, HW, G, ppc, silu, 1.f / ((float)(C / G) * (float)HW));
   E4T_CHECK_LAUNCH("gn_bwd_apply_kernel");
   return 0;
 }
@@ -467,11 +469,11 @@ extern "C" int e4t_layernorm_fwd(const void* x, const float* gamma, const float*
   return 0;
 }
 
-extern "C" int e4t_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, void* dx, int M, int D,
-                                 e4t_stream stream) {
+extern "C" int e4t_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* add, void* dx,
+                                 int M, int D, e4t_stream stream) {
   E4T_REQUIRE(x && dy && gamma && mean_rstd && dx && M > 0, "layernorm_bwd: null argument");
   E4T_REQUIRE(D % 8 == 0 && D <= LN_MAXC * 64 * 8, "layernorm: D=%d must be a multiple of 8 and <= 1536", D);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (bf16_t*)dx, M, D);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (const bf16_t*)add, (bf16_t*)dx, M, D);
   E4T_CHECK_LAUNCH("ln_bwd_kernel");
   return 0;
 }

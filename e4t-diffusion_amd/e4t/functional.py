@@ -299,6 +299,42 @@ def group_norm(x1, x2, gamma, beta, B, HW, G, eps, silu):
     return GroupNormFn.apply(x1, x2, gamma, beta, B, HW, G, eps, silu)
 
 
+class GroupNormSkipFn(torch.autograd.Function):
+    """GroupNorm at the entry of a residual block: returns (act(GN(x1|x2)), x1, x2) where the last two are the inputs
+    themselves, to be handed to the block's shortcut / residual.  In the backward the gradient that comes back through them
+    is added inside the GroupNorm backward kernel instead of by separate elementwise adds (cf. LayerNormSkipFn)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, gamma, beta, B, HW, G, eps, silu):
+        y, stats = ops.backend().groupnorm_fwd(x1, x2, gamma, beta, B, HW, G, eps, silu)
+        ctx.save_for_backward(x1, x2, stats, gamma, beta)
+        ctx.cfg = (B, HW, G, silu)
+        if x2 is None:
+            return y, x1.view_as(x1)
+        return y, x1.view_as(x1), x2.view_as(x2)
+
+    @staticmethod
+    def backward(ctx, dy, d1, d2=None):
+        x1, x2, stats, gamma, beta = ctx.saved_tensors
+        B, HW, G, silu = ctx.cfg
+        wp = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        if dy is None:
+            return d1, d2, None, None, None, None, None, None, None
+        a1 = None if d1 is None else d1.to(x1.dtype).contiguous()
+        a2 = None if d2 is None else d2.to(x2.dtype).contiguous()
+        dx1, dx2, dg, db = ops.backend().groupnorm_bwd(x1, x2, dy.contiguous(), stats, gamma, beta, a1, B, HW, G, silu,
+                                                       want_param_grads=wp, add2=a2)
+        return dx1, dx2, dg, db, None, None, None, None, None
+
+
+def group_norm_skip(x1, x2, gamma, beta, B, HW, G, eps, silu):
+    """-> (act(GN(x1|x2)), x1, x2): use the returned x1 / x2 as the operands of the block's shortcut (see GroupNormSkipFn)."""
+    if not (torch.is_grad_enabled() and (x1.requires_grad or (x2 is not None and x2.requires_grad))):
+        return GroupNormFn.apply(x1, x2, gamma, beta, B, HW, G, eps, silu), x1, x2
+    out = GroupNormSkipFn.apply(x1, x2, gamma, beta, B, HW, G, eps, silu)
+    return (out[0], out[1], None) if x2 is None else out
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -316,6 +352,35 @@ class LayerNormFn(torch.autograd.Function):
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class LayerNormSkipFn(torch.autograd.Function):
+    """Pre-LN residual block entry: returns (LN(x), x).  The second output is x itself, to be used as the block's residual
+    operand; in the backward the gradient arriving through that residual is added inside the LayerNorm backward kernel
+    instead of by a separate elementwise add of two (tokens x dim) tensors (attention.py:275-332 has 3 such per block)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, stats = ops.backend().layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, stats, gamma)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, stats, gamma = ctx.saved_tensors
+        wp = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if dy is None:
+            return dskip, None, None, None
+        add = None if dskip is None else dskip.to(x.dtype).contiguous()
+        dx, dg, db = ops.backend().layernorm_bwd(x, dy.contiguous(), gamma, stats, want_param_grads=wp, add=add)
+        return dx, dg, db, None
+
+
+def layer_norm_skip(x, gamma, beta, eps=1e-5):
+    """-> (LN(x), x): use the second value as the residual operand of the block (see LayerNormSkipFn)."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return LayerNormFn.apply(x, gamma, beta, eps), x
+    return LayerNormSkipFn.apply(x, gamma, beta, eps)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -57,12 +57,12 @@ class BasicTransformerBlock(nn.Module):
 
         def self_attn_half():
             h = hidden_states.reshape(B * T, d)
-            n = Fn.layer_norm(h, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            n, h = Fn.layer_norm_skip(h, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             return self.attn1(n.view(B, T, d), residual=h).reshape(B * T, d)
         shareable = prefix is not None and not getattr(self, "only_cross_attention", False)
         h = prefix.reuse("block0.attn1", self_attn_half) if shareable else self_attn_half()
-        n = Fn.layer_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        n, h = Fn.layer_norm_skip(h, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         h = self.attn2(n.view(B, T, d), encoder_hidden_states=encoder_hidden_states, residual=h).reshape(B * T, d)
-        n = Fn.layer_norm(h, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        n, h = Fn.layer_norm_skip(h, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         h = self.ff(n, residual=h)
         return h.view(B, T, d)

@@ -61,17 +61,18 @@ class ResnetBlock2D(nn.Module):
         B, H, W = m.B, m.H, m.W
         geom = (B, H, W, H, W)
         x2 = skip.x if skip is not None else None
-        h = Fn.group_norm(m.x, x2, self.norm1.weight, self.norm1.bias, B, H * W, self.groups, self.eps, True)
+        # x1 / x2 come back as the operands for the shortcut: their gradient is folded into the GroupNorm backward
+        h, x1, x2 = Fn.group_norm_skip(m.x, x2, self.norm1.weight, self.norm1.bias, B, H * W, self.groups, self.eps, True)
         rb = None
         if temb_act is not None and self.time_emb_proj is not None:
             rb = Fn.linear(temb_act, self.time_emb_proj.weight, self.time_emb_proj.bias, self._pt, out_f32=True)
         h = Fn.conv3x3(h, self.conv1.weight, self.conv1.bias, self._p1, geom, rowbias=rb)
         h = Fn.group_norm(h, None, self.norm2.weight, self.norm2.bias, B, H * W, self.groups, self.eps, True)
         if self.conv_shortcut is not None:
-            s = Fn.linear(m.x, self.conv_shortcut.weight, self.conv_shortcut.bias, self._ps, x2=x2)
+            s = Fn.linear(x1, self.conv_shortcut.weight, self.conv_shortcut.bias, self._ps, x2=x2)
         else:
             assert skip is None
-            s = m.x
+            s = x1
         y = Fn.conv3x3(h, self.conv2.weight, self.conv2.bias, self._p2, geom, residual=s)
         return FMap(y, B, H, W)
 

@@ -36,13 +36,13 @@ class Transformer2DModel(nn.Module):
     def forward_nhwc(self, m: FMap, ctx, prefix=None) -> FMap:
         B, HW = m.B, m.H * m.W
 
-        def project_in():
-            g = Fn.group_norm(m.x, None, self.norm.weight, self.norm.bias, B, HW, self.groups, 1e-6, False)
-            return Fn.linear(g, self.proj_in.weight, self.proj_in.bias, self._pin)     # 1x1 conv == per-pixel GEMM
-        h = prefix.reuse("attn0.proj_in", project_in) if prefix is not None else project_in()
+        def project_in():      # -> (proj_in(GN(x)), x as the residual operand of proj_out)
+            g, res, _ = Fn.group_norm_skip(m.x, None, self.norm.weight, self.norm.bias, B, HW, self.groups, 1e-6, False)
+            return Fn.linear(g, self.proj_in.weight, self.proj_in.bias, self._pin), res     # 1x1 conv == per-pixel GEMM
+        h, res = prefix.reuse("attn0.proj_in", project_in) if prefix is not None else project_in()
         d = h.shape[1]
         h = h.view(B, HW, d)
         for i, blk in enumerate(self.transformer_blocks):
             h = blk(h, encoder_hidden_states=ctx, prefix=prefix if i == 0 else None)
-        y = Fn.linear(h.reshape(B * HW, d), self.proj_out.weight, self.proj_out.bias, self._pout, residual=m.x)
+        y = Fn.linear(h.reshape(B * HW, d), self.proj_out.weight, self.proj_out.bias, self._pout, residual=res)
         return FMap(y, B, m.H, m.W)

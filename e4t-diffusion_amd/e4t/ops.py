@@ -284,17 +284,19 @@ class HipBackend:
                  "e4t_groupnorm_apply")
         return y, stats
 
-    def groupnorm_bwd(self, x1, x2, dy, stats, gamma, beta, add, B, HW, G, silu, want_param_grads=False):
+    def groupnorm_bwd(self, x1, x2, dy, stats, gamma, beta, add, B, HW, G, silu, want_param_grads=False, add2=None):
+        """add / add2: gradients reaching x1 / x2 through another consumer (bf16, same shapes), fused into the kernel."""
         C1, C2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
         Cn = C1 + C2
-        assert dy.is_contiguous() and (add is None or add.is_contiguous())
+        assert dy.is_contiguous() and (add is None or (add.is_contiguous() and add.shape == x1.shape and add.dtype == x1.dtype))
+        assert add2 is None or (x2 is not None and add2.is_contiguous() and add2.shape == x2.shape and add2.dtype == x2.dtype)
         dx1 = torch.empty_like(x1)
         dx2 = torch.empty_like(x2) if x2 is not None else None
         ch = self.lib.e4t_groupnorm_num_chunks(B, HW)
         cpart = torch.empty((B * ch, Cn, 2), dtype=f32, device=x1.device) if want_param_grads else None
         nb = self.lib.e4t_groupnorm_workspace_bytes(B, HW, Cn, G, 0) + B * G * 8
         ws = self.workspace(nb, x1.device)
-        _C.check(self.lib.e4t_groupnorm_bwd(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(add), _ptr(dx1),
+        _C.check(self.lib.e4t_groupnorm_bwd(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(add), _ptr(add2), _ptr(dx1),
                                             _ptr(dx2), _ptr(cpart), B, HW, G, int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_bwd")
         dgamma = dbeta = None
         if want_param_grads:
@@ -310,11 +312,11 @@ class HipBackend:
         _C.check(self.lib.e4t_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), M, D, float(eps), _stream()), "e4t_layernorm_fwd")
         return y, stats
 
-    def layernorm_bwd(self, x, dy, gamma, stats, want_param_grads=False):
+    def layernorm_bwd(self, x, dy, gamma, stats, want_param_grads=False, add=None):
         M, D = x.shape
-        assert dy.is_contiguous()
+        assert dy.is_contiguous() and (add is None or (add.is_contiguous() and add.shape == x.shape and add.dtype == x.dtype))
         dx = torch.empty_like(x)
-        _C.check(self.lib.e4t_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(stats), _ptr(dx), M, D, _stream()), "e4t_layernorm_bwd")
+        _C.check(self.lib.e4t_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(stats), _ptr(add), _ptr(dx), M, D, _stream()), "e4t_layernorm_bwd")
         dgamma = dbeta = None
         if want_param_grads:
             nblk = self.lib.e4t_layernorm_param_grad_blocks(M)

@@ -111,17 +111,20 @@ int e4t_groupnorm_stats(const void* x1, int C1, const void* x2, int C2, int B, i
 int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C2, const float* mean_rstd, const float* gamma,
                         const float* beta, void* y /* bf16 [B*HW][C1+C2] */, int B, int HW, int G, int silu,
                         e4t_stream stream);
-/* dx1|dx2 = d/dx of act(GN(x)) given dy, plus optional `add` (bf16 [B*HW][C]); optional per-chunk
+/* dx1|dx2 = d/dx of act(GN(x)) given dy, plus the optional gradients that reach x1 / x2 through another consumer (the
+ * ResBlock shortcut / residual): add1 bf16 [B*HW][C1], add2 bf16 [B*HW][C2], either may be NULL; optional per-chunk
  * channel partials [B][chunks][C][2] = (sum dz, sum dz*xhat) for dbeta/dgamma. */
 int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void* dy, const float* mean_rstd,
-                      const float* gamma, const float* beta, const void* add, void* dx1, void* dx2,
+                      const float* gamma, const float* beta, const void* add1, const void* add2, void* dx1, void* dx2,
                       float* dgamma_dbeta_partial, int B, int HW, int G, int silu, void* workspace, size_t ws_bytes,
                       e4t_stream stream);
 /* LayerNorm over the last dim (attention.py:259,268,273; open_clip ViT ln_*). */
 int e4t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd /* [M][2] or NULL */,
                       int M, int D, float eps, e4t_stream stream);
-int e4t_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, void* dx, int M, int D,
-                      e4t_stream stream);
+/* dx = LN'(dy) (+ add): `add` (bf16 [M][D] or NULL) is the gradient that reaches x through the residual branch of a
+ * pre-LN block, fused here instead of a separate elementwise add. */
+int e4t_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* add, void* dx,
+                      int M, int D, e4t_stream stream);
 int e4t_layernorm_param_grad_blocks(int M);
 int e4t_layernorm_param_grad(const void* x, const void* dy, const float* mean_rstd, int M, int D, float* part_dgamma,
                              float* part_dbeta, e4t_stream stream);

@@ -166,7 +166,7 @@ class EmuBackend:
             y = F.silu(y)
         return self._act(y), torch.stack([mean, rstd], dim=-1).contiguous()
 
-    def groupnorm_bwd(self, x1, x2, dy, stats, gamma, beta, add, B, HW, G, silu, want_param_grads=False):
+    def groupnorm_bwd(self, x1, x2, dy, stats, gamma, beta, add, B, HW, G, silu, want_param_grads=False, add2=None):
         x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
         Cn = x.shape[-1]
         cpg = Cn // G
@@ -182,9 +182,11 @@ class EmuBackend:
         s2 = (dzg * xhg).sum(dim=(1, 3)) / n
         dx = rstd[:, None, :, None] * (dzg - s1[:, None, :, None] - xhg * s2[:, None, :, None])
         dx = dx.reshape(B * HW, Cn)
-        if add is not None:
-            dx = dx + add.float()
         C1 = x1.shape[-1]
+        if add is not None:
+            dx[:, :C1] += add.float()
+        if add2 is not None:
+            dx[:, C1:] += add2.float()
         dx1 = self._act(dx[:, :C1].contiguous())
         dx2 = self._act(dx[:, C1:].contiguous()) if x2 is not None else None
         dgamma = dbeta = None
@@ -200,10 +202,12 @@ class EmuBackend:
         y = (xf - mean[:, None]) * rstd[:, None] * gamma.float() + beta.float()
         return self._act(y), (torch.stack([mean, rstd], dim=-1).contiguous() if need_stats else None)
 
-    def layernorm_bwd(self, x, dy, gamma, stats, want_param_grads=False):
+    def layernorm_bwd(self, x, dy, gamma, stats, want_param_grads=False, add=None):
         xh = (x.float() - stats[:, :1]) * stats[:, 1:]
         dg = dy.float() * gamma.float()
         dx = stats[:, 1:] * (dg - dg.mean(-1, keepdim=True) - xh * (dg * xh).mean(-1, keepdim=True))
+        if add is not None:
+            dx = dx + add.float()
         dgamma = dbeta = None
         if want_param_grads:
             dgamma, dbeta = (dy.float() * xh).sum(0), dy.float().sum(0)

@@ -188,9 +188,10 @@ def check_norms(hip, emu, dev):
         out.append((tag + " fwd", rel(y, yr), TOL1))
         out.append((tag + " stats", rel(st, str_), 1e-4))
         dy = rnd(g, B * HW, Cn, dev=dev)
-        add = rnd(g, B * HW, Cn, dev=dev) if i % 2 == 0 else None
-        dx1, dx2, dga, dbe = hip.groupnorm_bwd(x1, x2, dy, str_, gamma, beta, add, B, HW, G, silu, want_param_grads=True)
-        ex1, ex2, ega, ebe = emu.groupnorm_bwd(x1, x2, dy, str_, gamma, beta, add, B, HW, G, silu, want_param_grads=True)
+        add = rnd(g, B * HW, C1, dev=dev) if i % 2 == 0 else None            # gradient through the block's shortcut
+        add2 = rnd(g, B * HW, C2, dev=dev) if (C2 and i != 3) else None
+        dx1, dx2, dga, dbe = hip.groupnorm_bwd(x1, x2, dy, str_, gamma, beta, add, B, HW, G, silu, want_param_grads=True, add2=add2)
+        ex1, ex2, ega, ebe = emu.groupnorm_bwd(x1, x2, dy, str_, gamma, beta, add, B, HW, G, silu, want_param_grads=True, add2=add2)
         out.append((tag + " bwd dx1", rel(dx1, ex1), TOL1))
         if C2:
             out.append((tag + " bwd dx2", rel(dx2, ex2), TOL1))
@@ -210,6 +211,9 @@ def check_norms(hip, emu, dev):
         out.append((f"layernorm {M}x{D} bwd dx", rel(dx, ex), TOL1))
         out.append((f"layernorm {M}x{D} bwd dgamma", rel(dga, ega), 1e-3))
         out.append((f"layernorm {M}x{D} bwd dbeta", rel(dbe, ebe), 1e-3))
+        skip = rnd(g, M, D, dev=dev)
+        out.append((f"layernorm {M}x{D} bwd dx + residual grad", rel(hip.layernorm_bwd(x, dy, gamma, str_, add=skip)[0],
+                                                                     emu.layernorm_bwd(x, dy, gamma, str_, add=skip)[0]), TOL1))
     return out
 
 
