@@ -53,7 +53,7 @@ struct GemmArgs {
   const void* residual;
   int ldr;
   const float* rowbias;
-  int rows_per_batch;
+  int rows_per_batch, ldrb;
   int M, N, K;
   float alpha;
   int flags;
@@ -70,7 +70,7 @@ struct GemmArgs {
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int row, int col) {
   v *= p.alpha;
   if (p.bias) v += p.bias[col];
-  if (p.rowbias) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.N + col];
+  if (p.rowbias) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
   if (p.flags & E4T_ACT_GELU) v = gelu_f(v);
   if (p.residual) {
     if (p.flags & E4T_RES_F32) v += ((const float*)p.residual)[(size_t)row * p.ldr + col];
@@ -113,7 +113,7 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][
           float v = acc[i][j][r] * p.alpha + bv;
           if (p.rowbias) {
             const int row = mw + rl;
-            if (row < p.M && col < p.N) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.N + col];
+            if (row < p.M && col < p.N) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
           }
           if (p.flags & E4T_ACT_GELU) v = gelu_f(v);
           stage[rl * ELD + cl] = f2bf(v);
@@ -1016,7 +1016,7 @@ extern "C" int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream) {
   memset(&p, 0, sizeof(p));
   p.A = (const bf16_t*)d->A; p.A2 = (const bf16_t*)d->A2; p.K1 = d->A2 ? d->K1 : d->K; p.lda = d->lda; p.lda2 = d->lda2;
   p.B = (const bf16_t*)d->B; p.ldb = d->ldb; p.C = d->C; p.ldc = d->ldc; p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr;
-  p.rowbias = d->rowbias; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
+  p.rowbias = d->rowbias; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1; p.ldrb = d->ldrb > 0 ? d->ldrb : d->N;
   p.M = d->M; p.N = d->N; p.K = d->K; p.alpha = d->alpha; p.flags = d->flags; p.ws = (float*)d->workspace;
   p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.strideBias = d->strideBias;
   p.reduce_batch = (d->flags & E4T_REDUCE_BATCH) ? 1 : 0;
@@ -1038,7 +1038,7 @@ extern "C" int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream) {
   memset(&p, 0, sizeof(p));
   p.A = (const bf16_t*)d->X; p.K1 = 9 * Cin; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
   p.mode = mode; p.B = (const bf16_t*)d->W; p.ldb = 9 * Cin; p.C = d->Y; p.ldc = Cout; p.bias = d->bias;
-  p.residual = d->residual; p.ldr = Cout; p.rowbias = d->rowbias; p.rows_per_batch = Hout * Wout;
+  p.residual = d->residual; p.ldr = Cout; p.rowbias = d->rowbias; p.rows_per_batch = Hout * Wout; p.ldrb = d->ldrb > 0 ? d->ldrb : Cout;
   p.M = d->B * Hout * Wout; p.N = Cout; p.K = 9 * Cin; p.alpha = 1.f; p.flags = d->flags; p.ws = (float*)d->workspace;
   return launch_gemm(p, true, d->tile, d->workspace_bytes, d->splitk, 1, (hipStream_t)stream);
 }

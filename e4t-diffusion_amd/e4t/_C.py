@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
         ("lda", i32), ("lda2", i32), ("ldb", i32), ("ldc", i32), ("ldr", i32),
         ("rows_per_batch", i32), ("flags", i32), ("tile", i32), ("splitk", i32), ("batch", i32),
         ("strideA", i64), ("strideB", i64), ("strideC", i64), ("strideBias", i64),
-        ("alpha", f32),
+        ("alpha", f32), ("ldrb", i32),
     ]
 
 
@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("X", vp), ("W", vp), ("Y", vp), ("bias", vp), ("residual", vp), ("rowbias", vp),
         ("workspace", vp), ("workspace_bytes", sz),
         ("B", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("Hout", i32), ("Wout", i32), ("Cout", i32),
-        ("mode", i32), ("flags", i32), ("tile", i32), ("splitk", i32),
+        ("mode", i32), ("flags", i32), ("tile", i32), ("splitk", i32), ("ldrb", i32),
     ]
 
 

@@ -275,6 +275,28 @@ def conv3x3(x, weight, bias, prep, geom, mode=_C.CONV_S1, rowbias=None, residual
     return ConvFn.apply(x, weight, bias, rowbias, residual, prep, geom, mode, out_f32)
 
 
+class TimeEmbProjAllFn(torch.autograd.Function):
+    """time_emb_proj(silu(emb)) of EVERY ResBlock of the UNet in one GEMM ([3P] ResnetBlock2D: `temb = time_emb_proj(act(temb))`,
+    22 Linear(1280 -> Cout) on the same (B, 1280) input; M = B rows make each a latency-bound launch of its own).
+    Returns one fp32 (B, Cout_i) column-slice view per block of a single (B, sum Cout) matrix; the conv epilogue reads its
+    slice through the row stride (`ldrb`).  Frozen weights only (pretrain): dX = (cat of the slices' grads) . Wcat."""
+
+    @staticmethod
+    def forward(ctx, temb_act, wcat, wcat_t, bcat, splits):
+        y = ops.backend().gemm(temb_act, wcat, bias=bcat, out_dtype=f32)
+        ctx.save_for_backward(wcat_t)
+        ctx.splits, ctx.act = splits, temb_act.dtype
+        return tuple(y[:, o:o + c] for o, c in splits)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (wcat_t,) = ctx.saved_tensors
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros((ref.shape[0], c)) for g, (o, c) in zip(grads, ctx.splits)]
+        dy = torch.cat(parts, dim=1).to(ctx.act)
+        return ops.backend().gemm(dy, wcat_t), None, None, None, None
+
+
 # ----------------------------------------------------------------------------------------------
 # norms
 # ----------------------------------------------------------------------------------------------

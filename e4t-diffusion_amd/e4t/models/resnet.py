@@ -55,6 +55,7 @@ class ResnetBlock2D(nn.Module):
         self._p1, self._p2 = Fn.PreparedConv(self.conv1.weight), Fn.PreparedConv(self.conv2.weight)
         self._pt = Fn.PreparedLinear(self.time_emb_proj.weight) if self.time_emb_proj is not None else None
         self._ps = Fn.PreparedLinear(self.conv_shortcut.weight) if self.conv_shortcut is not None else None
+        self._rb = None
 
     def forward_nhwc(self, m: FMap, skip: FMap = None, temb_act=None) -> FMap:
         """m (+ optional skip = the second torch.cat source); temb_act = silu(emb) as [B, temb] (ACT dtype)."""
@@ -63,8 +64,8 @@ class ResnetBlock2D(nn.Module):
         x2 = skip.x if skip is not None else None
         # x1 / x2 come back as the operands for the shortcut: their gradient is folded into the GroupNorm backward
         h, x1, x2 = Fn.group_norm_skip(m.x, x2, self.norm1.weight, self.norm1.bias, B, H * W, self.groups, self.eps, True)
-        rb = None
-        if temb_act is not None and self.time_emb_proj is not None:
+        rb = self._rb          # set by the UNet when all blocks' projections were evaluated in one GEMM (TimeEmbProjAllFn)
+        if rb is None and temb_act is not None and self.time_emb_proj is not None:
             rb = Fn.linear(temb_act, self.time_emb_proj.weight, self.time_emb_proj.bias, self._pt, out_f32=True)
         h = Fn.conv3x3(h, self.conv1.weight, self.conv1.bias, self._p1, geom, rowbias=rb)
         h = Fn.group_norm(h, None, self.norm2.weight, self.norm2.bias, B, H * W, self.groups, self.eps, True)

@@ -134,6 +134,9 @@ class UNet2DConditionModel(nn.Module):
         # Weight-offset banks in gradient-finalisation order: the up-block heads are final
         # first in the backward, the mid/down heads (shared by both UNet passes) last.
         self._prefix = _SharedPrefix()
+        from .resnet import ResnetBlock2D
+        self._resblocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        self._temb_cat, self._temb_rb = None, None
         self.share_prefix = False          # enabled by `with unet.shared_prefix():` around the two passes of one step
         self.wo_banks = [WOBank("up"), WOBank("mid_down")]
         for mod in self.up_blocks.modules():
@@ -167,6 +170,28 @@ class UNet2DConditionModel(nn.Module):
 
     def set_use_memory_efficient_attention_xformers(self, valid: bool, attention_op=None):
         self.set_attn_processor(HipAttnProcessor())
+
+    def _clear_rb(self):
+        for r in self._resblocks:
+            r._rb = None
+
+    def _time_emb_proj_all(self, temb_act):
+        """One GEMM for the time-embedding projections of all ResBlocks (functional.TimeEmbProjAllFn); None when any of
+        them is trainable (tuning) — the blocks then run their own Linear."""
+        lins = [r.time_emb_proj for r in self._resblocks]
+        if any(l is None or l.weight.requires_grad or l.bias is None or l.bias.requires_grad for l in lins):
+            return None
+        key = (tuple(l.weight.data_ptr() for l in lins), temb_act.dtype, temb_act.device)
+        if self._temb_cat is None or self._temb_cat[0] != key:
+            w = torch.cat([l.weight.detach() for l in lins], dim=0).to(temb_act.dtype).contiguous()      # [sum Cout, temb]
+            b = torch.cat([l.bias.detach().float() for l in lins], dim=0).contiguous()
+            splits, o = [], 0
+            for l in lins:
+                splits.append((o, l.out_features))
+                o += l.out_features
+            self._temb_cat = (key, w, w.t().contiguous(), b, tuple(splits))
+        _, w, wt, b, splits = self._temb_cat
+        return Fn.TimeEmbProjAllFn.apply(temb_act, w, wt, b, splits)
 
     def shared_prefix(self):
         """Context manager: forwards issued inside it on the SAME (sample, timestep) tensors share the context-independent
@@ -219,11 +244,15 @@ class UNet2DConditionModel(nn.Module):
         def stem():
             emb = self.time_embedding(be.timestep_embedding(t, self._temb_in))
             temb_act = Fn.silu(emb)      # every ResBlock consumes silu(emb): evaluate it once
+            self._temb_rb = self._time_emb_proj_all(temb_act)
             # 2. conv_in: 4 latent channels zero-padded to one 64-wide K tile
             x = torch.zeros((B * H * W, 64), dtype=act, device=dev)
             x[:, :Cin] = sample.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
             return temb_act, Fn.conv3x3(x, self.conv_in.weight, self.conv_in.bias, self._pin, (B, H, W, H, W))
-        temb_act, x0 = prefix.reuse("stem", stem)
+        self._temb_rb = None
+        temb_act, x0, rbs = prefix.reuse("stem", lambda: stem() + (self._temb_rb,))
+        for r, rb in zip(self._resblocks, rbs or [None] * len(self._resblocks)):
+            r._rb = rb
         ctx = encoder_hidden_states.to(act).contiguous()
         m = FMap(x0, B, H, W)
         # 3. down
@@ -238,6 +267,7 @@ class UNet2DConditionModel(nn.Module):
         # 4. mid
         m = self.mid_block.forward_nhwc(m, temb_act, ctx)
         if return_encoder_outputs:
+            self._clear_rb()
             return dict(down_block_samples=tuple(s.nchw() for s in skips + (m,)))
         # 5. up
         for blk in self.up_blocks:
@@ -248,6 +278,7 @@ class UNet2DConditionModel(nn.Module):
         h = Fn.group_norm(m.x, None, self.conv_norm_out.weight, self.conv_norm_out.bias, B, H * W, self._groups, self._eps, True)
         y = Fn.conv3x3(h, self.conv_out.weight, self.conv_out.bias, self._pout, (B, H, W, H, W), out_f32=True)
         out = y.view(B, H, W, -1).permute(0, 3, 1, 2)
+        self._clear_rb()
         if not return_dict:
             return (out,)
         return UNet2DConditionOutput(sample=out)

@@ -183,6 +183,7 @@ class HipBackend:
         d.lda, d.lda2, d.ldb, d.ldc = a.stride(-2), (a2.stride(-2) if a2 is not None else 0), b.stride(-2), out.stride(-2)
         d.ldr = residual.stride(-2) if residual is not None else 0
         d.rows_per_batch = rows_per_batch
+        d.ldrb = rowbias.stride(0) if rowbias is not None else 0
         flags = 0
         if out.dtype == f32:
             flags |= _C.OUT_F32
@@ -225,6 +226,7 @@ class HipBackend:
         if accum:
             flags |= _C.ACCUM
         d.mode, d.flags, d.tile, d.splitk = mode, flags, tile, splitk
+        d.ldrb = rowbias.stride(0) if rowbias is not None else 0
         need = _gemm_ws_need(M, Cout, 9 * Cin, 1, tile, splitk, False)
         ws = self.workspace(need, x.device) if need else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)

@@ -49,7 +49,7 @@ typedef struct {
   void* C;             /* bf16 or fp32 [M][ldc] */
   const float* bias;   /* optional fp32 [N] */
   const void* residual;/* optional [M][ldr], added after activation */
-  const float* rowbias;/* optional fp32 [M/rows_per_batch][N] (ResBlock time-embedding add) */
+  const float* rowbias;/* optional fp32 [M/rows_per_batch][ldrb] (ResBlock time-embedding add) */
   void* workspace;     /* fp32 scratch for split-K / batch reduction, or NULL */
   size_t workspace_bytes;
   int M, N, K, K1;
@@ -61,6 +61,7 @@ typedef struct {
   int batch;           /* >= 1; operand base pointers advance by the strides below (elements) */
   long long strideA, strideB, strideC, strideBias;
   float alpha;
+  int ldrb;            /* row stride of rowbias (elements); 0 = N */
 } e4t_gemm_desc;
 int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream);
 
@@ -79,11 +80,13 @@ typedef struct {
   void* Y;             /* bf16/fp32 [B][Hout][Wout][Cout] */
   const float* bias;   /* fp32 [Cout] or NULL */
   const void* residual;/* [B][Hout][Wout][Cout] or NULL */
-  const float* rowbias;/* fp32 [B][Cout] or NULL */
+  const float* rowbias;/* fp32 [B][ldrb] or NULL */
   void* workspace;
   size_t workspace_bytes;
   int B, Hin, Win, Cin, Hout, Wout, Cout;
   int mode, flags, tile, splitk;
+  int ldrb;            /* row stride of rowbias (elements); 0 = Cout.  Lets all ResBlocks' time-embedding projections
+                          live in one (B, sum Cout) matrix produced by a single GEMM */
 } e4t_conv_desc;
 int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream);
 
