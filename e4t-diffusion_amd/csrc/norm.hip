@@ -130,12 +130,45 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* partial, 
   }
 }
 
+// Block-cooperative finalize (fused into the consumers: saves one launch per GroupNorm call each way): every wave walks
+// groups wave, wave+4, ...; lane c sums chunks c, c+64, ... in double, fixed-order butterfly — the same order as the
+// stand-alone gn_finalize_kernel, so both paths are bitwise identical; fin(g, sum0, sum1) runs on lane 0 of the wave.
+template <typename Fin>
+__device__ __forceinline__ void gn_block_sum_partials(const float* partial_b /* [nchunk][G][2] of this batch */, int nchunk, int G, Fin fin) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int g = wave; g < G; g += nw) {
+    double s = 0.0, q = 0.0;
+    for (int c = lane; c < nchunk; c += 64) {
+      const float2 pp = *(const float2*)(partial_b + ((size_t)c * G + g) * 2);
+      s += pp.x; q += pp.y;
+    }
+    s = wave_sum_f64(s); q = wave_sum_f64(q);
+    if (lane == 0) fin(g, s, q);
+  }
+  __syncthreads();
+}
+
 // y = act(gamma * (x - mean) * rstd + beta), written as one contiguous (B*HW, C) bf16 matrix
+// FUSED: mean / rstd are finalised from the stats kernel's chunk partials in the prologue (and written to mean_rstd_out by
+// chunk 0 of every batch entry for the backward) instead of by a separate finalize launch.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNSrc s, const float* mean_rstd, const float* gamma, const float* beta,
-                                                       bf16_t* y, int HW, int G, int pix_per_chunk, int silu) {
+                                                       bf16_t* y, int HW, int G, int pix_per_chunk, int silu,
+                                                       const float* partial, float inv_n, float eps, float* mean_rstd_out) {
   const int C = s.C1 + s.C2, cpg = C / G;
   const GNMap m(C);
   const int b = blockIdx.y;
+  __shared__ float mr_lds[FUSED ? 512 : 2];
+  if (FUSED) {
+    gn_block_sum_partials(partial + (size_t)b * gridDim.x * G * 2, gridDim.x, G, [&](int g, double sm, double sq) {
+      const double mean = sm * inv_n;
+      double var = sq * inv_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+      mr_lds[g * 2] = mf; mr_lds[g * 2 + 1] = rf;
+      if (blockIdx.x == 0) { mean_rstd_out[((size_t)b * G + g) * 2] = mf; mean_rstd_out[((size_t)b * G + g) * 2 + 1] = rf; }
+    });
+  }
   const int p0 = blockIdx.x * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
   float sc[GN_MAXS][8], sh[GN_MAXS][8];
@@ -146,7 +179,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNSrc s, const float* mea
       sc[i][j] = 0.f; sh[i][j] = 0.f;
       if (m.ch[i] >= 0) {
         const int c = m.ch[i] * 8 + j, g = c / cpg;
-        const float mean = mean_rstd[((size_t)b * G + g) * 2], rstd = mean_rstd[((size_t)b * G + g) * 2 + 1];
+        const float mean = FUSED ? mr_lds[g * 2] : mean_rstd[((size_t)b * G + g) * 2];
+        const float rstd = FUSED ? mr_lds[g * 2 + 1] : mean_rstd[((size_t)b * G + g) * 2 + 1];
         sc[i][j] = rstd * gamma[c];
         sh[i][j] = beta[c] - mean * sc[i][j];
       }
@@ -213,28 +247,18 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(GNSrc s, const bf16_t
                   chan_partial ? chan_partial + ((size_t)b * gridDim.x + chunk) * C * 2 : nullptr);
 }
 
-// gsum[b][g] = (S1, S2) summed over chunks (one wave per (b, g), as gn_finalize_kernel)
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* partial, int nchunk, int G, int BG, float* gsum) {
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (i >= BG) return;
-  const int b = i / G, g = i - b * G;
-  double s = 0.0, q = 0.0;
-  for (int c = lane; c < nchunk; c += 64) {
-    const float2 pp = *(const float2*)(partial + (((size_t)b * nchunk + c) * G + g) * 2);
-    s += pp.x; q += pp.y;
-  }
-  s = wave_sum_f64(s); q = wave_sum_f64(q);
-  if (lane == 0) { gsum[i * 2] = (float)s; gsum[i * 2 + 1] = (float)q; }
-}
-
 // Backward pass 2: dx = rstd * (dz*gamma - (S1 + xhat*S2)/n) (+ add), split into dx1 | dx2 along C
+// gsum == nullptr: (S1, S2) are reduced from bwd_stats' chunk partials in the prologue (no finalize launch)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t* dy, const float* mean_rstd, const float* gsum,
                                                            const float* gamma, const float* beta, const bf16_t* add1,
                                                            const bf16_t* add2, bf16_t* dx1, bf16_t* dx2, int HW, int G,
-                                                           int pix_per_chunk, int silu, float inv_n) {
+                                                           int pix_per_chunk, int silu, float inv_n, const float* partial) {
   const int C = s.C1 + s.C2, cpg = C / G;
   const GNMap m(C);
   const int b = blockIdx.y;
+  __shared__ float gs_lds[512];
+  if (!gsum) gn_block_sum_partials(partial + (size_t)b * gridDim.x * G * 2, gridDim.x, G,
+                                   [&](int g, double sm, double sq) { gs_lds[g * 2] = (float)sm; gs_lds[g * 2 + 1] = (float)sq; });
   const int p0 = blockIdx.x * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
   float mu[GN_MAXS][8], rs[GN_MAXS][8], ga[GN_MAXS][8], be[GN_MAXS][8], g1[GN_MAXS][8], g2[GN_MAXS][8];
@@ -247,7 +271,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t
         const int c = m.ch[i] * 8 + j, g = c / cpg;
         mu[i][j] = mean_rstd[((size_t)b * G + g) * 2]; rs[i][j] = mean_rstd[((size_t)b * G + g) * 2 + 1];
         ga[i][j] = gamma[c]; be[i][j] = beta[c];
-        g1[i][j] = gsum[((size_t)b * G + g) * 2] * inv_n; g2[i][j] = gsum[((size_t)b * G + g) * 2 + 1] * inv_n;
+        g1[i][j] = (gsum ? gsum[((size_t)b * G + g) * 2] : gs_lds[g * 2]) * inv_n;
+        g2[i][j] = (gsum ? gsum[((size_t)b * G + g) * 2 + 1] : gs_lds[g * 2 + 1]) * inv_n;
       }
     }
   for (int p = p0 + m.pg; p < p1; p += m.PG) {
@@ -431,7 +456,25 @@ extern "C" int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C
   E4T_REQUIRE(mean_rstd && gamma && beta && y, "groupnorm_apply: null argument");
   const int ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch);
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(ch, Bn), dim3(256), 0, (hipStream_t)stream, s, mean_rstd, gamma, beta, (bf16_t*)y, HW, G, ppc, silu);
+  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ch, Bn), dim3(256), 0, (hipStream_t)stream, s, mean_rstd, gamma, beta, (bf16_t*)y, HW, G, ppc,
+                     silu, (const float*)nullptr, 0.f, 0.f, (float*)nullptr);
+  E4T_CHECK_LAUNCH("gn_apply_kernel");
+  return 0;
+}
+
+extern "C" int e4t_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta, void* y,
+                                 float* mean_rstd, int Bn, int HW, int G, float eps, int silu, void* workspace, size_t ws_bytes,
+                                 e4t_stream stream) {
+  if (int e = gn_check(x1, C1, x2, C2, Bn, HW, G)) return e;
+  E4T_REQUIRE(gamma && beta && y && mean_rstd, "groupnorm_fwd: null argument");
+  const int C = C1 + C2, ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch);
+  E4T_REQUIRE(workspace && ws_bytes >= (size_t)Bn * ch * G * 2 * sizeof(float), "groupnorm_fwd: workspace too small");
+  GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
+  E4T_CHECK_LAUNCH("gn_stats_kernel");
+  hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
+                     (const float*)workspace, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
   E4T_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
 }
@@ -452,10 +495,10 @@ extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2,
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, (const bf16_t*)dy, mean_rstd,
                      gamma, beta, HW, G, ppc, silu, partial, dgamma_dbeta_partial);
   E4T_CHECK_LAUNCH("gn_bwd_stats_kernel");
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(BG, 4)), dim3(256), 0, st, (const float*)partial, ch, G, BG, gsum);
-  E4T_CHECK_LAUNCH("gn_bwd_finalize_kernel");
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ch, Bn), dim3(256), 0, st, s, (const bf16_t*)dy, mean_rstd, (const float*)gsum, gamma, beta,
-                     (const bf16_t*)add1, (const bf16_t*)add2, (bf16_t*)dx1, (bf16_t*)dx2, HW, G, ppc, silu, 1.f / ((float)(C / G) * (float)HW));
+  (void)gsum;     // (S1, S2) are reduced from the partials inside gn_bwd_apply_kernel: no finalize launch
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ch, Bn), dim3(256), 0, st, s, (const bf16_t*)dy, mean_rstd, (const float*)nullptr, gamma, beta,
+                     (const bf16_t*)add1, (const bf16_t*)add2, (bf16_t*)dx1, (bf16_t*)dx2, HW, G, ppc, silu, 1.f / ((float)(C / G) * (float)HW),
+                     (const float*)partial);
   E4T_CHECK_LAUNCH("gn_bwd_apply_kernel");
   return 0;
 }

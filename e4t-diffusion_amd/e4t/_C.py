@@ -57,6 +57,7 @@ SIGNATURES = {
     "e4t_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "e4t_groupnorm_stats": (i32, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, sz, vp]),
     "e4t_groupnorm_apply": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "e4t_groupnorm_fwd": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, sz, vp]),
     "e4t_groupnorm_bwd": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "e4t_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "e4t_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),

@@ -279,6 +279,17 @@ class HipBackend:
         stats = torch.empty((B, G, 2), dtype=f32, device=x1.device)
         nb = self.lib.e4t_groupnorm_workspace_bytes(B, HW, Cn, G, 0)
         ws = self.workspace(nb, x1.device)
+        y = torch.empty((B * HW, Cn), dtype=bf16, device=x1.device)
+        _C.check(self.lib.e4t_groupnorm_fwd(_ptr(x1), C1, _ptr(x2), C2, _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), B, HW, G, float(eps),
+                                            int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_fwd")
+        return y, stats
+
+    def groupnorm_fwd_unfused(self, x1, x2, gamma, beta, B, HW, G, eps, silu):
+        """stats (+ finalize) and apply as separate ABI calls — kept for the kernel checks of those entry points."""
+        C1, C2 = x1.shape[-1], (x2.shape[-1] if x2 is not None else 0)
+        Cn = C1 + C2
+        stats = torch.empty((B, G, 2), dtype=f32, device=x1.device)
+        ws = self.workspace(self.lib.e4t_groupnorm_workspace_bytes(B, HW, Cn, G, 0), x1.device)
         _C.check(self.lib.e4t_groupnorm_stats(_ptr(x1), C1, _ptr(x2), C2, B, HW, G, float(eps), _ptr(stats), _ptr(ws), ws.numel(), _stream()),
                  "e4t_groupnorm_stats")
         y = torch.empty((B * HW, Cn), dtype=bf16, device=x1.device)

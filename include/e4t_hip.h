@@ -114,6 +114,11 @@ int e4t_groupnorm_stats(const void* x1, int C1, const void* x2, int C2, int B, i
 int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C2, const float* mean_rstd, const float* gamma,
                         const float* beta, void* y /* bf16 [B*HW][C1+C2] */, int B, int HW, int G, int silu,
                         e4t_stream stream);
+/* stats + apply in two launches (the apply kernel finalises mean / rstd from the chunk partials itself and writes them to
+ * mean_rstd for the backward).  workspace: e4t_groupnorm_workspace_bytes(B, HW, C, G, 0). */
+int e4t_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta, void* y,
+                      float* mean_rstd /* out [B][G][2] */, int B, int HW, int G, float eps, int silu, void* workspace,
+                      size_t ws_bytes, e4t_stream stream);
 /* dx1|dx2 = d/dx of act(GN(x)) given dy, plus the optional gradients that reach x1 / x2 through another consumer (the
  * ResBlock shortcut / residual): add1 bf16 [B*HW][C1], add2 bf16 [B*HW][C2], either may be NULL; optional per-chunk
  * channel partials [B][chunks][C][2] = (sum dz, sum dz*xhat) for dbeta/dgamma. */

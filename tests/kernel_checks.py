@@ -187,6 +187,8 @@ def check_norms(hip, emu, dev):
         tag = f"groupnorm B{B} HW{HW} C{C1}+{C2} silu{int(silu)}"
         out.append((tag + " fwd", rel(y, yr), TOL1))
         out.append((tag + " stats", rel(st, str_), 1e-4))
+        y2, st2 = hip.groupnorm_fwd_unfused(x1, x2, gamma, beta, B, HW, G, 1e-5, silu)
+        out.append((tag + " fused == stats/finalize/apply entry points", float((y2 != y).sum() + (st2 != st).sum()), 0.0))
         dy = rnd(g, B * HW, Cn, dev=dev)
         add = rnd(g, B * HW, C1, dev=dev) if i % 2 == 0 else None            # gradient through the block's shortcut
         add2 = rnd(g, B * HW, C2, dev=dev) if (C2 and i != 3) else None
