@@ -306,8 +306,18 @@ class E4TEncoder(nn.Module):
         return self._gW, self._gB, f.weight.grad, f.bias.grad
 
     # ---- forward ------------------------------------------------------------------------------------------
-    def forward(self, x, unet_down_block_samples: tuple):
-        """x: (B,3,H,W) image in [-1,1]; unet_down_block_samples: the 13 maps from UNet(..., return_encoder_outputs=True)."""
+    def vision_is_frozen(self) -> bool:
+        return not any(p.requires_grad for p in self.clip_vision.parameters())
+
+    def encode_vision(self, x):
+        """The CLIP-ViT half of forward(): depends on the image only, so a trainer may launch it early (on a side stream)
+        and hand the result back through forward(vision=...)."""
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not self.vision_is_frozen()):
+            return self.clip_vision(x)
+
+    def forward(self, x, unet_down_block_samples: tuple, vision=None):
+        """x: (B,3,H,W) image in [-1,1]; unet_down_block_samples: the 13 maps from UNet(..., return_encoder_outputs=True);
+        vision: optional precomputed encode_vision(x)."""
         act = ops.ACT
         B = x.shape[0]
         maps = []
@@ -319,9 +329,7 @@ class E4TEncoder(nn.Module):
         e0, e2 = self.unet_feature_embedder[0], self.unet_feature_embedder[2]
         u = Fn.linear(pooled.to(act), e0.weight, e0.bias, self._p0)
         u = Fn.linear(Fn.leaky_relu(u), e2.weight, e2.bias, self._p2)                      # [B, hid]
-        vit_trainable = any(p.requires_grad for p in self.clip_vision.parameters())
-        with torch.set_grad_enabled(torch.is_grad_enabled() and vit_trainable):
-            cls, tokens = self.clip_vision(x)
+        cls, tokens = vision if vision is not None else self.encode_vision(x)
         hs = torch.cat([cls[:, None], tokens[:, 1::2]], dim=1).contiguous()               # [B, n, hid]  (:155-156)
         assert hs.shape[1] == len(self.first_linears), (hs.shape, len(self.first_linears))
         ybar = _HeadFn.apply(hs, u, self)                                                  # [B, hid] fp32

@@ -149,7 +149,8 @@ class HipBackend:
 
     # ------------------------------------------------------------------ workspaces
     def workspace(self, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index)
+        # one scratch buffer per (device, stream): kernels of concurrent streams must not share split-K / stats partials
+        key = (device.type, device.index, _stream() if device.type == "cuda" else 0)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
