@@ -61,8 +61,9 @@ SIGNATURES = {
     "e4t_groupnorm_bwd": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "e4t_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "e4t_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
-    "e4t_layernorm_param_grad_blocks": (i32, [i32]),
-    "e4t_layernorm_param_grad": (i32, [vp, vp, vp, i32, i32, vp, vp, vp]),
+    "e4t_colreduce_splits": (i32, [i32]),
+    "e4t_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "e4t_layernorm_param_grad": (i32, [vp, vp, vp, i32, i32, vp, vp, i32, vp, sz, vp]),
     "e4t_wo_vecs_floats": (sz, [i32, i32]),
     "e4t_wo_partial_floats": (sz, [i32, i32]),
     "e4t_wo_forward": (i32, [vp, i32, i32, i32, vp]),

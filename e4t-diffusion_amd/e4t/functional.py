@@ -129,7 +129,7 @@ class LinearFn(torch.autograd.Function):
                 dw = dw[:, :kw].contiguous()
             dw = dw.reshape(ctx.prep.weight.shape)
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum(0)
+            db = ops.backend().colsum(dyb)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
         return dx, dw, db, dres, dx2, None, None, None
@@ -261,7 +261,7 @@ class ConvFn(torch.autograd.Function):
             dwk = be.gemm(dyT, xcolT, out_dtype=f32)                       # [Cout, 9 * Cx]
             dw = dwk.view(wshape[0], 9, ctx.cin)[:, :, : wshape[1]].permute(0, 2, 1).reshape(wshape).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum(0)
+            db = ops.backend().colsum(dyb)
         if has_rb and ctx.needs_input_grad[3]:
             drb = torch.zeros((B, cout), dtype=f32, device=dy.device)
             be.spatial_mean(dyb, B, Hout * Wout, drb, 0)

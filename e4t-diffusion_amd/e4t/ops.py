@@ -333,12 +333,25 @@ class HipBackend:
         _C.check(self.lib.e4t_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(stats), _ptr(add), _ptr(dx), M, D, _stream()), "e4t_layernorm_bwd")
         dgamma = dbeta = None
         if want_param_grads:
-            nblk = self.lib.e4t_layernorm_param_grad_blocks(M)
-            pg = torch.empty((nblk, D), dtype=f32, device=x.device)
-            pb = torch.empty((nblk, D), dtype=f32, device=x.device)
-            _C.check(self.lib.e4t_layernorm_param_grad(_ptr(x), _ptr(dy), _ptr(stats), M, D, _ptr(pg), _ptr(pb), _stream()), "e4t_layernorm_param_grad")
-            dgamma, dbeta = pg.sum(0), pb.sum(0)
+            dgamma, dbeta = torch.empty(D, dtype=f32, device=x.device), torch.empty(D, dtype=f32, device=x.device)
+            ws = self.workspace(2 * self.lib.e4t_colreduce_splits(M) * D * 4, x.device)
+            _C.check(self.lib.e4t_layernorm_param_grad(_ptr(x), _ptr(dy), _ptr(stats), M, D, _ptr(dgamma), _ptr(dbeta), 0, _ptr(ws), ws.numel(),
+                                                       _stream()), "e4t_layernorm_param_grad")
         return dx, dgamma, dbeta
+
+    def colsum(self, x, out=None, accumulate=False):
+        """fp32 column sums of a (M, C) bf16 matrix (bias gradients); accumulate=True adds into `out`."""
+        M, Cn = x.shape
+        assert x.stride(1) == 1 and x.dtype == bf16
+        if Cn % 8 or x.stride(0) % 8 or x.data_ptr() % 16:          # e.g. conv_out's 4 channels: not worth a kernel
+            r = x.float().sum(0)
+            return r if out is None else (out.add_(r) if accumulate else out.copy_(r))
+        if out is None:
+            out, accumulate = torch.empty(Cn, dtype=f32, device=x.device), False
+        assert out.dtype == f32 and out.is_contiguous() and out.numel() == Cn
+        ws = self.workspace(self.lib.e4t_colreduce_splits(M) * Cn * 4, x.device)
+        _C.check(self.lib.e4t_colsum(_ptr(x), x.stride(0), M, Cn, _ptr(out), int(accumulate), _ptr(ws), ws.numel(), _stream()), "e4t_colsum")
+        return out
 
     # ------------------------------------------------------------------ streaming ops
     def geglu_fwd(self, u):

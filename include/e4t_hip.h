@@ -133,9 +133,14 @@ int e4t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
  * pre-LN block, fused here instead of a separate elementwise add. */
 int e4t_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* add, void* dx,
                       int M, int D, e4t_stream stream);
-int e4t_layernorm_param_grad_blocks(int M);
-int e4t_layernorm_param_grad(const void* x, const void* dy, const float* mean_rstd, int M, int D, float* part_dgamma,
-                             float* part_dbeta, e4t_stream stream);
+/* Column reductions over the rows of a (M, C) bf16 matrix (two launches, deterministic).  workspace: fp32
+ * [e4t_colreduce_splits(M)][C] (x2 for the LayerNorm variant).  accumulate != 0: out += result (gradient accumulation). */
+int e4t_colreduce_splits(int M);
+/* out[c] = sum_r x[r][c]: bias gradients of nn.Linear / nn.Conv2d (tuning_e4t.py trains every UNet weight). */
+int e4t_colsum(const void* x, int ldx, int M, int C, float* out, int accumulate, void* workspace, size_t ws_bytes, e4t_stream stream);
+/* dgamma[c] = sum_r dy * xhat, dbeta[c] = sum_r dy of a LayerNorm over the last dim. */
+int e4t_layernorm_param_grad(const void* x, const void* dy, const float* mean_rstd, int M, int D, float* dgamma, float* dbeta,
+                             int accumulate, void* workspace, size_t ws_bytes, e4t_stream stream);
 
 /* ---------------------------------------------------------------- weight offsets (wo.hip) ---- */
 /* One descriptor per WeightOffsets instance (weightoffsets.py:5-23) + the projection weight it

@@ -213,6 +213,13 @@ class EmuBackend:
             dgamma, dbeta = (dy.float() * xh).sum(0), dy.float().sum(0)
         return self._act(dx), dgamma, dbeta
 
+    def colsum(self, x, out=None, accumulate=False):
+        r = x.float().sum(0)
+        if out is None:
+            return r
+        out.copy_(out + r if accumulate else r)
+        return out
+
     # ------------------------------------------------------------------ streaming ops
     def geglu_fwd(self, u):
         a, g = u.float().chunk(2, dim=-1)

@@ -221,6 +221,14 @@ def check_norms(hip, emu, dev):
 
 def check_streaming(hip, emu, dev):
     out = []
+    g = gen(179, dev)
+    for M, Cn in [(37, 64), (5000, 320), (65536, 320), (1232, 2560), (300, 8)]:
+        xs = rnd(g, M, Cn + 8, dev=dev)[:, :Cn]                      # strided view
+        out.append((f"colsum {M}x{Cn}", rel(hip.colsum(xs), emu.colsum(xs)), 1e-3))
+    acc = torch.ones(320, dtype=f32, device=dev)
+    xs = rnd(g, 700, 320, dev=dev)
+    hip.colsum(xs, out=acc, accumulate=True)
+    out.append(("colsum accumulate", rel(acc, 1.0 + emu.colsum(xs)), 1e-3))
     g = gen(180, dev)
     u = rnd(g, 300, 2 * 640, dev=dev)
     dh = rnd(g, 300, 640, dev=dev)
