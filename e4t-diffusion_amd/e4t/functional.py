@@ -74,15 +74,40 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
-def _weight_grad(dy, x, x2=None):
-    """dW[N, K] = dy^T . x  (fp32) via two transposes + one NT GEMM whose contraction runs over the rows."""
+def _weight_grad(dy, x, x2=None, out=None):
+    """dW[N, K] = dy^T . x  (fp32) via two transposes + one NT GEMM whose contraction runs over the rows.
+    out: fp32 [N, K] to ACCUMULATE into (a parameter's .grad) instead of returning a fresh tensor."""
     be = ops.backend()
     M = dy.shape[0]
     dyT = be.transpose(dy, pad_to=_pad8(M))
     xT = be.transpose(x, pad_to=_pad8(M))
     if x2 is not None:
         xT = torch.cat([xT, be.transpose(x2, pad_to=_pad8(M))], dim=0)
+    if out is not None:
+        return be.gemm(dyT, xT, out=out, accum=True)
     return be.gemm(dyT, xT, out_dtype=f32)
+
+
+# Gradient accumulation without autograd's AccumulateGrad: when a trainer has installed persistent fp32 .grad storage
+# (E4TTrainer's flat gradient buffer, zeroed once per step) and opted in, weight / bias gradients are accumulated into it
+# by the producing kernel (GEMM ACCUM epilogue, colsum accumulate) and the autograd function returns None for them —
+# in tuning that removes ~900 elementwise adds and as many temporaries per step.  Off by default: code that relies on
+# autograd hooks on the parameters (e.g. torch DDP) must see the gradients come out of backward().
+_INPLACE_PARAM_GRADS = False
+
+
+def set_inplace_param_grads(enabled: bool):
+    global _INPLACE_PARAM_GRADS
+    _INPLACE_PARAM_GRADS = bool(enabled)
+
+
+def _grad_slot(p):
+    if not _INPLACE_PARAM_GRADS or p is None or not p.is_leaf:
+        return None
+    g = p.grad
+    if g is None or g.dtype != f32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
 
 
 # ----------------------------------------------------------------------------------------------
@@ -97,6 +122,7 @@ class LinearFn(torch.autograd.Function):
         wv = w[:, :K] if w.shape[1] != K else w
         y = be.gemm(x, wv, a2=x2, bias=bias, residual=residual, gelu=gelu, out_dtype=f32 if out_f32 else act_dtype())
         ctx.prep, ctx.gelu = prep, gelu
+        ctx.bias_param = bias if (bias is not None and bias.requires_grad and bias.is_leaf) else None
         ctx.N = weight.shape[0]
         need_w = weight.requires_grad
         ctx.save_for_backward(x if need_w else None, x2 if need_w else None)
@@ -123,13 +149,23 @@ class LinearFn(torch.autograd.Function):
         if has_x2 and ctx.needs_input_grad[4]:
             dx2 = be.gemm(dyb, wTn[ctx.k1:])
         if ctx.needs_input_grad[1]:
-            dw = _weight_grad(dyb, x, x2)
-            kw = ctx.prep.weight[0].numel()          # true K (x may carry zero pad columns, e.g. patch-embed 588 -> 592)
-            if dw.shape[1] != kw:
-                dw = dw[:, :kw].contiguous()
-            dw = dw.reshape(ctx.prep.weight.shape)
+            wp = ctx.prep.weight
+            kw = wp[0].numel()                       # true K (x may carry zero pad columns, e.g. patch-embed 588 -> 592)
+            kx = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+            g = _grad_slot(wp)
+            if g is not None and kx == kw:
+                _weight_grad(dyb, x, x2, out=g.view(N, kw))      # accumulates straight into the (flat-buffer) .grad
+            else:
+                dw = _weight_grad(dyb, x, x2)
+                if dw.shape[1] != kw:
+                    dw = dw[:, :kw].contiguous()
+                dw = dw.reshape(wp.shape)
         if has_bias and ctx.needs_input_grad[2]:
-            db = ops.backend().colsum(dyb)
+            g = _grad_slot(ctx.bias_param) if ctx.bias_param is not None else None
+            if g is not None:
+                ops.backend().colsum(dyb, out=g, accumulate=True)
+            else:
+                db = ops.backend().colsum(dyb)
         if has_res and ctx.needs_input_grad[3]:
             dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
         return dx, dw, db, dres, dx2, None, None, None
@@ -219,6 +255,7 @@ class ConvFn(torch.autograd.Function):
         ctx.prep, ctx.geom, ctx.mode = prep, geom, mode
         ctx.cin = x.shape[1]
         ctx.has = (bias is not None, rowbias is not None, residual is not None)
+        ctx.bias_param = bias if (bias is not None and bias.requires_grad and bias.is_leaf) else None
         ctx.res_dtype = residual.dtype if residual is not None else None
         ctx.save_for_backward(x if weight.requires_grad else None)
         return y
@@ -261,7 +298,11 @@ class ConvFn(torch.autograd.Function):
             dwk = be.gemm(dyT, xcolT, out_dtype=f32)                       # [Cout, 9 * Cx]
             dw = dwk.view(wshape[0], 9, ctx.cin)[:, :, : wshape[1]].permute(0, 2, 1).reshape(wshape).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
-            db = ops.backend().colsum(dyb)
+            g = _grad_slot(ctx.bias_param) if ctx.bias_param is not None else None
+            if g is not None:
+                ops.backend().colsum(dyb, out=g, accumulate=True)
+            else:
+                db = ops.backend().colsum(dyb)
         if has_rb and ctx.needs_input_grad[3]:
             drb = torch.zeros((B, cout), dtype=f32, device=dy.device)
             be.spatial_mean(dyb, B, Hout * Wout, drb, 0)

@@ -22,6 +22,7 @@ import os
 import torch
 import torch.nn.functional as F
 
+from . import functional as Fn
 from . import ops
 
 f32 = torch.float32
@@ -269,7 +270,11 @@ class E4TTrainer:
         loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
         self._armed = True
         self._head_pending = getattr(self, "_head_last", 0)
-        loss.backward()
+        Fn.set_inplace_param_grads(True)     # weight / bias gradients accumulate straight into the flat buffer (functional.py)
+        try:
+            loss.backward()
+        finally:
+            Fn.set_inplace_param_grads(False)
         self._armed = False
         self.all_reduce_grads()
         self.clip_grad_norm()

@@ -115,3 +115,32 @@ def test_shared_prefix_is_result_preserving(emu_fp32):
     torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-6, atol=1e-8)
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-6, atol=1e-8)
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-4, atol=1e-7)
+
+
+def test_inplace_param_grads_match_autograd(emu_fp32):
+    """Tuning (every UNet weight trainable): weight / bias gradients accumulated by the producing kernels straight into the
+    trainer's flat buffer (functional.set_inplace_param_grads) must equal what autograd's AccumulateGrad produces."""
+    from e4t import functional as Fn
+    from e4t.trainer import E4TTrainer
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    pixels = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
+    latents = torch.randn(B, 4, 16, 16, generator=g) * 0.18215
+    noise = torch.randn(B, 4, 16, 16, generator=g)
+    t = torch.tensor([301, 44])
+    ids = torch.randint(1, 99, (B, 9), generator=g)
+    pidx = torch.tensor([3, 6])
+    res = []
+    for inplace in (False, True):
+        _, _, n_unet, n_enc, text = build()
+        tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long),
+                        device=torch.device("cpu"), tuning=True)
+        loss, _, _ = tr.losses(pixels, latents, noise, t, ids, pidx)
+        Fn.set_inplace_param_grads(inplace)
+        try:
+            loss.backward()
+        finally:
+            Fn.set_inplace_param_grads(False)
+        res.append(tr.flat.grad.detach().clone())
+        assert float(res[-1].abs().max()) > 0
+    torch.testing.assert_close(res[0], res[1], rtol=1e-4, atol=1e-7)
