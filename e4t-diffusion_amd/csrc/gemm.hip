@@ -875,6 +875,132 @@ extern "C" int e4t_debug_pp_trace(unsigned long long* out) {
 namespace {
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// TN variant: C[M, N] = alpha * A^T . B with A = [K][M], B = [K][N] row-major bf16 — the contraction runs over the ROWS.
+// This is the weight gradient dW = dY^T . X of every linear layer as the tensors lie in memory; the NT kernels above need
+// both operands transposed first (two extra passes over dY and X per weight gradient).
+//   * operand tiles are [64 k-rows][128 columns] (256-B rows), still moved by LDS-DMA, 4 rows per wave-instruction;
+//   * the MFMA fragments (lane = output row / column, 8 consecutive k) are gathered with gfx950's transposing LDS read
+//     ds_read_b64_tr_b16: within a 16-lane group, source lane i' supplies 4 contiguous elements and output lane i receives,
+//     in slot j, element (i % 4) of source lane 4j + i / 4 (probed on hardware: tools/probe/tr_probe.hip).  Pointing
+//     source lane i' at T[kbase + i'/4][n0 + 4 (i' % 4)] therefore hands lane i the column n0 + i of rows kbase .. kbase+3;
+//     two such reads (rows +0 and +4) make one bf16x8 operand;
+//   * bank conflicts: a 32-lane half reads 64 contiguous bytes from each of 4 consecutive rows; rows are 256 B apart = the
+//     same banks, so 32-byte unit u of row r is stored at unit u ^ (2 (r & 3)) (swizzle applied on the DMA source side).
+// 128 x 128 x 64 tile, 8 waves (wave tile 32 x 64), two LDS buffers, one barrier per K-tile, as the NT kernel.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* lds_lo, const bf16_t* lds_hi) {
+  union { s16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_lo);
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_hi);
+  return u.v;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
+  constexpr int BM = 128, BN = 128, WGN = 2, WM = 32, WN = 64, FN = 2;
+  constexpr int OPER = BK * 128;                 // elements per operand tile: 64 rows x 128 columns
+  constexpr int TILE = 2 * OPER;
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * TILE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  int tile_x, tile_y;
+  xcd_tile(tile_x, tile_y, p.group_m);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+
+  const int nkt = (p.K + BK - 1) / BK;
+  const int sz = blockIdx.z;                     // split index (no batching in this variant)
+  const int kt_begin = sz * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nkt) kt_end = nkt;
+
+  const bf16_t* const zero = (const bf16_t*)&g_zero16;
+  // DMA: piece q = 4 tile rows; wave w feeds pieces 2w, 2w+1 of each operand.  lane -> (row in piece, physical 16-B chunk)
+  const int prow = lane >> 4, pchunk = lane & 15;
+  const int lchunk = (((pchunk >> 1) ^ (2 * prow)) << 1) | (pchunk & 1);      // logical chunk stored at this physical slot
+  const bool a_col_ok = m0 + lchunk * 8 < p.M, b_col_ok = n0 + lchunk * 8 < p.N;
+  const bf16_t* a_ptr[2];
+  const bf16_t* b_ptr[2];
+  auto place = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kk = kt * BK + (wave * 2 + i) * 4 + prow;
+      a_ptr[i] = (a_col_ok && kk < p.K) ? p.A + (size_t)kk * p.lda + m0 + lchunk * 8 : zero;
+      b_ptr[i] = (b_col_ok && kk < p.K) ? p.B + (size_t)kk * p.ldb + n0 + lchunk * 8 : zero;
+    }
+  };
+  auto issue_tile = [&](int kt, bf16_t* buf) {
+    if (kt == kt_begin || (kt + 1) * BK > p.K) {
+      place(kt);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a_ptr[i] += (a_ptr[i] != zero) ? (size_t)BK * p.lda : 0;
+        b_ptr[i] += (b_ptr[i] != zero) ? (size_t)BK * p.ldb : 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(a_ptr[i], buf + (wave * 2 + i) * 512);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(b_ptr[i], buf + OPER + (wave * 2 + i) * 512);
+  };
+
+  f32x16 acc[1][FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+  // fragment gather addresses (elements) inside an operand tile for k-step 0, rows +0; +4 rows = +512, next k-step = +2048
+  const int g16 = lane >> 4, il = lane & 15;
+  const int frow = (g16 >> 1) * 8 + (il >> 2);
+  auto frag_off = [&](int col0) {                 // col0: first of the 32 tile columns of the MFMA block
+    const int col = col0 + 16 * (g16 & 1) + 4 * (il & 3);
+    const int unit = (col >> 4) ^ (2 * (il >> 2));
+    return frow * 128 + unit * 16 + (col & 15);
+  };
+  const int a_off = frag_off(wm * WM);
+  int b_off[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) b_off[j] = OPER + frag_off(wn * WN + j * 32);
+
+  if (kt_begin < kt_end) issue_tile(kt_begin, smem);
+  auto body = [&](auto CURc, int kt) {
+    constexpr int CUR = decltype(CURc)::value;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    const bf16_t* st = smem + CUR * TILE;
+    bf16x8 af[2], bfr[2][FN];
+    af[0] = tr_frag(st + a_off, st + a_off + 512);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bfr[0][j] = tr_frag(st + b_off[j], st + b_off[j] + 512);
+    if (kt + 1 < kt_end) issue_tile(kt + 1, smem + (CUR ^ 1) * TILE);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int c = ks & 1, n = c ^ 1;
+      if (ks + 1 < BK / 16) {
+        af[n] = tr_frag(st + a_off + (ks + 1) * 2048, st + a_off + (ks + 1) * 2048 + 512);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bfr[n][j] = tr_frag(st + b_off[j] + (ks + 1) * 2048, st + b_off[j] + (ks + 1) * 2048 + 512);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[c], bfr[c][j], acc[0][j], 0, 0, 0);
+    }
+  };
+  {
+    int kt = kt_begin;
+    for (; kt + 2 <= kt_end; kt += 2) {
+      body(std::integral_constant<int, 0>{}, kt);
+      body(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (kt < kt_end) body(std::integral_constant<int, 0>{}, kt);
+  }
+  __syncthreads();
+  write_tile<WM, WN, 1, FN>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
+}
+
 // sums `nz` consecutive partial slabs starting at slab blockIdx.y*nz, then runs the epilogue for batch entry blockIdx.y
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p, int nz) {
   const size_t total = (size_t)p.M * p.N;
@@ -1021,6 +1147,54 @@ extern "C" int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream) {
   p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.strideBias = d->strideBias;
   p.reduce_batch = (d->flags & E4T_REDUCE_BATCH) ? 1 : 0;
   return launch_gemm(p, false, d->tile, d->workspace_bytes, d->splitk, batch, (hipStream_t)stream);
+}
+
+extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
+  E4T_REQUIRE(d && d->A && d->B && d->C, "gemm_tn: null operand");
+  E4T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch <= 1 && !d->A2 && !d->rowbias, "gemm_tn: bad / unsupported arguments");
+  E4T_REQUIRE(d->M % 8 == 0 && d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && ((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0,
+              "gemm_tn: M, N, lda, ldb must be multiples of 8 and the operands 16-byte aligned");
+  GemmArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16_t*)d->A; p.lda = d->lda; p.B = (const bf16_t*)d->B; p.ldb = d->ldb;
+  p.C = d->C; p.ldc = d->ldc; p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.K1 = d->K; p.alpha = d->alpha; p.flags = d->flags & ~E4T_REDUCE_BATCH;
+  p.rows_per_batch = 1; p.ldrb = d->N;
+  p.ws = (float*)d->workspace;
+  const int nkt = cdiv(p.K, BK), gx = cdiv(p.N, 128), gy = cdiv(p.M, 128);
+  const long long tiles = (long long)gx * gy;
+  int splitk = d->splitk;
+  if (splitk <= 0) {      // weight gradients: few output tiles, very long K -> fill the 512 workgroup slots by splitting K
+    splitk = (int)(512 / tiles);
+    if (splitk > 32) splitk = 32;
+    if (splitk > nkt / 16) splitk = nkt / 16;
+    if (splitk < 1) splitk = 1;
+  }
+  if (splitk > nkt) splitk = nkt;
+  p.ktiles_per_split = cdiv(nkt, splitk);
+  splitk = cdiv(nkt, p.ktiles_per_split);
+  const size_t need = (size_t)splitk * p.M * p.N * sizeof(float);
+  if (splitk > 1 && (p.ws == nullptr || d->workspace_bytes < need)) {
+    if (d->splitk > 1) E4T_FAIL(-12, "gemm_tn: split-K=%d needs %zu workspace bytes, have %zu", splitk, need, d->workspace_bytes);
+    splitk = 1;
+    p.ktiles_per_split = nkt;
+  }
+  if (splitk <= 1) p.ws = nullptr;
+  p.splitk = splitk;
+  p.group_m = 8;
+  p.fast_epi = !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
+               (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, splitk), dim3(512), 0, st, p);
+  E4T_CHECK_LAUNCH("gemm_tn_kernel");
+  if (p.ws) {
+    const size_t total = (size_t)p.M * p.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, p, splitk);
+    E4T_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
+  return 0;
 }
 
 extern "C" int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream) {

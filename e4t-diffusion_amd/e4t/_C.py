@@ -50,6 +50,7 @@ SIGNATURES = {
     "e4t_last_error": (C.c_char_p, []),
     "e4t_device_info": (i32, [C.c_char_p, i32, C.POINTER(i32)]),
     "e4t_gemm_nt": (i32, [C.POINTER(GemmDesc), vp]),
+    "e4t_gemm_tn": (i32, [C.POINTER(GemmDesc), vp]),
     "e4t_conv3x3": (i32, [C.POINTER(ConvDesc), vp]),
     "e4t_attention_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp]),
     "e4t_attention_bwd": (i32, [vp] * 10 + [i32] * 9 + [i64] * 4 + [f32, vp]),

@@ -75,17 +75,18 @@ def _pad8(n):
 
 
 def _weight_grad(dy, x, x2=None, out=None):
-    """dW[N, K] = dy^T . x  (fp32) via two transposes + one NT GEMM whose contraction runs over the rows.
+    """dW[N, K] = dy^T . x  (fp32): the TN GEMM contracts over the rows of both operands as they lie in memory (no transposes).
     out: fp32 [N, K] to ACCUMULATE into (a parameter's .grad) instead of returning a fresh tensor."""
     be = ops.backend()
-    M = dy.shape[0]
-    dyT = be.transpose(dy, pad_to=_pad8(M))
-    xT = be.transpose(x, pad_to=_pad8(M))
-    if x2 is not None:
-        xT = torch.cat([xT, be.transpose(x2, pad_to=_pad8(M))], dim=0)
-    if out is not None:
-        return be.gemm(dyT, xT, out=out, accum=True)
-    return be.gemm(dyT, xT, out_dtype=f32)
+    if x2 is None:
+        if out is not None:
+            return be.gemm_tn(dy, x, out=out, accum=True)
+        return be.gemm_tn(dy, x, out_dtype=f32)
+    k1 = x.shape[1]
+    res = out if out is not None else torch.empty((dy.shape[1], k1 + x2.shape[1]), dtype=f32, device=dy.device)
+    be.gemm_tn(dy, x, out=res[:, :k1], accum=out is not None)          # fused-concat source 1 -> columns [0, k1)
+    be.gemm_tn(dy, x2, out=res[:, k1:], accum=out is not None)         # source 2 -> columns [k1, K)
+    return res
 
 
 # Gradient accumulation without autograd's AccumulateGrad: when a trainer has installed persistent fp32 .grad storage
@@ -205,10 +206,7 @@ class WOLinearFn(torch.autograd.Function):
         slot = ctx.slot
         dy = dy.contiguous()
         dx = be.gemm(dy, slot.weffT) if ctx.needs_input_grad[0] else None
-        M = dy.shape[0]
-        dyT = be.transpose(dy, pad_to=_pad8(M))
-        xT = be.transpose(x, pad_to=_pad8(M))
-        be.gemm(dyT, xT, out=slot.dweff, accum=slot.dweff_valid)
+        be.gemm_tn(dy, x, out=slot.dweff, accum=slot.dweff_valid)        # dW_eff (+)= dy^T . x
         slot.dweff_valid = True
         return dx, torch.zeros_like(ctx.saved_tensors[0][:1, :1], dtype=f32).reshape(1) if False else _zero_token(dy.device), None
 

@@ -208,6 +208,31 @@ class HipBackend:
                     lambda: _C.check(self.lib.e4t_gemm_nt(C.byref(d), st), "e4t_gemm_nt"))
         return out
 
+    def gemm_tn(self, a, b, *, out=None, out_dtype=f32, accum=False, alpha=1.0, splitk=0):
+        """C[M, N] = alpha * a^T . b with a = [K, M], b = [K, N] (bf16, unit inner stride): contraction over the rows —
+        dW = dY^T . X without transposes."""
+        _rowmajor(a, "gemm_tn A"); _rowmajor(b, "gemm_tn B")
+        K, M = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == K
+        if out is None:
+            out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+        _rowmajor(out, "gemm_tn C")
+        d = _C.GemmDesc()
+        d.A, d.B, d.C = _ptr(a), _ptr(b), _ptr(out)
+        d.M, d.N, d.K, d.K1 = M, N, K, K
+        d.lda, d.ldb, d.ldc = a.stride(0), b.stride(0), out.stride(0)
+        flags = (_C.OUT_F32 if out.dtype == f32 else 0) | (_C.ACCUM if accum else 0)
+        d.flags, d.splitk, d.batch, d.alpha = flags, splitk, 1, alpha
+        cd = lambda x, y: (x + y - 1) // y
+        nkt, tiles = cd(K, 64), cd(M, 128) * cd(N, 128)
+        sk = splitk if splitk > 0 else max(1, min(512 // tiles, 32, nkt // 16))
+        ws = self.workspace(4 * sk * M * N, a.device) if sk > 1 else None
+        d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
+        st = _stream()
+        self._timed("gemm_tn", 2.0 * M * N * K, lambda: _C.check(self.lib.e4t_gemm_tn(C.byref(d), st), "e4t_gemm_tn"))
+        return out
+
     # ------------------------------------------------------------------ conv
     def conv3x3(self, x, w, B, Hin, Win, Hout, Wout, mode, *, bias=None, residual=None, rowbias=None, out=None,
                 out_dtype=bf16, accum=False, tile=0, splitk=0):

@@ -64,6 +64,11 @@ typedef struct {
   int ldrb;            /* row stride of rowbias (elements); 0 = N */
 } e4t_gemm_desc;
 int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream);
+/* C[M,N] = epi(alpha * A^T . B) with A = bf16 [K][lda >= M], B = bf16 [K][ldb >= N]: the contraction runs over the ROWS of both
+ * operands — the weight gradient dW = dY^T . X of every linear layer (autograd of cross_attention.py:506-518, attention.py:376,419,
+ * ...) without transposing dY and X first.  Same descriptor; A2 / rowbias / batch are not supported; split-K is automatic
+ * (workspace >= splitk * M * N * 4 bytes, falls back to one pass when it is smaller). */
+int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream);
 
 /* 3x3 convolution, pad 1, NHWC, implicit GEMM (no im2col buffer).
  * Replaces [3P diffusers 0.14] ResnetBlock2D.conv1/conv2, Downsample2D.conv (stride 2),

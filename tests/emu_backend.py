@@ -85,6 +85,13 @@ class EmuBackend:
             wd = self._act(t.reshape(I, 9 * Opad))
         return wf, wd
 
+    def gemm_tn(self, a, b, *, out=None, out_dtype=f32, accum=False, alpha=1.0, splitk=0):
+        y = alpha * (a.float().t() @ b.float())
+        if out is None:
+            return y if out_dtype == f32 else self._act(y)
+        out.copy_((out.float() + y if accum else y).to(out.dtype))
+        return out
+
     def conv3x3(self, x, w, B, Hin, Win, Hout, Wout, mode, *, bias=None, residual=None, rowbias=None, out=None,
                 out_dtype=bf16, accum=False, tile=0, splitk=0):
         Cin, Cout = x.shape[-1], w.shape[0]

@@ -63,6 +63,20 @@ def check_gemm(hip, emu, dev):
         y = hip.gemm(a, b, bias=bias, residual=res, tile=tile, splitk=sk)
         yr = emu.gemm(a, b, bias=bias, residual=res)
         out.append((f"gemm {M}x{N}x{K} t{tile} s{sk} bias+res", rel(y, yr), TOL1))
+    # TN: contraction over the rows (weight gradients)
+    for i, (K, M, N, sk) in enumerate([(64, 128, 128, 1), (1000, 320, 320, 0), (4096, 960, 320, 0), (777, 200, 72, 3), (65536, 320, 320, 0),
+                                       (1232, 2560, 768, 0), (130, 8, 1280, 1)]):
+        g = gen(40 + i, dev)
+        a, b = rnd(g, K, M + 8, dev=dev)[:, :M], rnd(g, K, N, scale=K ** -0.5, dev=dev)
+        out.append((f"gemm_tn K{K} M{M} N{N} s{sk}", rel(hip.gemm_tn(a, b, splitk=sk), emu.gemm_tn(a, b)), TOLF * 50))
+    g = gen(48, dev)
+    a, b = rnd(g, 500, 320, dev=dev), rnd(g, 500, 328, scale=0.05, dev=dev)
+    c1 = rnd(g, 320, 328, dtype=f32, dev=dev); c2 = c1.clone()
+    hip.gemm_tn(a, b, out=c1, accum=True); emu.gemm_tn(a, b, out=c2, accum=True)
+    out.append(("gemm_tn fp32 accumulate", rel(c1, c2), TOLF * 50))
+    wide = torch.zeros(320, 700, dtype=f32, device=dev); wide2 = wide.clone()
+    hip.gemm_tn(a, b, out=wide[:, 100:428]); emu.gemm_tn(a, b, out=wide2[:, 100:428])
+    out.append(("gemm_tn into a column slice", rel(wide, wide2), TOLF * 50))
     g = gen(30, dev)
     # two-source A, gelu, fp32 out, accumulate, rowbias
     M, N, K1, K2 = 384, 192, 128, 64
