@@ -496,6 +496,46 @@ __global__ __launch_bounds__(256) void im2col_T_kernel(const bf16_t* x, bf16_t* 
 }
 }  // namespace
 
+// ---- plain im2col for the same weight gradients through the TN GEMM (no transposes at all): out[m][tap*C + c] ----
+namespace {
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* x, bf16_t* out, int Hin, int Win, int C, int Hout, int Wout,
+                                                     long long Mpix, int mode) {
+  const int cpr = C >> 3;                                     // 16-byte chunks per (pixel, tap)
+  const long long total = Mpix * 9 * cpr;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int ch = (int)(idx % cpr);
+    const long long t = idx / cpr;
+    const int tap = (int)(t % 9);
+    const long long m = t / 9;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int hw = Hout * Wout;
+    const int b = (int)(m / hw);
+    const int rem = (int)(m - (long long)b * hw);
+    const int oy = rem / Wout, ox = rem - oy * Wout;
+    int iy, ix;
+    bool ok;
+    if (mode == E4T_CONV_S1) { iy = oy + ky - 1; ix = ox + kx - 1; ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win; }
+    else if (mode == E4T_CONV_S2) { iy = 2 * oy + ky - 1; ix = 2 * ox + kx - 1; ok = iy >= 0 && iy < Hin && ix >= 0 && ix < Win; }
+    else { iy = oy + ky - 1; ix = ox + kx - 1; ok = iy >= 0 && iy < 2 * Hin && ix >= 0 && ix < 2 * Win; iy >>= 1; ix >>= 1; }
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ok) v = *(const uint4*)(x + (((long long)b * Hin + iy) * Win + ix) * C + ch * 8);
+    *(uint4*)(out + (m * 9 + tap) * C + ch * 8) = v;
+  }
+}
+}  // namespace
+
+extern "C" int e4t_im2col(const void* x, void* out, int Bn, int Hin, int Win, int C, int Hout, int Wout, int mode, e4t_stream s) {
+  E4T_REQUIRE(x && out && Bn > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && C % 8 == 0, "im2col: bad arguments (C must be a multiple of 8)");
+  E4T_REQUIRE(mode == E4T_CONV_S1 || mode == E4T_CONV_S2 || mode == E4T_CONV_UP2, "im2col: mode must be S1, S2 or UP2");
+  const long long Mpix = (long long)Bn * Hout * Wout;
+  long long blocks = (Mpix * 9 * (C / 8) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)out, Hin, Win, C, Hout, Wout,
+                     Mpix, mode);
+  E4T_CHECK_LAUNCH("im2col_kernel");
+  return 0;
+}
+
 extern "C" int e4t_im2col_T(const void* x, void* out, int Bn, int Hin, int Win, int C, int Hout, int Wout, int ldo, int mode, e4t_stream s) {
   E4T_REQUIRE(x && out && Bn > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "im2col_T: bad arguments");
   E4T_REQUIRE(C % 4 == 0 && ldo % 4 == 0 && (long long)ldo >= (long long)Bn * Hout * Wout, "im2col_T: C, ldo must be multiples of 4, ldo >= B*Hout*Wout");

@@ -287,13 +287,15 @@ class ConvFn(torch.autograd.Function):
                 dx = dx[:, : ctx.cin].contiguous()
         dw = None
         if ctx.needs_input_grad[1]:
-            # dW[co][tap][ci] = sum_pixels dY[m][co] * X[src(m, tap)][ci]: gather-transpose of X, transpose of dY, one
-            # split-K NT GEMM contracting over the pixels (tuning mode only; pre-training freezes these weights)
+            # dW[co][tap][ci] = sum_pixels dY[m][co] * X[src(m, tap)][ci]: im2col of X, then one split-K TN GEMM contracting
+            # over the pixels (tuning mode only; pre-training freezes these weights)
             (x,) = ctx.saved_tensors
             wshape = ctx.prep.weight.shape
-            xcolT = be.im2col_T(x, B, Hin, Win, Hout, Wout, ctx.mode)
-            dyT = be.transpose(dyb, pad_to=xcolT.shape[1])
-            dwk = be.gemm(dyT, xcolT, out_dtype=f32)                       # [Cout, 9 * Cx]
+            if cout % 8 == 0 and x.shape[1] % 8 == 0:
+                dwk = be.gemm_tn(dyb, be.im2col(x, B, Hin, Win, Hout, Wout, ctx.mode), out_dtype=f32)    # [Cout, 9 * Cx], no transposes
+            else:       # conv_out (4 output channels): the transposed route pads the row count instead
+                xcolT = be.im2col_T(x, B, Hin, Win, Hout, Wout, ctx.mode)
+                dwk = be.gemm(be.transpose(dyb, pad_to=xcolT.shape[1]), xcolT, out_dtype=f32)
             dw = dwk.view(wshape[0], 9, ctx.cin)[:, :, : wshape[1]].permute(0, 2, 1).reshape(wshape).contiguous()
         if has_bias and ctx.needs_input_grad[2]:
             g = _grad_slot(ctx.bias_param) if ctx.bias_param is not None else None

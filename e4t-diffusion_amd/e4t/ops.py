@@ -451,6 +451,14 @@ class HipBackend:
         _C.check(self.lib.e4t_im2col_T(_ptr(x), _ptr(out), B, Hin, Win, Cn, Hout, Wout, ld, mode, _stream()), "e4t_im2col_T")
         return out
 
+    def im2col(self, x, B, Hin, Win, Hout, Wout, mode):
+        """bf16 [B*Hin*Win, C] -> [B*Hout*Wout, 9*C] (tap-major columns): B operand of the TN weight-gradient GEMM"""
+        assert x.is_contiguous() and x.shape[1] % 8 == 0
+        Cn = x.shape[1]
+        out = torch.empty((B * Hout * Wout, 9 * Cn), dtype=bf16, device=x.device)
+        _C.check(self.lib.e4t_im2col(_ptr(x), _ptr(out), B, Hin, Win, Cn, Hout, Wout, mode, _stream()), "e4t_im2col")
+        return out
+
     def softmax_rows_(self, x):
         """in-place softmax over the last dim of a bf16 matrix [..., L] with contiguous rows"""
         L = x.shape[-1]

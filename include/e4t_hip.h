@@ -197,6 +197,8 @@ int e4t_softmax_rows(void* x, long long rows, int L, int ld, e4t_stream stream);
 int e4t_im2col3_rgb(const float* pixels_nchw, void* out, int B, int H, int W, e4t_stream stream);
 /* out[(tap*C + c)][m] = gathered X (3x3 taps, zero outside), m over OUTPUT pixels: B operand of the conv weight-gradient GEMM */
 int e4t_im2col_T(const void* x, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int ldo, int mode, e4t_stream stream);
+/* out[m][tap*C + c] (bf16 [B*Hout*Wout][9*C]): with e4t_gemm_tn, dW[co][tap][ci] = dY^T . im2col(X) needs no transposes. */
+int e4t_im2col(const void* x, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int mode, e4t_stream stream);
 int e4t_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int step, float grad_scale, e4t_stream stream);                                        /* pretrain_e4t.py:387-392,652 */
 int e4t_sumsq_partial(const float* g, long long n, float* partial, int nblocks, e4t_stream stream);                      /* tuning_e4t.py:335 grad-norm */

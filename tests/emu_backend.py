@@ -317,6 +317,10 @@ class EmuBackend:
         out[:, : B * Hout * Wout] = cols
         return self._act(out)
 
+    def im2col(self, x, B, Hin, Win, Hout, Wout, mode):
+        t = self.im2col_T(x, B, Hin, Win, Hout, Wout, mode)
+        return t[:, : B * Hout * Wout].t().contiguous()
+
     def softmax_rows_(self, x):
         x.copy_(torch.softmax(x.float(), dim=-1).to(x.dtype))
         return x

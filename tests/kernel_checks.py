@@ -278,6 +278,7 @@ def check_streaming(hip, emu, dev):
     for mode, (Bn, Hin, Hout) in ((1, (2, 12, 12)), (2, (3, 9, 5)), (3, (2, 6, 12))):
         xi = rnd(g, Bn * Hin * Hin, 72, dev=dev)
         out.append((f"im2col_T mode{mode}", rel(hip.im2col_T(xi, Bn, Hin, Hin, Hout, Hout, mode), emu.im2col_T(xi, Bn, Hin, Hin, Hout, Hout, mode)), 0.0))
+        out.append((f"im2col mode{mode}", rel(hip.im2col(xi, Bn, Hin, Hin, Hout, Hout, mode), emu.im2col(xi, Bn, Hin, Hin, Hout, Hout, mode)), 0.0))
     sc = rnd(g, 3, 100, 4096, scale=2.0, dev=dev)
     out.append(("softmax_rows 4096", rel(hip.softmax_rows_(sc.clone()), emu.softmax_rows_(sc.clone())), TOL1))
     sc = rnd(g, 77, 64, scale=3.0, dev=dev)
