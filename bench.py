@@ -167,8 +167,23 @@ def main():
                  "conv64": "gemm_dma_kernel<64,64,2,2,conv,2> (implicit-GEMM 3x3 conv)",
                  "gemm128": "gemm_dma_kernel<128,128,4,2,dense,2>", "gemm160": "gemm_dma_kernel<128,160,4,1,dense,2>",
                  "gemm64": "gemm_dma_kernel<64,64,2,2,dense,2>",
-                 "conv512": "gemm_pp_kernel<conv> (256x256 ping-pong implicit-GEMM 3x3 conv)", "gemm512": "gemm_pp_kernel<dense> (256x256 ping-pong)"}
-        roof = dict(bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / sec / MFMA_PEAK, traffic=None,
+                 "conv512": "gemm_pp_kernel<conv> (256x256 ping-pong implicit-GEMM 3x3 conv)", "gemm512": "gemm_pp_kernel<dense> (256x256 ping-pong)",
+                 "gemm_tn": "gemm_tn_kernel (weight gradients, contraction over rows)"}
+        # HBM bytes per launch of that kernel symbol from the TCC counters: collected offline with tools/pmc_traffic.sh on this
+        # very command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 as
+        # MI355X_MICROARCH.md prescribes; check: adamw_kernel comes out at 10.49 GB = 28 B x 374.5 M parameters)
+        traffic = None
+        sym = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, 2>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, 2>",
+               "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2>", "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, 2>",
+               "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, 2>", "conv512": "gemm_pp_kernel<1>", "gemm512": "gemm_pp_kernel<0>",
+               "gemm_tn": "gemm_tn_kernel"}.get(dom)
+        csv_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.csv")
+        if sym and os.path.exists(csv_path) and args.model == "sd14" and args.batch == 16:
+            for line in open(csv_path).read().splitlines()[1:]:
+                parts = line.rsplit(",", 4)
+                if parts[0] == sym:
+                    traffic = float(parts[4])
+        roof = dict(bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / sec / MFMA_PEAK, traffic=traffic,
                     kernel=names.get(dom, dom), launches_per_step=n, avg_launch_ms=sec / n * 1e3,
                     per_kernel={k: dict(tflops=v[0] / v[1] / 1e12, ms_per_step=v[1] * 1e3, launches=v[2]) for k, v in sorted(agg.items())},
                     step_mfma_frac_necessary=ips * HOT_FLOP_PER_IMAGE[args.model] / (world * MFMA_PEAK),
