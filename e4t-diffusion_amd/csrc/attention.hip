@@ -12,10 +12,12 @@
 //   forward, one wave = 32 queries:   S^T[key][q] = K . Q^T   (A = K tile from LDS, B = Q in registers)
 //     -> every lane owns ONE query column (q = lane & 31) and 16 of the 32 keys in registers, so the
 //        row max / row sum are 16 in-register ops + one cross-half exchange, and m, l are per-lane scalars;
-//     O^T[d][q] += V^T . P^T   (A = V^T tile from LDS, B = P^T straight from the S^T accumulator registers)
+//     O^T[d][q] += V^T . P^T   (A = V^T gathered from the ROW-MAJOR V tile in LDS with the transposing read
+//        ds_read_b64_tr_b16, B = P^T straight from the S^T accumulator registers)
 //     -> the S^T accumulator layout IS the B-operand layout once the 32 keys of a sub-tile are
-//        enumerated in the order the accumulator holds them; V^T is read from LDS in that same order,
-//        so P never goes through LDS or a cross-lane shuffle.  O^T keeps q in the lane: rescale is a scalar.
+//        enumerated in the order the accumulator holds them ({4hi..4hi+3} u {4hi+8..4hi+11} per k-step): two
+//        4-row gathers supply V^T in exactly that order, so P never goes through LDS or a cross-lane shuffle
+//        and no transposed image of V is ever written.  O^T keeps q in the lane: rescale is a scalar.
 //   backward dQ: same skeleton (dQ^T[d][q] += K^T . dS^T).
 //   backward dK/dV, one wave = 32 keys: S[q][key] = Q . K^T (key in the lane), dV^T[d][key] += dO^T . P,
 //     dK^T[d][key] += Q^T . dS.   Two kernels (dQ | dK,dV) -> no atomics, bitwise deterministic.
@@ -49,8 +51,10 @@ struct Cfg {
   static constexpr int DV = (DH + 31) / 32 * 32;  // row-tile padding for the transposed accumulators
   static constexpr int NKS = DK / 16;
   static constexpr int NDT = DV / 32;
-  static constexpr int KLD = DK + 8;   // LDS row stride (elements) of row-major tiles: 16-B aligned, conflict-free b128
-  static constexpr int TLD = 64 + 8;   // LDS row stride of transposed tiles [d][64 rows]: 144 B, conflict-free b128
+  // LDS images are row-major [64 rows][LDE] with 256-B (DH = 160: 512-B) rows; the 16-B slot L of row r lives at slot
+  // (((L>>2) ^ (r&3)) << 2) | ((L&3) ^ ((r>>2)&3)): conflict-free both for the row-major ds_read_b128 fragments (lane
+  // groups {0-3,12-15,20-27} / {4-11,16-19,28-31}) and for the transposing 4-row x 64-B gathers (no single padded stride is).
+  static constexpr int LDE = DH <= 128 ? 128 : 256;
   static constexpr int NCH = DH / 8;   // 16-byte chunks per source row
   static constexpr int NIT = (32 * NCH + 255) / 256;   // (row pair, chunk) items per thread per 64-row tile
 };
@@ -64,12 +68,10 @@ union Frag {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// Column permutation of transposed tiles: inside every 16-column block the 4-groups [4,8) and [8,12) are swapped,
-// so that the 8 rows a 32x32 accumulator half holds for one MFMA k-step ({4hi..4hi+3} u {4hi+8..4hi+11}) sit in
-// 8 CONSECUTIVE columns -> one ds_read_b128 per A fragment.
-__device__ __forceinline__ int tcol(int c) {
-  const int j = c & 15;
-  return (c & ~15) | ((j >= 4 && j < 12) ? (j ^ 12) : j);     // 4..7 <-> 8..11
+// element offset of the logical 16-byte slot L of tile row r in a swizzled LDS image (see Cfg)
+template <int LDE>
+__device__ __forceinline__ int img_off(int r, int L) {
+  return r * LDE + (((((L >> 2) ^ (r & 3)) << 2) | ((L & 3) ^ ((r >> 2) & 3))) << 3);
 }
 
 // One 64-row x DH tile of a row-major global matrix, held in registers between its global load and its LDS
@@ -94,45 +96,27 @@ struct TileRegs {
       }
     }
   }
-  // row-major image lds[64][KLD]
+  // swizzled row-major image lds[64][LDE]
   __device__ __forceinline__ void store_rows(bf16_t* lds) const {
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
       const int item = threadIdx.x + it * 256;
       const int ch = item >> 5, kp = item & 31;
       if (item < 32 * C::NCH) {
-        *(uint4*)(lds + (2 * kp) * C::KLD + ch * 8) = v[it][0];
-        *(uint4*)(lds + (2 * kp + 1) * C::KLD + ch * 8) = v[it][1];
-      }
-    }
-  }
-  // transposed image ldsT[d][TLD], column = tcol(row - r0)
-  __device__ __forceinline__ void store_T(bf16_t* ldsT) const {
-#pragma unroll
-    for (int it = 0; it < C::NIT; ++it) {
-      const int item = threadIdx.x + it * 256;
-      const int ch = item >> 5, kp = item & 31;
-      if (item < 32 * C::NCH) {
-        const uint32_t a[4] = {v[it][0].x, v[it][0].y, v[it][0].z, v[it][0].w};
-        const uint32_t b[4] = {v[it][1].x, v[it][1].y, v[it][1].z, v[it][1].w};
-        const int col = tcol(2 * kp);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          *(uint32_t*)(ldsT + (ch * 8 + 2 * j) * C::TLD + col) = (a[j] & 0xffffu) | (b[j] << 16);
-          *(uint32_t*)(ldsT + (ch * 8 + 2 * j + 1) * C::TLD + col) = (a[j] >> 16) | (b[j] & 0xffff0000u);
-        }
+        *(uint4*)(lds + img_off<C::LDE>(2 * kp, ch)) = v[it][0];
+        *(uint4*)(lds + img_off<C::LDE>(2 * kp + 1, ch)) = v[it][1];
       }
     }
   }
 };
 
-// the zero pad columns [DH, DK) of a row-major LDS tile are written once (the tile stores never touch them)
+// the zero pad slots [DH, DK) of an LDS image are written once (the tile stores never touch them)
 template <int DH>
 __device__ __forceinline__ void zero_pad_cols(bf16_t* lds) {
   constexpr int PADC = (Cfg<DH>::DK - DH) / 8;
   if (PADC > 0)
     for (int i = threadIdx.x; i < 64 * PADC; i += 256)
-      *(uint4*)(lds + (i / PADC) * Cfg<DH>::KLD + DH + (i % PADC) * 8) = make_uint4(0, 0, 0, 0);
+      *(uint4*)(lds + img_off<Cfg<DH>::LDE>(i / PADC, Cfg<DH>::NCH + i % PADC)) = make_uint4(0, 0, 0, 0);
 }
 
 // B-operand fragments of a row held in registers: 8 consecutive d starting at ks*16 + hi*8 (zero beyond DH / R)
@@ -148,10 +132,36 @@ __device__ __forceinline__ void load_row_frags(const bf16_t* g, int ld, int row,
   }
 }
 
-// A-operand from a transposed tile: row d, the 8 slots of MFMA k-step k2 of 32-row sub-tile `sub`
-// (= the order the 32x32 accumulator holds its rows; contiguous thanks to tcol())
-__device__ __forceinline__ bf16x8 load_T_frag(const bf16_t* ldsT, int TLD, int d, int sub, int k2, int hi) {
-  return *(const bf16x8*)(ldsT + d * TLD + sub * 32 + k2 * 16 + 8 * hi);
+// Per-lane fragment offsets into a swizzled image (elements; add (32 sub + 16 k2) * LDE for the sub-tile / k-step):
+//   row[ks]      row-major A operand: tile row = lane & 31, the 16-B slot of MFMA k-step ks
+//   tr_lo/hi[dt] transposed A operand (rows d = 32 dt + (lane & 31), 8 k-slots = tile rows {4hi..4hi+3} u {4hi+8..4hi+11}):
+//                source address of this lane for the two ds_read_b64_tr_b16 gathers (source lane i' of a 16-lane group
+//                supplies 4 contiguous elements of row (i' >> 2) at column 16 (group & 1) + 4 (i' & 3); output lane i
+//                receives column i of those 4 rows — probed on hardware, tools/probe/tr_probe.hip)
+template <int DH>
+struct FragOff {
+  using C = Cfg<DH>;
+  int row[C::NKS], tr_lo[C::NDT], tr_hi[C::NDT];
+  __device__ __forceinline__ FragOff() {
+    const int lane = threadIdx.x & 63, li = lane & 31, hi = lane >> 5, il = lane & 15, d16 = (lane >> 4) & 1;
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) row[ks] = img_off<C::LDE>(li, ks * 2 + hi);
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) {
+      const int L = dt * 4 + 2 * d16 + ((il & 3) >> 1), r = 4 * hi + (il >> 2);
+      tr_lo[dt] = img_off<C::LDE>(r, L) + 4 * (il & 1);
+      tr_hi[dt] = img_off<C::LDE>(r + 8, L) + 4 * (il & 1);
+    }
+  }
+};
+template <int DH>
+__device__ __forceinline__ bf16x8 load_row_frag(const bf16_t* img, const FragOff<DH>& f, int sub, int ks) {
+  return *(const bf16x8*)(img + sub * 32 * Cfg<DH>::LDE + f.row[ks]);
+}
+template <int DH>
+__device__ __forceinline__ bf16x8 load_T_frag(const bf16_t* img, const FragOff<DH>& f, int dt, int sub, int k2) {
+  const bf16_t* b = img + (sub * 32 + k2 * 16) * Cfg<DH>::LDE;
+  return tr_frag(b + f.tr_lo[dt], b + f.tr_hi[dt]);
 }
 // accumulator registers [8*k2, 8*k2+8) -> bf16 B-operand
 __device__ __forceinline__ bf16x8 pack_acc(const float* p, int k2) {
@@ -186,8 +196,9 @@ __device__ __forceinline__ void store_T_acc(const f32x16* acc, float mul, bf16_t
 template <int DH>
 __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
   using C = Cfg<DH>;
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[C::DV * C::TLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::LDE];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * C::LDE];
+  const FragOff<DH> fo;
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, hi = lane >> 5;
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
   for (int kv0 = 0; kv0 < p.S; kv0 += 64) {
     __syncthreads();                       // everyone finished reading the previous tile
     kr.store_rows(Ks);
-    vr.store_T(Vt);
+    vr.store_rows(Vs);
     __syncthreads();
     if (kv0 + 64 < p.S) {                  // next tile's loads fly under this tile's MFMAs
       kr.load(Kb, p.ldk, kv0 + 64, p.S);
@@ -226,8 +237,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::NKS; ++ks) {
-        const bf16x8 a = *(const bf16x8*)(Ks + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(Ks, fo, sub, ks), qf[ks], s, 0, 0, 0);
       }
       float pr[16];
       float mx = -INFINITY;
@@ -261,8 +271,8 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
       const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);
 #pragma unroll
       for (int dt = 0; dt < C::NDT; ++dt) {
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Vt, C::TLD, dt * 32 + li, sub, 0, hi), pf0, o[dt], 0, 0, 0);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Vt, C::TLD, dt * 32 + li, sub, 1, hi), pf1, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Vs, fo, dt, sub, 0), pf0, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Vs, fo, dt, sub, 1), pf1, o[dt], 0, 0, 0);
       }
     }
   }
@@ -300,9 +310,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p, int Bn) {
 template <int DH>
 __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(AttnArgs p) {
   using C = Cfg<DH>;
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * C::KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Kt[C::DV * C::TLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::LDE];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * C::LDE];
+  const FragOff<DH> fo;
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, hi = lane >> 5;
@@ -330,7 +340,6 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
   for (int kv0 = 0; kv0 < p.S; kv0 += 64) {
     __syncthreads();
     kr.store_rows(Ks);
-    kr.store_T(Kt);
     vr.store_rows(Vs);
     __syncthreads();
     if (kv0 + 64 < p.S) {
@@ -344,10 +353,8 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < C::NKS; ++ks) {
-        const bf16x8 a = *(const bf16x8*)(Ks + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
-        const bf16x8 a2 = *(const bf16x8*)(Vs + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dof[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(Ks, fo, sub, ks), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(Vs, fo, sub, ks), dof[ks], dp, 0, 0, 0);
       }
       float ds[16];
       if (kv0 + 64 > p.S) {                // ragged last tile only
@@ -364,8 +371,8 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
       const bf16x8 f0 = pack_acc(ds, 0), f1 = pack_acc(ds, 1);
 #pragma unroll
       for (int dt = 0; dt < C::NDT; ++dt) {
-        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Kt, C::TLD, dt * 32 + li, sub, 0, hi), f0, acc[dt], 0, 0, 0);
-        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Kt, C::TLD, dt * 32 + li, sub, 1, hi), f1, acc[dt], 0, 0, 0);
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Ks, fo, dt, sub, 0), f0, acc[dt], 0, 0, 0);
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Ks, fo, dt, sub, 1), f1, acc[dt], 0, 0, 0);
       }
     }
   }
@@ -378,10 +385,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
 template <int DH>
 __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
   using C = Cfg<DH>;
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * C::KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * C::KLD];
-  __shared__ __attribute__((aligned(16))) bf16_t Qt[C::DV * C::TLD];
-  __shared__ __attribute__((aligned(16))) bf16_t dOt[C::DV * C::TLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * C::LDE];
+  __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * C::LDE];
+  const FragOff<DH> fo;
   __shared__ __attribute__((aligned(16))) float Ls[64], Dls[64];
   const int b = blockIdx.z, h = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -425,9 +431,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_
     }
     __syncthreads();
     qr.store_rows(Qs);
-    qr.store_T(Qt);
     dor.store_rows(dOs);
-    dor.store_T(dOt);
     if (threadIdx.x < 64) { Ls[threadIdx.x] = l_next; Dls[threadIdx.x] = d_next; }
     __syncthreads();
     if (PF && q0 + 64 < p.T) {
@@ -442,10 +446,8 @@ __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < C::NKS; ++ks) {
-        const bf16x8 a = *(const bf16x8*)(Qs + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[ks], s, 0, 0, 0);
-        const bf16x8 a2 = *(const bf16x8*)(dOs + (sub * 32 + li) * C::KLD + ks * 16 + hi * 8);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, vf[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(Qs, fo, sub, ks), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(dOs, fo, sub, ks), vf[ks], dp, 0, 0, 0);
       }
       // No masks: a query row beyond T carries L = +inf (-> p = 0 exactly, dO row = 0 keeps dp finite), and a key lane
       // beyond S only pollutes its own accumulator column, which is never stored.
@@ -466,10 +468,10 @@ __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_
       const bf16x8 sf0 = pack_acc(ds, 0), sf1 = pack_acc(ds, 1);
 #pragma unroll
       for (int dt = 0; dt < C::NDT; ++dt) {
-        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(dOt, C::TLD, dt * 32 + li, sub, 0, hi), pf0, dvt[dt], 0, 0, 0);
-        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(dOt, C::TLD, dt * 32 + li, sub, 1, hi), pf1, dvt[dt], 0, 0, 0);
-        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Qt, C::TLD, dt * 32 + li, sub, 0, hi), sf0, dkt[dt], 0, 0, 0);
-        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag(Qt, C::TLD, dt * 32 + li, sub, 1, hi), sf1, dkt[dt], 0, 0, 0);
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(dOs, fo, dt, sub, 0), pf0, dvt[dt], 0, 0, 0);
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(dOs, fo, dt, sub, 1), pf1, dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Qs, fo, dt, sub, 0), sf0, dkt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Qs, fo, dt, sub, 1), sf1, dkt[dt], 0, 0, 0);
       }
     }
   }

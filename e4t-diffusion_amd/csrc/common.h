@@ -14,6 +14,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define E4T_WAVE 64
 
+// One bf16x8 MFMA operand gathered with two transposing LDS reads (ds_read_b64_tr_b16, gfx950): each lane passes the address
+// of 4 contiguous bf16; within a 16-lane group, output lane i receives in slot j element (i % 4) of source lane 4j + i / 4.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* lds_lo, const uint16_t* lds_hi) {
+  union { s16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_lo);
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_hi);
+  return u.v;
+}
+
 // ---- error plumbing (never throws across the ABI) -------------------------------------------
 extern "C" void e4t_set_error(const char* msg);
 #define E4T_FAIL(code, ...)                                  \

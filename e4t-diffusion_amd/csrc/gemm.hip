@@ -889,14 +889,6 @@ namespace {
 //     same banks, so 32-byte unit u of row r is stored at unit u ^ (2 (r & 3)) (swizzle applied on the DMA source side).
 // 128 x 128 x 64 tile, 8 waves (wave tile 32 x 64), two LDS buffers, one barrier per K-tile, as the NT kernel.
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* lds_lo, const bf16_t* lds_hi) {
-  union { s16x4 h[2]; bf16x8 v; } u;
-  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_lo);
-  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds_hi);
-  return u.v;
-}
-
 __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
   constexpr int BM = 128, BN = 128, WGN = 2, WM = 32, WN = 64, FN = 2;
   constexpr int OPER = BK * 128;                 // elements per operand tile: 64 rows x 128 columns
