@@ -216,11 +216,15 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = -INFINITY, l = 0.f;
+  constexpr bool SUM_BY_MFMA = C::DV > DH && DH % 8 == 0;      // a spare O^T row (d = DH) exists: it accumulates sum_k p
 
   TileRegs<DH> kr, vr;
   kr.load(Kb, p.ldk, 0, p.S);
   vr.load(Vb, p.ldv, 0, p.S);
   zero_pad_cols<DH>(Ks);
+  if (SUM_BY_MFMA) {       // V image: element d = DH of every key row = 1.0 (bf16), the rest of that 16-B slot = 0; never overwritten
+    if (threadIdx.x < 64) *(uint4*)(Vs + img_off<C::LDE>(threadIdx.x, C::NCH)) = make_uint4(0x3F80u, 0, 0, 0);
+  }
   for (int kv0 = 0; kv0 < p.S; kv0 += 64) {
     __syncthreads();                       // everyone finished reading the previous tile
     kr.store_rows(Ks);
@@ -239,35 +243,44 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
       for (int ks = 0; ks < C::NKS; ++ks) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(Ks, fo, sub, ks), qf[ks], s, 0, 0, 0);
       }
+      // Softmax bookkeeping is VALU work on a VALU-bound kernel (PMC: ~18 VALU instructions per MFMA), so it is kept minimal:
+      //  * the row max is taken on the raw scores and the scale folded into the exp argument (one fma per element);
+      //  * the running max m is only raised when some row of the wave exceeds it by more than 2^8 ("lazy rescaling"):
+      //    p = exp2(s - m) <= 256 stays harmless in fp32 / bf16, and the O / l rescale (alpha) is skipped on most tiles;
+      //    m, l and LSE = m + log2 l stay mutually consistent, so the result is unchanged;
+      //  * for head dims with a spare accumulator row (40, 80) the row sum l is produced by the P.V MFMA itself (V image
+      //    column DH holds ones), not by 16 adds + a cross-half exchange per sub-tile.
       float pr[16];
       float mx = -INFINITY;
-      if (kv0 + 64 > p.S) {                // ragged last tile only: keys beyond S get -inf
+      const bool tail = kv0 + 64 > p.S;        // ragged last tile only: keys beyond S get -inf
+      if (tail) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + sub * 32 + acc_row(r, hi);
-          pr[r] = key < p.S ? s[r] * p.scale2 : -INFINITY;
-          mx = fmaxf(mx, pr[r]);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          pr[r] = s[r] * p.scale2;
-          mx = fmaxf(mx, pr[r]);
+          s[r] = key < p.S ? s[r] : -INFINITY;
         }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = fast_exp2(m - mn);
-      float rs = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { pr[r] = fast_exp2(pr[r] - mn); rs += pr[r]; }
-      rs += __shfl_xor(rs, 32, 64);
-      l = l * alpha + rs;
-      m = mn;
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale2;         // scale2 > 0
+      if (__builtin_amdgcn_ballot_w64(mx > m + 8.f) != 0) {
+        const float mn = fmaxf(m, mx);
+        const float alpha = fast_exp2(m - mn);
+        m = mn;
+        if (!SUM_BY_MFMA) l *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < C::NDT; ++dt)
+        for (int dt = 0; dt < C::NDT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pr[r] = fast_exp2(s[r] * p.scale2 - m);
+      if (!SUM_BY_MFMA) {
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs += pr[r];
+        l += rs + __shfl_xor(rs, 32, 64);
+      }
       const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);
 #pragma unroll
       for (int dt = 0; dt < C::NDT; ++dt) {
@@ -275,6 +288,12 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Vs, fo, dt, sub, 1), pf1, o[dt], 0, 0, 0);
       }
     }
+  }
+  if (SUM_BY_MFMA) {       // O^T row d = DH sits in accumulator block DH / 32, register (DH % 32) / 8 * 4 of the hi = 0 lanes
+    constexpr int blk = DH / 32, reg = (DH % 32) / 8 * 4;
+    static_assert((DH % 32) % 8 == 0 && ((DH % 32) / 8) * 8 + 0 == DH % 32, "spare row must be row 8k of its block");
+    l = o[blk][reg];
+    l = __shfl(l, li, 64);                 // hi = 1 lanes take it from lane li
   }
   const float inv = 1.f / l;
   store_T_acc<DH>(o, inv, p.Out + b * p.bo + h * DH, p.ldo, q, p.T, hi);
