@@ -65,6 +65,7 @@ struct GemmArgs {
   int reduce_batch; // partials of all (batch, split) pairs are summed into ONE C
   int fast_epi;     // bf16 C, 16-byte aligned rows: LDS-staged vectorised epilogue
   long long strideA, strideB, strideC, strideBias;
+  unsigned a_bytes, a2_bytes, b_bytes;   // operand extents from the (batch-adjusted) base pointers, for buffer resources (pp kernel)
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int row, int col) {
@@ -658,15 +659,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nkt) kt_end = nkt;
 
-  const bf16_t* const zero = (const bf16_t*)&g_zero16;
+  // Operands are addressed through buffer resources (buffer_load ... lds): a 32-bit per-lane byte offset that changes only
+  // when the conv tap / concat source changes, plus a wave-uniform SGPR offset that walks K (+64 B per quarter).  Issuing a
+  // quarter costs no VALU at all, and out-of-range rows / conv padding simply carry an out-of-range offset (the hardware
+  // returns zeros) instead of a redirected pointer.
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFF0000u;          // >= every extent the launcher accepts
   // DMA: one wave-instruction = 16 rows x 64 B; wave w feeds quarter rows 32w + 16j + (lane >> 2), j = 0, 1
   const int drow = lane >> 2, dslot = lane & 3;
   long long a_base[2];
   int a_oy[2], a_ox[2], a_kc[2];
   bool a_ok[2];
-  const bf16_t* b_row[2];
-  int b_kc[2];
-  bool b_ok[2];
+  unsigned b_vo[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int r = wave * 32 + j * 16 + drow;
@@ -685,23 +691,24 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
       a_base[j] = (long long)b * p.Hin * p.Win;
     }
     const int gn = n0 + r;
-    b_ok[j] = gn < p.N;
-    b_kc[j] = kc;
-    b_row[j] = p.B + (size_t)(b_ok[j] ? gn : 0) * p.ldb;
+    b_vo[j] = gn < p.N ? (unsigned)(((size_t)gn * p.ldb + kc) * 2) : OOB;
   }
-  const bf16_t* a_ptr[2];
-  const bf16_t* b_ptr[2];
+  unsigned a_vo[2];
+  int a_so = 0, b_so = 0;          // wave-uniform byte offsets along K
+  bool a_second = false;           // reading the second concat source
   auto place_a = [&](int k0) {
     if (MODE == 0) {
-      const bf16_t* src = p.A;
       int ld = p.lda, koff = k0;
-      if (k0 >= p.K1) { src = p.A2; ld = p.lda2; koff = k0 - p.K1; }
+      a_second = k0 >= p.K1;
+      if (a_second) { ld = p.lda2; koff = k0 - p.K1; }
+      a_so = koff * 2;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) a_ptr[j] = a_ok[j] ? src + a_base[j] * ld + koff + a_kc[j] : zero;
+      for (int j = 0; j < 2; ++j) a_vo[j] = a_ok[j] ? (unsigned)((a_base[j] * ld + a_kc[j]) * 2) : OOB;
     } else {
       const int tap = k0 / p.Cin;
       const int ci0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
+      a_so = ci0 * 2;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int iy, ix;
@@ -725,33 +732,27 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
           iy = sy >> 1; ix = sx >> 1;
           ok = ok && iy < p.Hin && ix < p.Win;
         }
-        a_ptr[j] = ok ? p.A + (a_base[j] + (long long)iy * p.Win + ix) * p.Cin + ci0 + a_kc[j] : zero;
+        a_vo[j] = ok ? (unsigned)(((a_base[j] + (long long)iy * p.Win + ix) * p.Cin + a_kc[j]) * 2) : OOB;
       }
     }
   };
-  // The A and B streams are each issued in increasing k (lo(t), hi(t), lo(t+1), ...): one pointer per row, +32 per quarter.
+  // The A and B streams are each issued in increasing k (lo(t), hi(t), lo(t+1), ...): +64 bytes on the scalar offset per quarter.
   auto issue_a = [&](int kt, bool hi, bf16_t* dst) {
     const int k0 = kt * BK;
     const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
-    if (fresh) {
-      place_a(k0);
-    } else {
+    if (fresh) place_a(k0);
+    else a_so += HK * 2;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) a_ptr[j] += (a_ptr[j] != zero) ? HK : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < PP_NJ; ++j) PP_DMA(a_ptr[j], dst + (wave * 32 + j * 16) * HK);
+    for (int j = 0; j < PP_NJ; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_second ? rs_a2 : rs_a, (__attribute__((address_space(3))) void*)(dst + (wave * 32 + j * 16) * HK),
+                                               16, a_vo[j], a_so, 0, 0);
   };
   auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
-    if (!hi && kt == kt_begin) {
+    if (!hi && kt == kt_begin) b_so = kt * BK * 2;
+    else b_so += HK * 2;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b_ptr[j] = b_ok[j] ? b_row[j] + kt * BK + b_kc[j] : zero;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b_ptr[j] += (b_ptr[j] != zero) ? HK : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < PP_NJ; ++j) PP_DMA(b_ptr[j], dst + (wave * 32 + j * 16) * HK);
+    for (int j = 0; j < PP_NJ; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + (wave * 32 + j * 16) * HK), 16, b_vo[j], b_so, 0, 0);
   };
 
   f32x16 acc[4][2];
@@ -1034,7 +1035,15 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   }
   if (tile == 256 && !allow256) tile = 128;
   if (tile == 160 && !allow256) tile = 128;
-  if (tile == 512 && (!allow256 || p.K % BK != 0 || (p.A2 && p.K1 % BK != 0))) tile = 128;   // ping-pong kernel: whole K-tiles only
+  // ping-pong kernel: whole K-tiles only, and operands addressable with 32-bit byte offsets (buffer resources)
+  {
+    const unsigned long long lim = 0xFFFF0000ull;
+    unsigned long long ab, a2b = 0, bb = ((unsigned long long)(p.N - 1) * p.ldb + p.K) * 2;
+    if (conv) ab = (unsigned long long)((long long)p.M / ((long long)p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 2;   // batch * Hin * Win * Cin
+    else { ab = ((unsigned long long)(p.M - 1) * p.lda + p.K1) * 2; if (p.A2) a2b = ((unsigned long long)(p.M - 1) * p.lda2 + (p.K - p.K1)) * 2; }
+    if (tile == 512 && (!allow256 || p.K % BK != 0 || (p.A2 && p.K1 % BK != 0) || ab >= lim || a2b >= lim || bb >= lim)) tile = 128;
+    p.a_bytes = (unsigned)(ab < lim ? ab : 0); p.a2_bytes = (unsigned)(a2b < lim ? a2b : 0); p.b_bytes = (unsigned)(bb < lim ? bb : 0);
+  }
   const int tm = tile == 160 ? 128 : (tile == 512 ? 256 : tile), tn = tile == 256 ? 128 : (tile == 512 ? 256 : tile);   // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong
   const int gx = cdiv(p.N, tn), gy = cdiv(p.M, tm);
   // --- split-K: only when the grid underfills the chip and K is long ---
