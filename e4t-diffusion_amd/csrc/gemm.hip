@@ -337,6 +337,12 @@ __device__ __forceinline__ void dma16(const bf16_t* src, bf16_t* lds_wave_base) 
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same DMA through a buffer resource: 32-bit per-lane byte offset + wave-uniform SGPR byte offset; out-of-range offsets read
+// as zero.  (Kept in a non-template helper: the builtin is not instantiable from a value-dependent context on the host pass.)
+__device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff, bf16_t* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
 // Workgroup -> output-tile mapping.  The dispatcher deals consecutive workgroups (x fastest) round-robin over the 8 XCDs,
 // each with its own 4-MiB L2: with the plain blockIdx mapping the tiles sharing an A row panel (and, for the 3x3 convs,
 // the neighbouring image rows of the halo) sit in 8 different L2s and every panel is fetched 8 times.  Re-deal so that
@@ -390,7 +396,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nkt) kt_end = nkt;
 
-  const bf16_t* const zero = (const bf16_t*)&g_zero16;
+  // Operands are addressed through buffer resources (buffer_load ... lds): a 32-bit per-lane byte offset that changes only
+  // when the tile starts a new region — the first tile, a new 3x3 tap (conv), the switch to the second concat source
+  // (dense), the ragged last tile — plus a wave-uniform SGPR offset that walks K (+128 B per K-tile).  Issuing a tile costs
+  // no VALU at all (a per-tile 64-bit address recomputation cost ~1.2k issue cycles per wave, carried 64-bit pointers still
+  // 3 VALU each), and out-of-range rows / conv padding / K tails carry an out-of-range offset: the hardware returns zeros.
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFF0000u;          // >= every extent the launcher accepts
   const int lrow = lane >> 3, lslot = lane & 7;   // position of this lane inside a 1-KiB piece
 
   // rows this lane feeds: piece q = wave*NA + i covers tile rows q*8 .. q*8+7
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
       a_base[i] = (long long)b * p.Hin * p.Win;
     }
   }
-  const bf16_t* b_ptr[NB];
+  unsigned b_row[NB];
   int b_kc[NB];
   bool b_ok[NB];
 #pragma unroll
@@ -423,29 +437,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
     const int gn = n0 + r;
     b_ok[i] = gn < p.N && r < BN;
     b_kc[i] = (lslot ^ ((r >> 1) & 7)) * 8;
-    b_ptr[i] = p.B + (size_t)(b_ok[i] ? gn : 0) * p.ldb;
+    b_row[i] = (unsigned)(((size_t)(b_ok[i] ? gn : 0) * p.ldb + b_kc[i]) * 2);
   }
 
-  // Source pointers are carried ACROSS K-tiles and advanced by 64 elements per tile; the full (64-bit, per-row)
-  // address computation runs only when the tile starts a new region: the first tile, a new 3x3 tap (conv), the
-  // switch to the second concat source (dense), or the ragged last tile.  (A per-tile recomputation costs ~1.2k
-  // issue cycles per wave per tile — measured: 3x the tile's MFMA issue time.)
-  const bf16_t* a_ptr[NA];
-  const bf16_t* bq_ptr[NB];
+  unsigned a_vo[NA], b_vo[NB];
+  int a_so = 0, b_so = 0;          // wave-uniform byte offsets along K
+  bool a_second = false;           // reading the second concat source
   auto place_a = [&](int k0) {
     if (MODE == 0) {
-      const bf16_t* src = p.A;
       int ld = p.lda, koff = k0;
-      if (k0 >= p.K1) { src = p.A2; ld = p.lda2; koff = k0 - p.K1; }
+      a_second = k0 >= p.K1;
+      if (a_second) { ld = p.lda2; koff = k0 - p.K1; }
+      a_so = koff * 2;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const bool ok = a_ok[i] && (k0 + a_kc[i] < p.K);
-        a_ptr[i] = ok ? src + a_base[i] * ld + koff + a_kc[i] : zero;
+        a_vo[i] = ok ? (unsigned)((a_base[i] * ld + a_kc[i]) * 2) : OOB;
       }
     } else {
       const int tap = k0 / p.Cin;
       const int ci0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
+      a_so = ci0 * 2;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         int iy, ix;
@@ -469,15 +482,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
           iy = sy >> 1; ix = sx >> 1;
           ok = ok && iy < p.Hin && ix < p.Win;
         }
-        a_ptr[i] = ok ? p.A + (a_base[i] + (long long)iy * p.Win + ix) * p.Cin + ci0 + a_kc[i] : zero;
+        a_vo[i] = ok ? (unsigned)(((a_base[i] + (long long)iy * p.Win + ix) * p.Cin + a_kc[i]) * 2) : OOB;
       }
     }
   };
   auto place_b = [&](int k0) {
+    b_so = k0 * 2;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const bool ok = b_ok[i] && (k0 + b_kc[i] < p.K);
-      bq_ptr[i] = ok ? b_ptr[i] + k0 + b_kc[i] : zero;
+      b_vo[i] = ok ? b_row[i] : OOB;
     }
   };
   auto issue_tile = [&](int kt, bf16_t* buf) {
@@ -486,23 +500,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
     bf16_t* Bs = buf + BM * BK;
     const bool ragged = k0 + BK > p.K;                                      // wave-uniform conditions
     const bool fresh_a = kt == kt_begin || ragged || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0);
-    if (fresh_a) {
-      place_a(k0);
-    } else {
+    if (fresh_a) place_a(k0);
+    else a_so += BK * 2;
+    if (kt == kt_begin || ragged) place_b(k0);
+    else b_so += BK * 2;
 #pragma unroll
-      for (int i = 0; i < NA; ++i) a_ptr[i] += (a_ptr[i] != zero) ? BK : 0;
-    }
-    if (kt == kt_begin || ragged) {
-      place_b(k0);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NB; ++i) bq_ptr[i] += (bq_ptr[i] != zero) ? BK : 0;
-    }
-#pragma unroll
-    for (int i = 0; i < NA; ++i) dma16(a_ptr[i], As + (wave * NA + i) * 512);
+    for (int i = 0; i < NA; ++i)
+      buf_dma16(a_second ? rs_a2 : rs_a, a_vo[i], a_so, As + (wave * NA + i) * 512);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      if ((BN / 8) % NW == 0 || wave * NB + i < BN / 8) dma16(bq_ptr[i], Bs + (wave * NB + i) * 512);
+      if ((BN / 8) % NW == 0 || wave * NB + i < BN / 8)
+        buf_dma16(rs_b, b_vo[i], b_so, Bs + (wave * NB + i) * 512);
   };
 
   f32x16 acc[FM][FN];
@@ -614,11 +622,6 @@ __device__ unsigned long long g_pp_trace[2 * 6 * 64];
 #define PP_LDSREAD(ptr) bf16x8{}
 #else
 #define PP_LDSREAD(ptr) (*(const bf16x8*)(ptr))
-#endif
-#ifdef PP_NODMA      // timing ablations of the debug build (results are garbage)
-#define PP_DMA(src, dst) asm volatile("" ::"v"(src))
-#else
-#define PP_DMA(src, dst) dma16(src, dst)
 #endif
 #ifdef PP_DMA1
 #define PP_NJ 1
@@ -744,15 +747,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     else a_so += HK * 2;
 #pragma unroll
     for (int j = 0; j < PP_NJ; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_second ? rs_a2 : rs_a, (__attribute__((address_space(3))) void*)(dst + (wave * 32 + j * 16) * HK),
-                                               16, a_vo[j], a_so, 0, 0);
+      buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 32 + j * 16) * HK);
   };
   auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
     if (!hi && kt == kt_begin) b_so = kt * BK * 2;
     else b_so += HK * 2;
 #pragma unroll
     for (int j = 0; j < PP_NJ; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + (wave * 32 + j * 16) * HK), 16, b_vo[j], b_so, 0, 0);
+      buf_dma16(rs_b, b_vo[j], b_so, dst + (wave * 32 + j * 16) * HK);
   };
 
   f32x16 acc[4][2];
@@ -1035,14 +1037,18 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   }
   if (tile == 256 && !allow256) tile = 128;
   if (tile == 160 && !allow256) tile = 128;
-  // ping-pong kernel: whole K-tiles only, and operands addressable with 32-bit byte offsets (buffer resources)
+  // The DMA kernels address their operands through buffer resources (32-bit byte offsets): operands beyond 4 GB fall back to
+  // the register-staged kernel.  The ping-pong kernel additionally needs whole K-tiles.
+  bool buf_ok = true;
   {
     const unsigned long long lim = 0xFFFF0000ull;
     unsigned long long ab, a2b = 0, bb = ((unsigned long long)(p.N - 1) * p.ldb + p.K) * 2;
     if (conv) ab = (unsigned long long)((long long)p.M / ((long long)p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 2;   // batch * Hin * Win * Cin
     else { ab = ((unsigned long long)(p.M - 1) * p.lda + p.K1) * 2; if (p.A2) a2b = ((unsigned long long)(p.M - 1) * p.lda2 + (p.K - p.K1)) * 2; }
-    if (tile == 512 && (!allow256 || p.K % BK != 0 || (p.A2 && p.K1 % BK != 0) || ab >= lim || a2b >= lim || bb >= lim)) tile = 128;
-    p.a_bytes = (unsigned)(ab < lim ? ab : 0); p.a2_bytes = (unsigned)(a2b < lim ? a2b : 0); p.b_bytes = (unsigned)(bb < lim ? bb : 0);
+    buf_ok = ab < lim && a2b < lim && bb < lim;
+    if (tile == 512 && (!allow256 || !buf_ok || p.K % BK != 0 || (p.A2 && p.K1 % BK != 0))) tile = 128;
+    p.a_bytes = (unsigned)(buf_ok ? ab : 0); p.a2_bytes = (unsigned)(buf_ok ? a2b : 0); p.b_bytes = (unsigned)(buf_ok ? bb : 0);
+    if (!buf_ok && tile != 64) tile = 128;       // the register-staged fallback exists as 128x128 and 64x64 only
   }
   const int tm = tile == 160 ? 128 : (tile == 512 ? 256 : tile), tn = tile == 256 ? 128 : (tile == 512 ? 256 : tile);   // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong
   const int gx = cdiv(p.N, tn), gy = cdiv(p.M, tm);
@@ -1083,7 +1089,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                (p.strideC % 8 == 0) && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
   dim3 grid(gx, gy, splitk * batch), block(256);
   static const bool use_dma = getenv("E4T_GEMM_REGSTAGE") == nullptr;   // A/B switch: register-staged reference kernel
-  if (use_dma) {
+  if (use_dma && buf_ok) {
     if (tile == 512) {
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1>), grid, block, 0, st, p);
