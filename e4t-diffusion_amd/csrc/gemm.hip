@@ -911,35 +911,40 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nkt) kt_end = nkt;
 
-  const bf16_t* const zero = (const bf16_t*)&g_zero16;
+  // buffer-resource addressing as in the NT kernels: per-lane byte offset (row in piece, swizzled column chunk) fixed for the
+  // whole loop, the wave-uniform scalar offset walks the contraction rows (+64 rows per K-tile); rows beyond K and columns
+  // beyond M / N carry an out-of-range offset and read as zero
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFF0000u;
   // DMA: piece q = 4 tile rows; wave w feeds pieces 2w, 2w+1 of each operand.  lane -> (row in piece, physical 16-B chunk)
   const int prow = lane >> 4, pchunk = lane & 15;
   const int lchunk = (((pchunk >> 1) ^ (2 * prow)) << 1) | (pchunk & 1);      // logical chunk stored at this physical slot
   const bool a_col_ok = m0 + lchunk * 8 < p.M, b_col_ok = n0 + lchunk * 8 < p.N;
-  const bf16_t* a_ptr[2];
-  const bf16_t* b_ptr[2];
-  auto place = [&](int kt) {
+  unsigned a_col[2], b_col[2], a_vo[2], b_vo[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kk = kt * BK + (wave * 2 + i) * 4 + prow;
-      a_ptr[i] = (a_col_ok && kk < p.K) ? p.A + (size_t)kk * p.lda + m0 + lchunk * 8 : zero;
-      b_ptr[i] = (b_col_ok && kk < p.K) ? p.B + (size_t)kk * p.ldb + n0 + lchunk * 8 : zero;
-    }
-  };
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 4 + prow;              // tile row of this lane in piece i
+    a_col[i] = a_col_ok ? (unsigned)(((size_t)r * p.lda + m0 + lchunk * 8) * 2) : OOB;
+    b_col[i] = b_col_ok ? (unsigned)(((size_t)r * p.ldb + n0 + lchunk * 8) * 2) : OOB;
+  }
+  int a_so = 0, b_so = 0;
   auto issue_tile = [&](int kt, bf16_t* buf) {
-    if (kt == kt_begin || (kt + 1) * BK > p.K) {
-      place(kt);
-    } else {
+    if (kt == kt_begin || (kt + 1) * BK > p.K) {          // first tile, or the ragged last one: mask the rows beyond K
+      a_so = kt * BK * p.lda * 2; b_so = kt * BK * p.ldb * 2;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        a_ptr[i] += (a_ptr[i] != zero) ? (size_t)BK * p.lda : 0;
-        b_ptr[i] += (b_ptr[i] != zero) ? (size_t)BK * p.ldb : 0;
+        const bool row_ok = kt * BK + (wave * 2 + i) * 4 + prow < p.K;
+        a_vo[i] = row_ok ? a_col[i] : OOB;
+        b_vo[i] = row_ok ? b_col[i] : OOB;
       }
+    } else {
+      a_so += BK * p.lda * 2; b_so += BK * p.ldb * 2;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(a_ptr[i], buf + (wave * 2 + i) * 512);
+    for (int i = 0; i < 2; ++i) buf_dma16(rs_a, a_vo[i], a_so, buf + (wave * 2 + i) * 512);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) dma16(b_ptr[i], buf + OPER + (wave * 2 + i) * 512);
+    for (int i = 0; i < 2; ++i) buf_dma16(rs_b, b_vo[i], b_so, buf + OPER + (wave * 2 + i) * 512);
   };
 
   f32x16 acc[1][FN];
@@ -1170,6 +1175,11 @@ extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
   p.ws = (float*)d->workspace;
   const int nkt = cdiv(p.K, BK), gx = cdiv(p.N, 128), gy = cdiv(p.M, 128);
   const long long tiles = (long long)gx * gy;
+  {   // operand extents for the buffer resources (32-bit byte offsets)
+    const unsigned long long ab = ((unsigned long long)(p.K - 1) * p.lda + p.M) * 2, bb = ((unsigned long long)(p.K - 1) * p.ldb + p.N) * 2;
+    E4T_REQUIRE(ab < 0xFFFF0000ull && bb < 0xFFFF0000ull, "gemm_tn: operands beyond 4 GB are not supported");
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+  }
   int splitk = d->splitk;
   if (splitk <= 0) {      // weight gradients: few output tiles, very long K -> fill the 512 workgroup slots by splitting K
     splitk = (int)(512 / tiles);
