@@ -1037,7 +1037,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     // K-deep shapes whose N is a multiple of 256 and that fill the chip at least twice with 256x256 tiles (the VAE's 256-
     // and 512-channel convs): the ping-pong kernel (conv 512->512 @128^2: 1075 vs 928 TF, 8192^3: 1173 vs 971 TF)
     static const bool no_pp = getenv("E4T_GEMM_NOPP") != nullptr;     // A/B switch
-    if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && p.K % BK == 0 && nkt >= 32 && (!p.A2 || p.K1 % BK == 0) &&
+    if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && p.K % BK == 0 && nkt >= (conv ? 16 : 32) && (!p.A2 || p.K1 % BK == 0) &&
         (long long)cdiv(p.M, 256) * (p.N / 256) * batch >= 512) tile = 512;
   }
   if (tile == 256 && !allow256) tile = 128;

@@ -51,7 +51,7 @@ def _rowmajor(t: torch.Tensor, name: str):
 
 
 
-def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch):
+def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch, conv=False):
     """Mirror of launch_gemm()'s tile / split-K heuristic (csrc/gemm.hip) -> workspace bytes it will want."""
     cd = lambda a, b: (a + b - 1) // b
     nkt = cd(K, 64)
@@ -60,7 +60,7 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch):
         tile = 128 if (t128 >= 256 or (nkt >= 32 and t128 >= 64)) else 64
         if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
             tile = 160
-        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= 32 and cd(M, 256) * (N // 256) * nb >= 512:
+        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= (16 if conv else 32) and cd(M, 256) * (N // 256) * nb >= 512:
             tile = 512
     if tile == 512 and K % 64:
         tile = 128
@@ -134,7 +134,7 @@ class HipBackend:
         return r
 
     @staticmethod
-    def _tile(M, N, K, nb, tile):
+    def _tile(M, N, K, nb, tile, conv=False):
         """Mirror of launch_gemm()'s tile choice (csrc/gemm.hip), used only to label bench.py's per-kernel timings."""
         if tile in (64, 128, 256, 160, 512):
             return tile
@@ -143,7 +143,7 @@ class HipBackend:
         tile = 128 if (t128 >= 256 or (cd(K, 64) >= 32 and t128 >= 64)) else 64
         if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
             tile = 160
-        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= 32 and cd(M, 256) * (N // 256) * nb >= 512:
+        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= (16 if conv else 32) and cd(M, 256) * (N // 256) * nb >= 512:
             tile = 512
         return tile
 
@@ -253,11 +253,11 @@ class HipBackend:
             flags |= _C.ACCUM
         d.mode, d.flags, d.tile, d.splitk = mode, flags, tile, splitk
         d.ldrb = rowbias.stride(0) if rowbias is not None else 0
-        need = _gemm_ws_need(M, Cout, 9 * Cin, 1, tile, splitk, False)
+        need = _gemm_ws_need(M, Cout, 9 * Cin, 1, tile, splitk, False, conv=True)
         ws = self.workspace(need, x.device) if need else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
-        self._timed(f"conv{self._tile(M, Cout, 9 * Cin, 1, tile)}", 2.0 * M * Cout * 9 * Cin,
+        self._timed(f"conv{self._tile(M, Cout, 9 * Cin, 1, tile, conv=True)}", 2.0 * M * Cout * 9 * Cin,
                     lambda: _C.check(self.lib.e4t_conv3x3(C.byref(d), st), "e4t_conv3x3"))
         return out
 
