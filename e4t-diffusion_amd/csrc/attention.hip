@@ -83,17 +83,26 @@ template <int DH>
 struct TileRegs {
   using C = Cfg<DH>;
   uint4 v[C::NIT][2];
-  __device__ __forceinline__ void load(const bf16_t* g, int ld, int r0, int R) {
+  unsigned vo[C::NIT];          // byte offset of this thread's (row pair, chunk) inside a 64-row tile; out of range for idle threads
+  int ldb;                      // row stride in bytes
+  // Tiles are fetched through a buffer resource whose extent ends with the last valid row: rows beyond it (ragged last tile)
+  // and idle threads read zeros from the hardware, and stepping to the next tile is one scalar add — no per-tile address VALU
+  // on kernels that are VALU-bound.
+  __device__ __forceinline__ void init(int ld) {
+    ldb = ld * 2;
 #pragma unroll
     for (int it = 0; it < C::NIT; ++it) {
       const int item = threadIdx.x + it * 256;
       const int ch = item >> 5, kp = item & 31;
-      const int k0 = r0 + 2 * kp;
-      v[it][0] = make_uint4(0, 0, 0, 0); v[it][1] = make_uint4(0, 0, 0, 0);
-      if (item < 32 * C::NCH) {
-        if (k0 < R) v[it][0] = *(const uint4*)(g + (long long)k0 * ld + ch * 8);
-        if (k0 + 1 < R) v[it][1] = *(const uint4*)(g + (long long)(k0 + 1) * ld + ch * 8);
-      }
+      vo[it] = item < 32 * C::NCH ? (unsigned)((2 * kp * ld + ch * 8) * 2) : 0xFFFF0000u;
+    }
+  }
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int r0) {
+    const int soff = r0 * ldb;
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      v[it][0] = buf_load16(rs, vo[it], soff);
+      v[it][1] = buf_load16(rs, vo[it], soff + ldb);
     }
   }
   // swizzled row-major image lds[64][LDE]
@@ -219,8 +228,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
   constexpr bool SUM_BY_MFMA = C::DV > DH && DH % 8 == 0;      // a spare O^T row (d = DH) exists: it accumulates sum_k p
 
   TileRegs<DH> kr, vr;
-  kr.load(Kb, p.ldk, 0, p.S);
-  vr.load(Vb, p.ldv, 0, p.S);
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(Kb, (unsigned)(((long long)(p.S - 1) * p.ldk + DH) * 2));
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(Vb, (unsigned)(((long long)(p.S - 1) * p.ldv + DH) * 2));
+  kr.init(p.ldk); vr.init(p.ldv);
+  kr.load(rsK, 0);
+  vr.load(rsV, 0);
   zero_pad_cols<DH>(Ks);
   if (SUM_BY_MFMA) {       // V image: element d = DH of every key row = 1.0 (bf16), the rest of that 16-B slot = 0; never overwritten
     if (threadIdx.x < 64) *(uint4*)(Vs + img_off<C::LDE>(threadIdx.x, C::NCH)) = make_uint4(0x3F80u, 0, 0, 0);
@@ -231,8 +243,8 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
     vr.store_rows(Vs);
     __syncthreads();
     if (kv0 + 64 < p.S) {                  // next tile's loads fly under this tile's MFMAs
-      kr.load(Kb, p.ldk, kv0 + 64, p.S);
-      vr.load(Vb, p.ldv, kv0 + 64, p.S);
+      kr.load(rsK, kv0 + 64);
+      vr.load(rsV, kv0 + 64);
     }
     const int nsub = (p.S - kv0 > 32) ? 2 : 1;
     for (int sub = 0; sub < nsub; ++sub) {
@@ -352,8 +364,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
     for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
 
   TileRegs<DH> kr, vr;
-  kr.load(Kb, p.ldk, 0, p.S);
-  vr.load(Vb, p.ldv, 0, p.S);
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(Kb, (unsigned)(((long long)(p.S - 1) * p.ldk + DH) * 2));
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(Vb, (unsigned)(((long long)(p.S - 1) * p.ldv + DH) * 2));
+  kr.init(p.ldk); vr.init(p.ldv);
+  kr.load(rsK, 0);
+  vr.load(rsV, 0);
   zero_pad_cols<DH>(Ks);
   zero_pad_cols<DH>(Vs);
   for (int kv0 = 0; kv0 < p.S; kv0 += 64) {
@@ -362,8 +377,8 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
     vr.store_rows(Vs);
     __syncthreads();
     if (kv0 + 64 < p.S) {
-      kr.load(Kb, p.ldk, kv0 + 64, p.S);
-      vr.load(Vb, p.ldv, kv0 + 64, p.S);
+      kr.load(rsK, kv0 + 64);
+      vr.load(rsV, kv0 + 64);
     }
     const int nsub = (p.S - kv0 > 32) ? 2 : 1;
     for (int sub = 0; sub < nsub; ++sub) {
@@ -435,17 +450,20 @@ __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_
     }
   };
   constexpr bool PF = DH <= 80;            // register prefetch of the next tile (dh=160 would spill: load in place)
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(Qb, (unsigned)(((long long)(p.T - 1) * p.ldq + DH) * 2));
+  const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(dOb, (unsigned)(((long long)(p.T - 1) * p.ldo + DH) * 2));
+  qr.init(p.ldq); dor.init(p.ldo);
   if (PF) {
-    qr.load(Qb, p.ldq, 0, p.T);
-    dor.load(dOb, p.ldo, 0, p.T);
+    qr.load(rsQ, 0);
+    dor.load(rsdO, 0);
     load_stats(0);
   }
   zero_pad_cols<DH>(Qs);
   zero_pad_cols<DH>(dOs);
   for (int q0 = 0; q0 < p.T; q0 += 64) {
     if (!PF) {
-      qr.load(Qb, p.ldq, q0, p.T);
-      dor.load(dOb, p.ldo, q0, p.T);
+      qr.load(rsQ, q0);
+      dor.load(rsdO, q0);
       load_stats(q0);
     }
     __syncthreads();
@@ -454,8 +472,8 @@ __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_
     if (threadIdx.x < 64) { Ls[threadIdx.x] = l_next; Dls[threadIdx.x] = d_next; }
     __syncthreads();
     if (PF && q0 + 64 < p.T) {
-      qr.load(Qb, p.ldq, q0 + 64, p.T);
-      dor.load(dOb, p.ldo, q0 + 64, p.T);
+      qr.load(rsQ, q0 + 64);
+      dor.load(rsdO, q0 + 64);
       load_stats(q0 + 64);
     }
     const int nsub = (p.T - q0 > 32) ? 2 : 1;

@@ -107,6 +107,17 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;
 }
 
+// 16-byte global load through a buffer resource: 32-bit per-lane byte offset + wave-uniform scalar byte offset, out-of-range
+// offsets read as zero (non-template wrappers: the builtins cannot be instantiated from value-dependent contexts on the host pass)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_native;
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+  const u32x4_native v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
   const float s = 1.f / (1.f + __expf(-x));
