@@ -31,7 +31,8 @@ MFMA_PEAK = 2.5e15                                         # bf16 dense, /opt/sk
 
 def build_models(dev, model, seed):
     from e4t.encoder import E4TEncoder
-    from e4t.frozen import CLIP_TEXT_H, CLIP_TEXT_L, CLIPTextModel
+    from e4t.frozen import CLIP_TEXT_H, CLIP_TEXT_L
+    from e4t.text import CLIPTextModel          # CLIP text encoder on the HIP kernels
     from e4t.vae import VAEEncoder
     from e4t.models.unet_2d_condition import UNet2DConditionModel
     torch.manual_seed(seed)
@@ -46,7 +47,7 @@ def build_models(dev, model, seed):
     with torch.device(dev):
         unet = UNet2DConditionModel(**ucfg)
         enc = E4TEncoder(word_embedding_dim=wdim, block_out_channels=ucfg["block_out_channels"], arch="ViT-H-14")
-        text = CLIPTextModel(**tcfg).requires_grad_(False).to(torch.bfloat16)
+        text = CLIPTextModel(**tcfg).requires_grad_(False)      # fp32 master weights; bf16 compute copies are made once
         vae = VAEEncoder().requires_grad_(False)          # fp32 masters; the kernel path keeps its own bf16 copies
     return unet, enc, text, vae
 
@@ -205,7 +206,7 @@ def main():
                    config=dict(workload=("SD-1.4 UNet + ViT-H-14 E4T encoder pretrain step, 512px" if args.model == "sd14"
                                          else "SD-2.x UNet (ctx 1024, linear proj) + ViT-H-14 E4T encoder pretrain step, 768px"),
                                per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}", trainable="weight offsets + E4T head (ViT frozen)",
-                               frozen_on_stock_torch="CLIP text encoder (VAE encoder runs on the HIP kernels)", last_loss=float(loss)),
+                               frozen_on_stock_torch="none (CLIP text encoder and VAE encoder run on the HIP kernels; only embedding lookups / loss glue are torch ops)", last_loss=float(loss)),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out))
     if world > 1:

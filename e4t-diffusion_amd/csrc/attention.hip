@@ -43,6 +43,7 @@ struct AttnArgs {
   long long bq, bk, bv, bo;    // batch strides (elements)
   float scale2;                // scale * log2(e)
   float scale;
+  int causal;                  // key index > query index is masked
 };
 
 template <int DH>
@@ -265,11 +266,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
       float pr[16];
       float mx = -INFINITY;
       const bool tail = kv0 + 64 > p.S;        // ragged last tile only: keys beyond S get -inf
-      if (tail) {
+      if (tail || p.causal) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + sub * 32 + acc_row(r, hi);
-          s[r] = key < p.S ? s[r] : -INFINITY;
+          s[r] = (key < p.S && (!p.causal || key <= q)) ? s[r] : -INFINITY;
         }
       }
 #pragma unroll
@@ -391,11 +392,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(Vs, fo, sub, ks), dof[ks], dp, 0, 0, 0);
       }
       float ds[16];
-      if (kv0 + 64 > p.S) {                // ragged last tile only
+      if (kv0 + 64 > p.S || p.causal) {    // ragged last tile / causal mask
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv0 + sub * 32 + acc_row(r, hi);
-          const float pv = key < p.S ? fast_exp2(s[r] * p.scale2 - Lq) : 0.f;
+          const float pv = (key < p.S && (!p.causal || key <= q)) ? fast_exp2(s[r] * p.scale2 - Lq) : 0.f;
           ds[r] = pv * (dp[r] - Dq);
         }
       } else {
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           pr[r] = fast_exp2(s[r] * p.scale2 - lq[j]);
+          if (p.causal && q0 + sub * 32 + 8 * g + 4 * hi + j < key) pr[r] = 0.f;      // query before this lane's key
           ds[r] = pr[r] * (dp[r] - dq[j]);
         }
       }
@@ -547,14 +549,14 @@ int check_common(int Bn, int H, int T, int S, int DH, int ldq, int ldk, int ldv,
 
 extern "C" int e4t_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int Bn, int H, int T, int S,
                                  int DH, int ldq, int ldk, int ldv, int ldo, long long bq, long long bk, long long bv,
-                                 long long bo, float scale, e4t_stream stream) {
+                                 long long bo, float scale, int causal, e4t_stream stream) {
   if (int e = check_common(Bn, H, T, S, DH, ldq, ldk, ldv, ldo)) return e;
   E4T_REQUIRE(Q && K && V && O, "attention_fwd: null operand");
   AttnArgs p;
   memset(&p, 0, sizeof(p));
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Out = (bf16_t*)O; p.L = lse;
   p.T = T; p.S = S; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.bq = bq; p.bk = bk; p.bv = bv; p.bo = bo;
-  p.scale = scale; p.scale2 = scale * 1.4426950408889634f;
+  p.scale = scale; p.scale2 = scale * 1.4426950408889634f; p.causal = causal;
   hipStream_t st = (hipStream_t)stream;
   switch (DH) {
     case 32: return launch_fwd<32>(p, Bn, st);
@@ -568,7 +570,7 @@ extern "C" int e4t_attention_fwd(const void* Q, const void* K, const void* V, vo
 extern "C" int e4t_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                                  float* delta_ws, void* dQ, void* dK, void* dV, int Bn, int H, int T, int S, int DH, int ldq,
                                  int ldk, int ldv, int ldo, long long bq, long long bk, long long bv, long long bo, float scale,
-                                 e4t_stream stream) {
+                                 int causal, e4t_stream stream) {
   if (int e = check_common(Bn, H, T, S, DH, ldq, ldk, ldv, ldo)) return e;
   E4T_REQUIRE(Q && K && V && O && dO && lse && delta_ws && dQ && dK && dV, "attention_bwd: null operand");
   AttnArgs p;
@@ -576,7 +578,7 @@ extern "C" int e4t_attention_bwd(const void* Q, const void* K, const void* V, co
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (const bf16_t*)O; p.dO = (const bf16_t*)dO;
   p.L = (float*)lse; p.Delta = delta_ws; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
   p.T = T; p.S = S; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.bq = bq; p.bk = bk; p.bv = bv; p.bo = bo;
-  p.scale = scale; p.scale2 = scale * 1.4426950408889634f;
+  p.scale = scale; p.scale2 = scale * 1.4426950408889634f; p.causal = causal;
   hipStream_t st = (hipStream_t)stream;
   switch (DH) {
     case 32: return launch_bwd<32>(p, Bn, st);

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* u, const b
   }
 }
 
-// ---- unary: op 0 = silu, 1 = silu backward (dy, x) , 2 = gelu, 3 = gelu backward, 4 = leaky_relu(0.01), 5 = its backward ----
+// ---- unary: op 0 = silu, 1 = silu backward (dy, x) , 2 = gelu, 3 = gelu backward, 4 = leaky_relu(0.01), 5 = its backward,
+//            6 = quick_gelu x*sigmoid(1.702 x) (CLIP text encoder of SD-1.x), 7 = its backward ----
 __global__ __launch_bounds__(256) void unary_kernel(const bf16_t* x, const bf16_t* dy, bf16_t* y, long long n8, int op) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
     float f[8], d[8];
@@ -52,7 +53,9 @@ __global__ __launch_bounds__(256) void unary_kernel(const bf16_t* x, const bf16_
         case 2: f[k] = gelu_f(f[k]); break;
         case 3: f[k] = d[k] * dgelu_f(f[k]); break;
         case 4: f[k] = f[k] > 0.f ? f[k] : 0.01f * f[k]; break;
-        default: f[k] = f[k] > 0.f ? d[k] : 0.01f * d[k]; break;
+        case 5: f[k] = f[k] > 0.f ? d[k] : 0.01f * d[k]; break;
+        case 6: f[k] = f[k] / (1.f + __expf(-1.702f * f[k])); break;
+        default: { const float sg = 1.f / (1.f + __expf(-1.702f * f[k])); f[k] = d[k] * sg * (1.f + 1.702f * f[k] * (1.f - sg)); } break;
       }
     }
     *(uint4*)(y + i * 8) = pack8(f);
@@ -295,7 +298,7 @@ extern "C" int e4t_geglu_bwd(const void* u, const void* dh, void* du, long long 
   return 0;
 }
 extern "C" int e4t_unary(const void* x, const void* dy, void* y, long long n, int op, e4t_stream s) {
-  E4T_REQUIRE(x && y && n > 0 && n % 8 == 0 && op >= 0 && op <= 5, "unary: bad arguments (n %% 8 == 0 required)");
+  E4T_REQUIRE(x && y && n > 0 && n % 8 == 0 && op >= 0 && op <= 7, "unary: bad arguments (n %% 8 == 0 required)");
   E4T_REQUIRE(((op & 1) == 0) || dy, "unary: backward ops need dy");
   hipLaunchKernelGGL(unary_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)((op & 1) ? dy : nullptr), (bf16_t*)y, n / 8, op);
   E4T_CHECK_LAUNCH("unary_kernel");

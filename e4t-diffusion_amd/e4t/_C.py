@@ -52,8 +52,8 @@ SIGNATURES = {
     "e4t_gemm_nt": (i32, [C.POINTER(GemmDesc), vp]),
     "e4t_gemm_tn": (i32, [C.POINTER(GemmDesc), vp]),
     "e4t_conv3x3": (i32, [C.POINTER(ConvDesc), vp]),
-    "e4t_attention_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp]),
-    "e4t_attention_bwd": (i32, [vp] * 10 + [i32] * 9 + [i64] * 4 + [f32, vp]),
+    "e4t_attention_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, i32, vp]),
+    "e4t_attention_bwd": (i32, [vp] * 10 + [i32] * 9 + [i64] * 4 + [f32, i32, vp]),
     "e4t_groupnorm_num_chunks": (i32, [i32, i32]),
     "e4t_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "e4t_groupnorm_stats": (i32, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, sz, vp]),
@@ -94,7 +94,7 @@ SIGNATURES = {
 OUT_F32, RES_F32, ACT_GELU, ACCUM, REDUCE_BATCH = 1, 2, 4, 8, 16
 CONV_S1, CONV_S2, CONV_UP2, CONV_S2T, CONV_S2A = 1, 2, 3, 4, 5
 WO_STORE_F32, WO_OFFSETS_ONLY = 1, 2
-OP_SILU, OP_SILU_BWD, OP_GELU, OP_GELU_BWD, OP_LRELU, OP_LRELU_BWD = range(6)
+OP_SILU, OP_SILU_BWD, OP_GELU, OP_GELU_BWD, OP_LRELU, OP_LRELU_BWD, OP_QGELU, OP_QGELU_BWD = range(8)
 
 _lib = None
 

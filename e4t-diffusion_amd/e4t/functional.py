@@ -453,21 +453,21 @@ class AttentionFn(torch.autograd.Function):
     """self: qkv = [B*T, 3d] (q | k | v column blocks), kv = None.  cross: qkv = q [B*T, d], kv = [B*S, 2d]."""
 
     @staticmethod
-    def forward(ctx, qkv, kv, B, H, T, S, DH, scale):
+    def forward(ctx, qkv, kv, B, H, T, S, DH, scale, causal=False):
         d = H * DH
         if kv is None:
             q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
         else:
             q, k, v = qkv, kv[:, :d], kv[:, d:]
-        o, lse = ops.backend().attention_fwd(q, k, v, B, H, T, S, DH, scale)
+        o, lse = ops.backend().attention_fwd(q, k, v, B, H, T, S, DH, scale, causal=causal)
         ctx.save_for_backward(qkv, kv, o, lse)
-        ctx.cfg = (B, H, T, S, DH, scale)
+        ctx.cfg = (B, H, T, S, DH, scale, causal)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, kv, o, lse = ctx.saved_tensors
-        B, H, T, S, DH, scale = ctx.cfg
+        B, H, T, S, DH, scale, causal = ctx.cfg
         d = H * DH
         dqkv = torch.empty_like(qkv)
         dkv = torch.empty_like(kv) if kv is not None else None
@@ -477,12 +477,12 @@ class AttentionFn(torch.autograd.Function):
         else:
             q, k, v = qkv, kv[:, :d], kv[:, d:]
             dq, dk, dv = dqkv, dkv[:, :d], dkv[:, d:]
-        ops.backend().attention_bwd(q, k, v, o, do.contiguous(), lse, dq, dk, dv, B, H, T, S, DH, scale)
-        return dqkv, dkv, None, None, None, None, None, None
+        ops.backend().attention_bwd(q, k, v, o, do.contiguous(), lse, dq, dk, dv, B, H, T, S, DH, scale, causal=causal)
+        return dqkv, dkv, None, None, None, None, None, None, None
 
 
-def attention(qkv, kv, B, H, T, S, DH, scale):
-    return AttentionFn.apply(qkv, kv, B, H, T, S, DH, scale)
+def attention(qkv, kv, B, H, T, S, DH, scale, causal=False):
+    return AttentionFn.apply(qkv, kv, B, H, T, S, DH, scale, causal)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -523,6 +523,15 @@ def silu(x):
 
 def leaky_relu(x):
     return UnaryFn.apply(x, _C.OP_LRELU)
+
+
+def gelu(x):
+    return UnaryFn.apply(x, _C.OP_GELU)
+
+
+def quick_gelu(x):
+    """x * sigmoid(1.702 x): hidden_act of the SD-1.x CLIP text encoder"""
+    return UnaryFn.apply(x, _C.OP_QGELU)
 
 
 class SpatialMeanFn(torch.autograd.Function):

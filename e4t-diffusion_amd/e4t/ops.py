@@ -272,7 +272,7 @@ class HipBackend:
         return wf, wd
 
     # ------------------------------------------------------------------ attention
-    def attention_fwd(self, q, k, v, B, H, T, S, DH, scale, out=None, need_lse=True):
+    def attention_fwd(self, q, k, v, B, H, T, S, DH, scale, out=None, need_lse=True, causal=False):
         """q: [B*T, *] view, k/v: [B*S, *] views (row stride arbitrary); returns (o [B*T, H*DH], lse [B,H,T])."""
         for t in (q, k, v):
             _rowmajor(t, "attention operand")
@@ -283,10 +283,10 @@ class HipBackend:
         st = _stream()
         self._timed(f"attn_fwd{DH}", 4.0 * B * H * T * S * DH, lambda: _C.check(self.lib.e4t_attention_fwd(
             _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, T, S, DH, ldq, ldk, ldv, ldo,
-            T * ldq, S * ldk, S * ldv, T * ldo, float(scale), st), "e4t_attention_fwd"))
+            T * ldq, S * ldk, S * ldv, T * ldo, float(scale), int(causal), st), "e4t_attention_fwd"))
         return out, lse
 
-    def attention_bwd(self, q, k, v, o, do, lse, dq, dk, dv, B, H, T, S, DH, scale):
+    def attention_bwd(self, q, k, v, o, do, lse, dq, dk, dv, B, H, T, S, DH, scale, causal=False):
         """dq/dk/dv are pre-allocated views with the SAME strides as q/k/v; do has the strides of o."""
         ldq, ldk, ldv, ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
         assert dq.stride(0) == ldq and dk.stride(0) == ldk and dv.stride(0) == ldv and do.stride(0) == ldo
@@ -295,7 +295,7 @@ class HipBackend:
         self._timed(f"attn_bwd{DH}", 10.0 * B * H * T * S * DH, lambda: _C.check(self.lib.e4t_attention_bwd(
             _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk),
             _ptr(dv), B, H, T, S, DH, ldq, ldk, ldv, ldo, T * ldq, S * ldk, S * ldv, T * ldo,
-            float(scale), st), "e4t_attention_bwd"))
+            float(scale), int(causal), st), "e4t_attention_bwd"))
 
     # ------------------------------------------------------------------ norms
     def groupnorm_fwd(self, x1, x2, gamma, beta, B, HW, G, eps, silu):

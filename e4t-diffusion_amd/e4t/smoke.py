@@ -19,6 +19,7 @@ def run(dev, verbose=True):
     from . import ops
     from .encoder import E4TEncoder
     from .frozen import CLIPTextModel
+    from .text import CLIPTextModel as NativeCLIPTextModel
     from .models.unet_2d_condition import UNet2DConditionModel
     from .trainer import E4TTrainer
 
@@ -33,7 +34,7 @@ def run(dev, verbose=True):
     n_enc = E4TEncoder(word_embedding_dim=64, block_out_channels=BOC, arch="ViT-tiny-test", n_odd_layers=3)
     n_enc.load_state_dict(r_enc.state_dict())
     n_unet.to(dev); n_enc.to(dev)
-    text_d = CLIPTextModel(**TEXT_CFG).requires_grad_(False)
+    text_d = NativeCLIPTextModel(**TEXT_CFG).requires_grad_(False)      # text encoder on the HIP kernels too
     text_d.load_state_dict(text.state_dict())
     text_d.to(dev)
 

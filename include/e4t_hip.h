@@ -101,11 +101,11 @@ int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream);
  * Replaces cross_attention.py:521-531 (SDPA), :222-251,313-314 (math), :473-481 (xFormers). */
 int e4t_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int B, int H, int T, int S, int DH,
                       int ldq, int ldk, int ldv, int ldo, long long bq, long long bk, long long bv, long long bo,
-                      float scale, e4t_stream stream);
+                      float scale, int causal /* keys > query masked (CLIP text encoder) */, e4t_stream stream);
 /* delta_ws: fp32 [B][H][T] scratch.  dQ/dK/dV share the layout (strides) of Q/K/V; dO that of O. */
 int e4t_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                       float* delta_ws, void* dQ, void* dK, void* dV, int B, int H, int T, int S, int DH, int ldq, int ldk,
-                      int ldv, int ldo, long long bq, long long bk, long long bv, long long bo, float scale,
+                      int ldv, int ldo, long long bq, long long bk, long long bv, long long bo, float scale, int causal,
                       e4t_stream stream);
 
 /* ---------------------------------------------------------------- norms (norm.hip) ----------- */
@@ -183,6 +183,8 @@ int e4t_geglu_bwd(const void* u, const void* dh, void* du, long long M, int H, e
 #define E4T_OP_GELU_BWD 3
 #define E4T_OP_LRELU 4
 #define E4T_OP_LRELU_BWD 5
+#define E4T_OP_QGELU 6      /* x * sigmoid(1.702 x): CLIPTextModel hidden_act of SD-1.x (modeling_clip.py via transformers) */
+#define E4T_OP_QGELU_BWD 7
 int e4t_unary(const void* x, const void* dy, void* y, long long n, int op, e4t_stream stream);
 int e4t_add(const void* a, const void* b, void* y, long long n, e4t_stream stream);
 int e4t_transpose(const void* in, void* out, int batch, int R, int C, int ldi, int ldo, long long bsi, long long bso, e4t_stream stream);

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 bf16, f32 = torch.bfloat16, torch.float32
 CONV_S1, CONV_S2, CONV_UP2, CONV_S2T = 1, 2, 3, 4
-OP_SILU, OP_SILU_BWD, OP_GELU, OP_GELU_BWD, OP_LRELU, OP_LRELU_BWD = range(6)
+OP_SILU, OP_SILU_BWD, OP_GELU, OP_GELU_BWD, OP_LRELU, OP_LRELU_BWD, OP_QGELU, OP_QGELU_BWD = range(8)
 
 
 def _dsilu(x):
@@ -131,9 +131,16 @@ class EmuBackend:
     def _heads(t, B, L, H, DH):
         return t[:, : H * DH].float().reshape(B, L, H, DH).permute(0, 2, 1, 3)
 
-    def attention_fwd(self, q, k, v, B, H, T, S, DH, scale, out=None, need_lse=True):
+    @staticmethod
+    def _causal(s, causal):
+        if causal:
+            T, S = s.shape[-2:]
+            s = s.masked_fill(torch.arange(S, device=s.device)[None, :] > torch.arange(T, device=s.device)[:, None], float("-inf"))
+        return s
+
+    def attention_fwd(self, q, k, v, B, H, T, S, DH, scale, out=None, need_lse=True, causal=False):
         Q, K, V = self._heads(q, B, T, H, DH), self._heads(k, B, S, H, DH), self._heads(v, B, S, H, DH)
-        s = (Q @ K.transpose(-1, -2)) * scale
+        s = self._causal((Q @ K.transpose(-1, -2)) * scale, causal)
         lse = torch.logsumexp(s, dim=-1) / math.log(2.0)      # log2 units, as the kernel stores it
         o = (torch.softmax(s, dim=-1) @ V).permute(0, 2, 1, 3).reshape(B * T, H * DH)
         o = self._act(o)
@@ -142,11 +149,11 @@ class EmuBackend:
             o = out
         return o, (lse if need_lse else None)
 
-    def attention_bwd(self, q, k, v, o, do, lse, dq, dk, dv, B, H, T, S, DH, scale):
+    def attention_bwd(self, q, k, v, o, do, lse, dq, dk, dv, B, H, T, S, DH, scale, causal=False):
         Q, K, V = self._heads(q, B, T, H, DH), self._heads(k, B, S, H, DH), self._heads(v, B, S, H, DH)
         dO = self._heads(do, B, T, H, DH)
         O = self._heads(o, B, T, H, DH)
-        s = (Q @ K.transpose(-1, -2)) * scale
+        s = self._causal((Q @ K.transpose(-1, -2)) * scale, causal)
         P = torch.exp2(s / math.log(2.0) - lse[..., None])
         dV = P.transpose(-1, -2) @ dO
         dP = dO @ V.transpose(-1, -2)
@@ -250,8 +257,13 @@ class EmuBackend:
             y = d * _dgelu(xf)
         elif op == OP_LRELU:
             y = F.leaky_relu(xf, 0.01)
-        else:
+        elif op == OP_LRELU_BWD:
             y = torch.where(xf > 0, d, 0.01 * d)
+        elif op == OP_QGELU:
+            y = xf * torch.sigmoid(1.702 * xf)
+        else:
+            sg = torch.sigmoid(1.702 * xf)
+            y = d * sg * (1 + 1.702 * xf * (1 - sg))
         return self._act(y)
 
     def add(self, a, b):

@@ -144,11 +144,13 @@ def check_conv(hip, emu, dev):
 
 def check_attention(hip, emu, dev):
     out = []
-    cases = [  # B, H, T, S, DH
+    cases = [  # B, H, T, S, DH (, causal)
         (2, 2, 64, 64, 32), (2, 3, 200, 200, 40), (1, 2, 128, 77, 40), (2, 2, 96, 77, 80), (1, 2, 64, 64, 160),
         (1, 2, 257, 257, 80), (2, 2, 130, 33, 64), (1, 8, 1024, 1024, 40),
+        (3, 12, 77, 77, 64, True), (2, 3, 200, 200, 40, True), (1, 2, 128, 128, 80, True),      # causal: CLIP text encoder
     ]
-    for i, (B, H, T, S, DH) in enumerate(cases):
+    for i, case in enumerate(cases):
+        (B, H, T, S, DH), causal = case[:5], (len(case) > 5 and case[5])
         g = gen(90 + i, dev)
         d = H * DH
         # q, k, v as column slices of fused buffers (self-attn layout) when T == S, separate otherwise
@@ -166,14 +168,14 @@ def check_attention(hip, emu, dev):
             dkv_h, dkv_e = torch.zeros_like(kv), torch.zeros_like(kv)
             gh = (dq_h, dkv_h[:, :d], dkv_h[:, d:]); ge = (dq_e, dkv_e[:, :d], dkv_e[:, d:])
         scale = DH ** -0.5
-        o, lse = hip.attention_fwd(q, k, v, B, H, T, S, DH, scale)
-        o_r, lse_r = emu.attention_fwd(q, k, v, B, H, T, S, DH, scale)
-        tag = f"attn B{B} H{H} T{T} S{S} dh{DH}"
+        o, lse = hip.attention_fwd(q, k, v, B, H, T, S, DH, scale, causal=causal)
+        o_r, lse_r = emu.attention_fwd(q, k, v, B, H, T, S, DH, scale, causal=causal)
+        tag = f"attn B{B} H{H} T{T} S{S} dh{DH}" + (" causal" if causal else "")
         out.append((tag + " fwd O", rel(o, o_r), TOL2))
         out.append((tag + " fwd LSE", rel(lse, lse_r), 1e-3))
         do = rnd(g, B * T, d, dev=dev)
-        hip.attention_bwd(q, k, v, o, do, lse, gh[0], gh[1], gh[2], B, H, T, S, DH, scale)
-        emu.attention_bwd(q, k, v, o_r, do, lse_r, ge[0], ge[1], ge[2], B, H, T, S, DH, scale)
+        hip.attention_bwd(q, k, v, o, do, lse, gh[0], gh[1], gh[2], B, H, T, S, DH, scale, causal=causal)
+        emu.attention_bwd(q, k, v, o_r, do, lse_r, ge[0], ge[1], ge[2], B, H, T, S, DH, scale, causal=causal)
         for nm, a, b in zip(("dQ", "dK", "dV"), gh, ge):
             out.append((tag + " bwd " + nm, rel(a, b), TOL2))
     # peaked scores: one key dominates (exercises the online-softmax rescale with large max jumps)
@@ -249,7 +251,7 @@ def check_streaming(hip, emu, dev):
     out.append(("geglu fwd", rel(hip.geglu_fwd(u), emu.geglu_fwd(u)), TOL1))
     out.append(("geglu bwd", rel(hip.geglu_bwd(u, dh), emu.geglu_bwd(u, dh)), TOL1))
     x, dy = rnd(g, 64, 1280, dev=dev), rnd(g, 64, 1280, dev=dev)
-    for op in range(6):
+    for op in range(8):
         out.append((f"unary op{op}", rel(hip.unary(x, op, dy if op & 1 else None), emu.unary(x, op, dy if op & 1 else None)), TOL1))
     out.append(("add", rel(hip.add(x, dy), emu.add(x, dy)), TOL1))
     t = rnd(g, 130, 72, dev=dev)
