@@ -154,6 +154,7 @@ def main():
     if rank == 0 and not args.no_kernel_roofline:
         # one extra, instrumented step (outside the timed region): HIP events around every MFMA-kernel launch
         hip.prof = []
+        tr.overlap_vision = False      # per-kernel durations must not include a concurrently running side stream
         tr.train_step(*batch(10_000))
         torch.cuda.synchronize()
         agg = {}
