@@ -499,9 +499,13 @@ __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * g + j;
           pr[r] = fast_exp2(s[r] * p.scale2 - lq[j]);
-          if (p.causal && q0 + sub * 32 + 8 * g + 4 * hi + j < key) pr[r] = 0.f;      // query before this lane's key
           ds[r] = pr[r] * (dp[r] - dq[j]);
         }
+      }
+      if (p.causal) {                      // (CLIP text encoder only; kept out of the unmasked loop above)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (q0 + sub * 32 + acc_row(r, hi) < key) { pr[r] = 0.f; ds[r] = 0.f; }       // query before this lane's key
       }
       const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);
       const bf16x8 sf0 = pack_acc(ds, 0), sf1 = pack_acc(ds, 1);
