@@ -65,6 +65,7 @@ struct GemmArgs {
   int reduce_batch; // partials of all (batch, split) pairs are summed into ONE C
   int fast_epi;     // bf16 C, 16-byte aligned rows: LDS-staged vectorised epilogue
   long long strideA, strideB, strideC, strideBias;
+  float* colstats;                       // optional [M/32][N][2] column statistics of the output (fast bf16 epilogue only)
   unsigned a_bytes, a2_bytes, b_bytes;   // operand extents from the (batch-adjusted) base pointers, for buffer resources (pp kernel)
 };
 
@@ -138,8 +139,32 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][
 #pragma unroll
           for (int k = 0; k < 8; ++k) a[k] += b[k];
           v = pack8(a);
+          if (p.colstats) *(uint4*)(stage + rl * ELD + cch * 8) = v;      // the statistics are those of the FINAL values
         }
         *(uint4*)(Cb + (size_t)row * p.ldc + col) = v;
+      }
+    }
+    if (p.colstats) {
+      // Per-column (sum, sum of squares) of this wave's output rows, one record per 32-row block: the GroupNorm that consumes
+      // this tensor reduces these few floats instead of re-reading the whole activation (norm.hip, gn_finalize_cols_kernel).
+      // The wave reads back its own staged (bf16, final) tile; LDS operations of one wave execute in order.
+#pragma unroll
+      for (int c0 = 0; c0 < WN; c0 += 64) {
+        const int cl = c0 + lane, col = nw + cl;
+        if (cl < WN && col < p.N) {
+#pragma unroll
+          for (int rb = 0; rb < WM / 32; ++rb) {
+            if (mw + rb * 32 >= p.M) break;                               // M % 32 == 0 whenever statistics are requested
+            float sm = 0.f, sq = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+              const float x = bf2f(stage[(rb * 32 + r) * ELD + cl]);
+              sm += x; sq += x * x;
+            }
+            float* o = p.colstats + ((size_t)((mw >> 5) + rb) * p.N + col) * 2;
+            o[0] = sm; o[1] = sq;
+          }
+        }
       }
     }
     return;
@@ -1092,6 +1117,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   p.group_m = gm_env;
   p.fast_epi = !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                (p.strideC % 8 == 0) && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
+  if (p.colstats && (p.ws || !p.fast_epi || p.M % 32 != 0 || batch != 1)) p.colstats = nullptr;   // only the bf16 single-pass epilogue produces them
+  const int stats_written = p.colstats != nullptr;
   dim3 grid(gx, gy, splitk * batch), block(256);
   static const bool use_dma = getenv("E4T_GEMM_REGSTAGE") == nullptr;   // A/B switch: register-staged reference kernel
   if (use_dma && buf_ok) {
@@ -1132,7 +1159,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, p.reduce_batch ? 1 : batch), dim3(256), 0, st, p, nz);
     E4T_CHECK_LAUNCH("splitk_reduce_kernel");
   }
-  return 0;
+  return (use_dma && buf_ok) ? stats_written : 0;
 }
 
 }  // namespace
@@ -1158,6 +1185,7 @@ extern "C" int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream) {
   p.M = d->M; p.N = d->N; p.K = d->K; p.alpha = d->alpha; p.flags = d->flags; p.ws = (float*)d->workspace;
   p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.strideBias = d->strideBias;
   p.reduce_batch = (d->flags & E4T_REDUCE_BATCH) ? 1 : 0;
+  p.colstats = d->colstats;
   return launch_gemm(p, false, d->tile, d->workspace_bytes, d->splitk, batch, (hipStream_t)stream);
 }
 
@@ -1231,5 +1259,6 @@ extern "C" int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream) {
   p.mode = mode; p.B = (const bf16_t*)d->W; p.ldb = 9 * Cin; p.C = d->Y; p.ldc = Cout; p.bias = d->bias;
   p.residual = d->residual; p.ldr = Cout; p.rowbias = d->rowbias; p.rows_per_batch = Hout * Wout; p.ldrb = d->ldrb > 0 ? d->ldrb : Cout;
   p.M = d->B * Hout * Wout; p.N = Cout; p.K = 9 * Cin; p.alpha = 1.f; p.flags = d->flags; p.ws = (float*)d->workspace;
+  p.colstats = d->colstats;
   return launch_gemm(p, true, d->tile, d->workspace_bytes, d->splitk, 1, (hipStream_t)stream);
 }

@@ -154,13 +154,13 @@ __device__ __forceinline__ void gn_block_sum_partials(const float* partial_b /* 
 template <bool FUSED>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNSrc s, const float* mean_rstd, const float* gamma, const float* beta,
                                                        bf16_t* y, int HW, int G, int pix_per_chunk, int silu,
-                                                       const float* partial, float inv_n, float eps, float* mean_rstd_out) {
+                                                       const float* partial, int npart, float inv_n, float eps, float* mean_rstd_out) {
   const int C = s.C1 + s.C2, cpg = C / G;
   const GNMap m(C);
   const int b = blockIdx.y;
   __shared__ float mr_lds[FUSED ? 512 : 2];
   if (FUSED) {
-    gn_block_sum_partials(partial + (size_t)b * gridDim.x * G * 2, gridDim.x, G, [&](int g, double sm, double sq) {
+    gn_block_sum_partials(partial + (size_t)b * npart * G * 2, npart, G, [&](int g, double sm, double sq) {
       const double mean = sm * inv_n;
       double var = sq * inv_n - mean * mean;
       if (var < 0.0) var = 0.0;
@@ -497,7 +497,58 @@ extern "C" int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C
   const int ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch);
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
   hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ch, Bn), dim3(256), 0, (hipStream_t)stream, s, mean_rstd, gamma, beta, (bf16_t*)y, HW, G, ppc,
-                     silu, (const float*)nullptr, 0.f, 0.f, (float*)nullptr);
+                     silu, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr);
+  E4T_CHECK_LAUNCH("gn_apply_kernel");
+  return 0;
+}
+
+// Chunk partials (the format gn_stats_kernel writes: partial[b][chunk][g][2]) from the column statistics the producing GEMM /
+// conv epilogue left behind (gemm.hip, write_tile): cs[blk][c][2] = (sum, sum of squares) of channel c over the 32 pixels of
+// block blk.  One workgroup per (chunk of 32-pixel blocks, batch entry): thread t owns columns t, t+256, ...; a few KB .. MB of
+// statistics are read instead of a pass over the whole activation.  Deterministic (fixed summation order).
+namespace {
+__global__ __launch_bounds__(256) void gn_stats_cols_kernel(const float* cs1, int C1, const float* cs2, int C2, int nblk_img, int blk_per_chunk,
+                                                            int G, float* partial) {
+  extern __shared__ float lds[];            // [C][2] column totals of this chunk
+  const int C = C1 + C2, cpg = C / G;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const size_t rb0 = (size_t)b * nblk_img + (size_t)chunk * blk_per_chunk;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float* src = c < C1 ? cs1 + (rb0 * C1 + c) * 2 : cs2 + (rb0 * C2 + (c - C1)) * 2;
+    const size_t stride = (size_t)(c < C1 ? C1 : C2) * 2;
+    float sm = 0.f, sq = 0.f;
+    for (int k = 0; k < blk_per_chunk; ++k) {
+      const float2 v = *(const float2*)(src + k * stride);
+      sm += v.x; sq += v.y;
+    }
+    lds[c * 2] = sm; lds[c * 2 + 1] = sq;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    float ta = 0.f, tb = 0.f;
+    for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) { ta += lds[c * 2]; tb += lds[c * 2 + 1]; }
+    float* o = partial + (((size_t)b * gridDim.x + chunk) * G + threadIdx.x) * 2;
+    o[0] = ta; o[1] = tb;
+  }
+}
+}  // namespace
+
+extern "C" int e4t_groupnorm_fwd_cs(const void* x1, int C1, const float* cs1, const void* x2, int C2, const float* cs2, const float* gamma,
+                                    const float* beta, void* y, float* mean_rstd, int Bn, int HW, int G, float eps, int silu,
+                                    void* workspace, size_t ws_bytes, e4t_stream stream) {
+  if (int e = gn_check(x1, C1, x2, C2, Bn, HW, G)) return e;
+  E4T_REQUIRE(cs1 && ((cs2 != nullptr) == (C2 > 0)) && gamma && beta && y && mean_rstd && HW % 32 == 0, "groupnorm_fwd_cs: bad arguments");
+  const int C = C1 + C2, ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch), nblk = HW / 32;
+  const int npart = ch < nblk ? ch : nblk;                   // chunks of whole 32-pixel blocks
+  E4T_REQUIRE(nblk % npart == 0, "groupnorm_fwd_cs: %d blocks do not split into %d chunks", nblk, npart);
+  E4T_REQUIRE(workspace && ws_bytes >= (size_t)Bn * npart * G * 2 * sizeof(float), "groupnorm_fwd_cs: workspace too small");
+  GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_cols_kernel, dim3(npart, Bn), dim3(256), (size_t)C * 2 * sizeof(float), st, cs1, C1, cs2, C2, nblk, nblk / npart, G,
+                     (float*)workspace);
+  E4T_CHECK_LAUNCH("gn_stats_cols_kernel");
+  hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
+                     (const float*)workspace, npart, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
   E4T_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
 }
@@ -514,7 +565,7 @@ extern "C" int e4t_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2,
   hipLaunchKernelGGL(gn_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
   E4T_CHECK_LAUNCH("gn_stats_kernel");
   hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
-                     (const float*)workspace, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
+                     (const float*)workspace, ch, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
   E4T_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
 }

@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
         ("lda", i32), ("lda2", i32), ("ldb", i32), ("ldc", i32), ("ldr", i32),
         ("rows_per_batch", i32), ("flags", i32), ("tile", i32), ("splitk", i32), ("batch", i32),
         ("strideA", i64), ("strideB", i64), ("strideC", i64), ("strideBias", i64),
-        ("alpha", f32), ("ldrb", i32),
+        ("alpha", f32), ("ldrb", i32), ("colstats", vp),
     ]
 
 
@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("X", vp), ("W", vp), ("Y", vp), ("bias", vp), ("residual", vp), ("rowbias", vp),
         ("workspace", vp), ("workspace_bytes", sz),
         ("B", i32), ("Hin", i32), ("Win", i32), ("Cin", i32), ("Hout", i32), ("Wout", i32), ("Cout", i32),
-        ("mode", i32), ("flags", i32), ("tile", i32), ("splitk", i32), ("ldrb", i32),
+        ("mode", i32), ("flags", i32), ("tile", i32), ("splitk", i32), ("ldrb", i32), ("colstats", vp),
     ]
 
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "e4t_groupnorm_stats": (i32, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, sz, vp]),
     "e4t_groupnorm_apply": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "e4t_groupnorm_fwd": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, sz, vp]),
+    "e4t_groupnorm_fwd_cs": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, sz, vp]),
     "e4t_groupnorm_bwd": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "e4t_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "e4t_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
@@ -122,7 +123,9 @@ def load():
     return lib
 
 
-def check(code: int, what: str):
-    if code != 0:
-        msg = load().e4t_last_error()
-        raise E4TError(f"{what} failed ({code}): {msg.decode() if msg else '?'}")
+def check(code: int, what: str) -> int:
+    """negative = error (raises); 0 / positive = success (a few entry points return a positive status, e.g. 'colstats written')"""
+    if code >= 0:
+        return code
+    msg = load().e4t_last_error()
+    raise E4TError(f"{what} failed ({code}): {msg.decode() if msg else '?'}")

@@ -27,10 +27,11 @@ class PreparedLinear:
     """bf16 [N,K] and transposed [K,N] copies of an fp32 nn.Linear / 1x1-conv weight.
     Re-cast only when the master weight changed (frozen weights: exactly once)."""
 
-    def __init__(self, weight: torch.nn.Parameter):
+    def __init__(self, weight: torch.nn.Parameter, colstats: bool = False):
         self.weight = weight
         self.key = None
         self.w = self.wT = None
+        self.colstats = colstats       # the layer's output feeds a GroupNorm: let the GEMM epilogue leave column statistics behind
 
     def get(self):
         wt = self.weight
@@ -121,7 +122,7 @@ class LinearFn(torch.autograd.Function):
         w, wT = prep.get()
         K = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
         wv = w[:, :K] if w.shape[1] != K else w
-        y = be.gemm(x, wv, a2=x2, bias=bias, residual=residual, gelu=gelu, out_dtype=f32 if out_f32 else act_dtype())
+        y = be.gemm(x, wv, a2=x2, bias=bias, residual=residual, gelu=gelu, out_dtype=f32 if out_f32 else act_dtype(), colstats=prep.colstats)
         ctx.prep, ctx.gelu = prep, gelu
         ctx.bias_param = bias if (bias is not None and bias.requires_grad and bias.is_leaf) else None
         ctx.N = weight.shape[0]
@@ -248,8 +249,9 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, rowbias, residual, prep: PreparedConv, geom, mode: int, out_f32: bool):
         B, Hin, Win, Hout, Wout = geom
         wf, _ = prep.get()
+        # every bf16 3x3-conv output of the UNet feeds a GroupNorm: the epilogue leaves its column statistics behind
         y = ops.backend().conv3x3(x, wf, B, Hin, Win, Hout, Wout, mode, bias=bias, rowbias=rowbias, residual=residual,
-                                  out_dtype=f32 if out_f32 else act_dtype())
+                                  out_dtype=f32 if out_f32 else act_dtype(), colstats=not out_f32)
         ctx.prep, ctx.geom, ctx.mode = prep, geom, mode
         ctx.cin = x.shape[1]
         ctx.has = (bias is not None, rowbias is not None, residual is not None)

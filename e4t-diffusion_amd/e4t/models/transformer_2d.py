@@ -31,7 +31,8 @@ class Transformer2DModel(nn.Module):
             BasicTransformerBlock(inner, num_attention_heads, attention_head_dim, dropout=dropout,
                                   cross_attention_dim=cross_attention_dim, only_cross_attention=only_cross_attention,
                                   upcast_attention=upcast_attention) for _ in range(num_layers)])
-        self._pin, self._pout = Fn.PreparedLinear(self.proj_in.weight), Fn.PreparedLinear(self.proj_out.weight)
+        # proj_out's output is the next ResBlock's GroupNorm input: its GEMM epilogue leaves the column statistics behind
+        self._pin, self._pout = Fn.PreparedLinear(self.proj_in.weight), Fn.PreparedLinear(self.proj_out.weight, colstats=True)
 
     def forward_nhwc(self, m: FMap, ctx, prefix=None) -> FMap:
         B, HW = m.B, m.H * m.W

@@ -157,9 +157,16 @@ class HipBackend:
             self._ws[key] = ws
         return ws
 
+    @staticmethod
+    def _colstats_buf(out, M, N, wanted):
+        """fp32 [M/32, N, 2] buffer for the epilogue's per-32-row column statistics (None when not applicable)."""
+        if not wanted or out.dtype != bf16 or M % 32 or not out.is_contiguous():
+            return None
+        return torch.empty((M // 32, N, 2), dtype=f32, device=out.device)
+
     # ------------------------------------------------------------------ GEMM
     def gemm(self, a, b, *, a2=None, bias=None, residual=None, rowbias=None, rows_per_batch=0, out=None,
-             out_dtype=bf16, gelu=False, accum=False, alpha=1.0, reduce_batch=False, tile=0, splitk=0):
+             out_dtype=bf16, gelu=False, accum=False, alpha=1.0, reduce_batch=False, tile=0, splitk=0, colstats=False):
         batched = a.dim() == 3
         _rowmajor(a, "gemm A"); _rowmajor(b, "gemm B")
         if batched:
@@ -204,8 +211,12 @@ class HipBackend:
         ws = self.workspace(need, a.device) if need else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
-        self._timed(f"gemm{self._tile(M, N, K, nb, tile)}", 2.0 * M * N * K * nb,
-                    lambda: _C.check(self.lib.e4t_gemm_nt(C.byref(d), st), "e4t_gemm_nt"))
+        cs = self._colstats_buf(out, M, N, colstats and not batched)
+        d.colstats = _ptr(cs)
+        rc = self._timed(f"gemm{self._tile(M, N, K, nb, tile)}", 2.0 * M * N * K * nb,
+                         lambda: _C.check(self.lib.e4t_gemm_nt(C.byref(d), st), "e4t_gemm_nt"))
+        if cs is not None and rc == 1:
+            out._e4t_colstats = cs          # consumed by groupnorm_fwd (the GroupNorm of this activation skips its statistics pass)
         return out
 
     def gemm_tn(self, a, b, *, out=None, out_dtype=f32, accum=False, alpha=1.0, splitk=0):
@@ -234,7 +245,7 @@ class HipBackend:
         return out
 
     # ------------------------------------------------------------------ conv
-    def conv3x3(self, x, w, B, Hin, Win, Hout, Wout, mode, *, bias=None, residual=None, rowbias=None, out=None,
+    def conv3x3(self, x, w, B, Hin, Win, Hout, Wout, mode, *, colstats=False, bias=None, residual=None, rowbias=None, out=None,
                 out_dtype=bf16, accum=False, tile=0, splitk=0):
         Cin, Cout = x.shape[-1], w.shape[0]
         assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == 9 * Cin
@@ -257,8 +268,12 @@ class HipBackend:
         ws = self.workspace(need, x.device) if need else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
-        self._timed(f"conv{self._tile(M, Cout, 9 * Cin, 1, tile, conv=True)}", 2.0 * M * Cout * 9 * Cin,
-                    lambda: _C.check(self.lib.e4t_conv3x3(C.byref(d), st), "e4t_conv3x3"))
+        cs = self._colstats_buf(out, M, Cout, colstats)
+        d.colstats = _ptr(cs)
+        rc = self._timed(f"conv{self._tile(M, Cout, 9 * Cin, 1, tile, conv=True)}", 2.0 * M * Cout * 9 * Cin,
+                         lambda: _C.check(self.lib.e4t_conv3x3(C.byref(d), st), "e4t_conv3x3"))
+        if cs is not None and rc == 1:
+            out._e4t_colstats = cs
         return out
 
     def conv_weight_prepare(self, w_oihw, Ipad=None, Opad=None, want_fwd=True, want_dgrad=True):
@@ -306,6 +321,14 @@ class HipBackend:
         nb = self.lib.e4t_groupnorm_workspace_bytes(B, HW, Cn, G, 0)
         ws = self.workspace(nb, x1.device)
         y = torch.empty((B * HW, Cn), dtype=bf16, device=x1.device)
+        cs1 = getattr(x1, "_e4t_colstats", None)
+        cs2 = getattr(x2, "_e4t_colstats", None) if x2 is not None else None
+        nblk, nch = HW // 32, self.lib.e4t_groupnorm_num_chunks(B, HW)
+        if cs1 is not None and (x2 is None or cs2 is not None) and HW % 32 == 0 and nblk % min(nch, nblk) == 0:
+            # the producers left per-32-row column statistics behind: no statistics pass over the activation(s)
+            _C.check(self.lib.e4t_groupnorm_fwd_cs(_ptr(x1), C1, _ptr(cs1), _ptr(x2), C2, _ptr(cs2), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats),
+                                                   B, HW, G, float(eps), int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_fwd_cs")
+            return y, stats
         _C.check(self.lib.e4t_groupnorm_fwd(_ptr(x1), C1, _ptr(x2), C2, _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), B, HW, G, float(eps),
                                             int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_fwd")
         return y, stats

@@ -67,10 +67,10 @@ class VAEEncoder(_TorchVAEEncoder):
     @staticmethod
     def _res(be, x, B, H, W, p):
         h, _ = be.groupnorm_fwd(x, None, p["n1"][0], p["n1"][1], B, H * W, 32, 1e-6, True)
-        h = be.conv3x3(h, p["c1"][0], B, H, W, H, W, _C.CONV_S1, bias=p["c1"][1])
+        h = be.conv3x3(h, p["c1"][0], B, H, W, H, W, _C.CONV_S1, bias=p["c1"][1], colstats=True)
         h, _ = be.groupnorm_fwd(h, None, p["n2"][0], p["n2"][1], B, H * W, 32, 1e-6, True)
         s = x if p["sc"] is None else be.gemm(x, p["sc"][0], bias=p["sc"][1])
-        return be.conv3x3(h, p["c2"][0], B, H, W, H, W, _C.CONV_S1, bias=p["c2"][1], residual=s)
+        return be.conv3x3(h, p["c2"][0], B, H, W, H, W, _C.CONV_S1, bias=p["c2"][1], residual=s, colstats=True)
 
     @torch.no_grad()
     def moments(self, x):
@@ -81,13 +81,13 @@ class VAEEncoder(_TorchVAEEncoder):
         a = be.im2col3_rgb(x)
         if a.dtype != ops.ACT:
             a = a.to(ops.ACT)
-        h = be.gemm(a, c["conv_in"][0], bias=c["conv_in"][1])
+        h = be.gemm(a, c["conv_in"][0], bias=c["conv_in"][1], colstats=True)      # (every GroupNorm input below carries column statistics)
         for blk in c["down"]:
             for r in blk["res"]:
                 h = self._res(be, h, B, H, W, r)
             if blk["ds"] is not None:
                 Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
-                h = be.conv3x3(h, blk["ds"][0], B, H, W, Ho, Wo, _C.CONV_S2A, bias=blk["ds"][1])
+                h = be.conv3x3(h, blk["ds"][0], B, H, W, Ho, Wo, _C.CONV_S2A, bias=blk["ds"][1], colstats=True)
                 H, W = Ho, Wo
         m = c["mid"]
         h = self._res(be, h, B, H, W, m["r0"])
@@ -100,7 +100,7 @@ class VAEEncoder(_TorchVAEEncoder):
         be.softmax_rows_(s)
         vt = torch.stack([be.transpose(v[b]) for b in range(B)])                   # [B, C, T]
         o = be.gemm(s, vt).view(B * T, Cw)
-        h = be.gemm(o, m["proj"][0], bias=m["proj"][1], residual=h)
+        h = be.gemm(o, m["proj"][0], bias=m["proj"][1], residual=h, colstats=True)
         h = self._res(be, h, B, H, W, m["r1"])
         n, _ = be.groupnorm_fwd(h, None, c["norm_out"][0], c["norm_out"][1], B, T, 32, 1e-6, True)
         y = be.conv3x3(n, c["conv_out"][0], B, H, W, H, W, _C.CONV_S1, bias=c["conv_out"][1])      # [B*T, 8]

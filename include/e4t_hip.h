@@ -62,7 +62,11 @@ typedef struct {
   long long strideA, strideB, strideC, strideBias;
   float alpha;
   int ldrb;            /* row stride of rowbias (elements); 0 = N */
+  float* colstats;     /* optional out: fp32 [M/32][N][2] = per 32-row block (sum, sum of squares) of every output column, for the
+                          GroupNorm that consumes C (e4t_groupnorm_fwd_cs).  Produced only by the single-pass bf16 epilogue
+                          (M % 32 == 0, batch 1, no split-K): the call returns 1 when it was written, 0 otherwise */
 } e4t_gemm_desc;
+/* returns 0 (or 1, see colstats) on success, a negative errno-style code on error */
 int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream);
 /* C[M,N] = epi(alpha * A^T . B) with A = bf16 [K][lda >= M], B = bf16 [K][ldb >= N]: the contraction runs over the ROWS of both
  * operands — the weight gradient dW = dY^T . X of every linear layer (autograd of cross_attention.py:506-518, attention.py:376,419,
@@ -92,6 +96,7 @@ typedef struct {
   int mode, flags, tile, splitk;
   int ldrb;            /* row stride of rowbias (elements); 0 = Cout.  Lets all ResBlocks' time-embedding projections
                           live in one (B, sum Cout) matrix produced by a single GEMM */
+  float* colstats;     /* optional out, as in e4t_gemm_desc (M = B*Hout*Wout, N = Cout) */
 } e4t_conv_desc;
 int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream);
 
@@ -124,6 +129,11 @@ int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C2, const fl
 int e4t_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta, void* y,
                       float* mean_rstd /* out [B][G][2] */, int B, int HW, int G, float eps, int silu, void* workspace,
                       size_t ws_bytes, e4t_stream stream);
+/* Same result, with the statistics pass replaced by a reduction of the column statistics cs1 / cs2 ([B*HW/32][C1|C2][2]) that the
+ * GEMM / conv which produced x1 / x2 wrote in its epilogue (e4t_gemm_desc.colstats): the activation is read once, not twice. */
+int e4t_groupnorm_fwd_cs(const void* x1, int C1, const float* cs1, const void* x2, int C2, const float* cs2, const float* gamma,
+                         const float* beta, void* y, float* mean_rstd, int B, int HW, int G, float eps, int silu, void* workspace,
+                         size_t ws_bytes /* e4t_groupnorm_workspace_bytes(B, HW, C, G, 0) */, e4t_stream stream);
 /* dx1|dx2 = d/dx of act(GN(x)) given dy, plus the optional gradients that reach x1 / x2 through another consumer (the
  * ResBlock shortcut / residual): add1 bf16 [B*HW][C1], add2 bf16 [B*HW][C2], either may be NULL; optional per-chunk
  * channel partials [B][chunks][C][2] = (sum dz, sum dz*xhat) for dbeta/dgamma. */

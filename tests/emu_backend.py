@@ -43,7 +43,7 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ GEMM
     def gemm(self, a, b, *, a2=None, bias=None, residual=None, rowbias=None, rows_per_batch=0, out=None,
-             out_dtype=bf16, gelu=False, accum=False, alpha=1.0, reduce_batch=False, tile=0, splitk=0):
+             out_dtype=bf16, gelu=False, accum=False, alpha=1.0, reduce_batch=False, tile=0, splitk=0, colstats=False):
         A = a.float()
         if a2 is not None:
             A = torch.cat([A, a2.float()], dim=-1)
@@ -65,8 +65,16 @@ class EmuBackend:
         y = y.to(want) if (want == f32 or self.round) else y
         if out is not None:
             out.copy_(y)
-            return out
+            y = out
+        self._attach_colstats(y, colstats)
         return y
+
+    @staticmethod
+    def _attach_colstats(y, wanted):
+        """what the kernels' epilogue leaves behind: (sum, sum of squares) of every column per 32-row block"""
+        if wanted and y.dim() == 2 and y.shape[0] % 32 == 0:
+            blk = y.detach().float().reshape(y.shape[0] // 32, 32, y.shape[1])
+            y._e4t_colstats = torch.stack([blk.sum(1), (blk * blk).sum(1)], dim=-1).contiguous()
 
     # ------------------------------------------------------------------ conv
     def conv_weight_prepare(self, w_oihw, Ipad=None, Opad=None, want_fwd=True, want_dgrad=True):
@@ -92,7 +100,7 @@ class EmuBackend:
         out.copy_((out.float() + y if accum else y).to(out.dtype))
         return out
 
-    def conv3x3(self, x, w, B, Hin, Win, Hout, Wout, mode, *, bias=None, residual=None, rowbias=None, out=None,
+    def conv3x3(self, x, w, B, Hin, Win, Hout, Wout, mode, *, colstats=False, bias=None, residual=None, rowbias=None, out=None,
                 out_dtype=bf16, accum=False, tile=0, splitk=0):
         Cin, Cout = x.shape[-1], w.shape[0]
         xi = x.float().reshape(B, Hin, Win, Cin).permute(0, 3, 1, 2)
@@ -123,7 +131,8 @@ class EmuBackend:
         y = y.to(want) if (want == f32 or self.round) else y
         if out is not None:
             out.copy_(y)
-            return out
+            y = out
+        self._attach_colstats(y, colstats)
         return y
 
     # ------------------------------------------------------------------ attention
@@ -173,6 +182,14 @@ class EmuBackend:
         xg = x.reshape(B, HW, G, Cn // G)
         mean = xg.mean(dim=(1, 3))
         var = xg.var(dim=(1, 3), unbiased=False)
+        cs1, cs2 = getattr(x1, "_e4t_colstats", None), (getattr(x2, "_e4t_colstats", None) if x2 is not None else None)
+        if cs1 is not None and (x2 is None or cs2 is not None) and HW % 32 == 0:
+            # the product takes mean / var from the producers' column statistics: they must describe THIS tensor
+            self.colstats_hits = getattr(self, "colstats_hits", 0) + 1
+            cs = cs1 if cs2 is None else torch.cat([cs1, cs2], dim=1)
+            t = cs.reshape(B, HW // 32, G, Cn // G, 2).sum(dim=(1, 3)) / float(HW * (Cn // G))
+            torch.testing.assert_close(t[..., 0], mean, rtol=1e-3, atol=1e-4)
+            torch.testing.assert_close(t[..., 1] - t[..., 0] ** 2, var, rtol=1e-2, atol=1e-4)
         rstd = torch.rsqrt(var + eps)
         xh = (xg - mean[:, None, :, None]) * rstd[:, None, :, None]
         y = xh.reshape(B * HW, Cn) * gamma.float() + beta.float()

@@ -77,6 +77,16 @@ def check_gemm(hip, emu, dev):
     wide = torch.zeros(320, 700, dtype=f32, device=dev); wide2 = wide.clone()
     hip.gemm_tn(a, b, out=wide[:, 100:428]); emu.gemm_tn(a, b, out=wide2[:, 100:428])
     out.append(("gemm_tn into a column slice", rel(wide, wide2), TOLF * 50))
+    # column statistics left by the epilogue for the consuming GroupNorm (all tile variants; with / without residual)
+    for i, (M, N, K, tile) in enumerate([(256, 128, 128, 0), (4096, 320, 320, 160), (1024, 640, 1280, 128), (2048, 512, 2304, 512), (192, 72, 64, 64)]):
+        g = gen(60 + i, dev)
+        a, b = rnd(g, M, K, dev=dev), rnd(g, N, K, scale=K ** -0.5, dev=dev)
+        res = rnd(g, M, N, dev=dev) if i % 2 == 0 else None
+        y = hip.gemm(a, b, bias=rnd(g, N, dtype=f32, dev=dev), residual=res, tile=tile, splitk=1, colstats=True)
+        cs = getattr(y, "_e4t_colstats", None)
+        blk = y.float().reshape(M // 32, 32, N)
+        ref = torch.stack([blk.sum(1), (blk * blk).sum(1)], dim=-1)
+        out.append((f"gemm {M}x{N}x{K} t{tile} colstats", rel(cs, ref) if cs is not None else 1.0, 1e-5))
     g = gen(30, dev)
     # two-source A, gelu, fp32 out, accumulate, rowbias
     M, N, K1, K2 = 384, 192, 128, 64
@@ -203,6 +213,15 @@ def check_norms(hip, emu, dev):
         tag = f"groupnorm B{B} HW{HW} C{C1}+{C2} silu{int(silu)}"
         out.append((tag + " fwd", rel(y, yr), TOL1))
         out.append((tag + " stats", rel(st, str_), 1e-4))
+        if HW % 32 == 0:       # the same GroupNorm fed with the column statistics a producing GEMM would have left behind
+            def with_cs(t):
+                blk = t.float().reshape(t.shape[0] // 32, 32, t.shape[1])
+                t._e4t_colstats = torch.stack([blk.sum(1), (blk * blk).sum(1)], dim=-1).contiguous()
+                return t
+            x1c, x2c = with_cs(x1.clone()), (with_cs(x2.clone()) if x2 is not None else None)
+            y3, st3 = hip.groupnorm_fwd(x1c, x2c, gamma, beta, B, HW, G, 1e-5, silu)
+            out.append((tag + " via column statistics: y", rel(y3, y), 2e-3))
+            out.append((tag + " via column statistics: stats", rel(st3, st), 1e-4))
         y2, st2 = hip.groupnorm_fwd_unfused(x1, x2, gamma, beta, B, HW, G, 1e-5, silu)
         out.append((tag + " fused == stats/finalize/apply entry points", float((y2 != y).sum() + (st2 != st).sum()), 0.0))
         dy = rnd(g, B * HW, Cn, dev=dev)
