@@ -1094,7 +1094,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
       if (splitk > 8) splitk = 8;
       if (splitk > nkt / 16) splitk = nkt / 16;
       if (tiles > 256 && nkt < 128) splitk = 1;      // the second round only pays on long K (4096x1280x5120: 3 splits +4 %)
-    } else if (tile == 64 && tiles < 256 && nkt >= 64) {
+    } else if (tile == 64 && tiles < 256 && nkt >= 32) {
       splitk = (int)((512 + tiles - 1) / tiles);
       if (splitk > nkt / 16) splitk = nkt / 16;
     }

@@ -72,7 +72,7 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch, conv=False):
             splitk = min((512 if tiles <= 256 else 1024) // tiles, 8, nkt // 16)
             if tiles > 256 and nkt < 128:
                 splitk = 1
-        elif tile == 64 and tiles < 256 and nkt >= 64:
+        elif tile == 64 and tiles < 256 and nkt >= 32:
             splitk = min(cd(512, tiles), nkt // 16)
         splitk = max(splitk, 1)
     splitk = min(splitk, nkt)
