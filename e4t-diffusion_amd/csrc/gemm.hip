@@ -643,15 +643,11 @@ __device__ unsigned long long g_pp_trace[2 * 6 * 64];
 #else
 #define PP_STAMP(slot) do { } while (0)
 #endif
+// timing ablations of the debug trace build (results are garbage): -DPP_NOREAD skips the fragment reads, -DPP_NOWAIT the vmcnt waits
 #ifdef PP_NOREAD
 #define PP_LDSREAD(ptr) bf16x8{}
 #else
 #define PP_LDSREAD(ptr) (*(const bf16x8*)(ptr))
-#endif
-#ifdef PP_DMA1
-#define PP_NJ 1
-#else
-#define PP_NJ 2
 #endif
 template <int MODE>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
@@ -771,14 +767,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     if (fresh) place_a(k0);
     else a_so += HK * 2;
 #pragma unroll
-    for (int j = 0; j < PP_NJ; ++j)
+    for (int j = 0; j < 2; ++j)
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 32 + j * 16) * HK);
   };
   auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
     if (!hi && kt == kt_begin) b_so = kt * BK * 2;
     else b_so += HK * 2;
 #pragma unroll
-    for (int j = 0; j < PP_NJ; ++j)
+    for (int j = 0; j < 2; ++j)
       buf_dma16(rs_b, b_vo[j], b_so, dst + (wave * 32 + j * 16) * HK);
   };
 
