@@ -41,8 +41,16 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_DEV_INDEX = None
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device.  (torch.cuda.current_stream() costs ~9 us of host time per
+    call — 10 ms per training step at ~3500 launches; the raw query is ~0.3 us and still follows `with torch.cuda.stream(...)`.)"""
+    global _DEV_INDEX
+    if _DEV_INDEX is None:
+        _DEV_INDEX = torch.cuda.current_device()      # one process drives one GPU (one rank per device)
+    return torch._C._cuda_getCurrentRawStream(_DEV_INDEX)
 
 
 def _rowmajor(t: torch.Tensor, name: str):
