@@ -33,3 +33,31 @@ def test_version_and_error_plumbing():
     rc = lib.e4t_gemm_nt(d, None)
     assert rc == -22 and b"null operand" in lib.e4t_last_error()
     assert lib.e4t_wo_partial_floats(320, 320) == 10 * 320 * 2 + 10 * 320 + 10 * 320
+
+
+def test_descriptor_structs_match_the_header(tmp_path):
+    """The ctypes mirrors of e4t_gemm_desc / e4t_conv_desc / e4t_wo_desc must have the C compiler's layout: compile the
+    header with gcc and compare sizeof and every field offset."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("gcc not available")
+    structs = {"e4t_gemm_desc": _C.GemmDesc, "e4t_conv_desc": _C.ConvDesc, "e4t_wo_desc": _C.WODesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "e4t_hip.h")}"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, cls in structs.items():
+        assert got[(cname, "sizeof")] == C.sizeof(cls), (cname, got[(cname, "sizeof")], C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
