@@ -470,6 +470,14 @@ class HipBackend:
         _C.check(self.lib.e4t_clip_preprocess(_ptr(pixels), _ptr(out), B, Hin, Win, S, P, Kpad, _stream()), "e4t_clip_preprocess")
         return out
 
+    def image_prep(self, pool, table, B, S, out=None):
+        """raw uint8 RGB images packed in `pool` + int64 [B,8] plan `table` (both on the device) -> fp32 [B,3,S,S]"""
+        assert pool.dtype == torch.uint8 and table.dtype == torch.int64 and table.shape == (B, 8) and table.is_contiguous()
+        if out is None:
+            out = torch.empty((B, 3, S, S), dtype=torch.float32, device=pool.device)
+        _C.check(self.lib.e4t_image_prep(_ptr(pool), _ptr(table), _ptr(out), B, S, _stream()), "e4t_image_prep")
+        return out
+
     def adamw(self, p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
         _C.check(self.lib.e4t_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, grad_scale, _stream()), "e4t_adamw")
 

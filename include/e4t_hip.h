@@ -203,6 +203,12 @@ int e4t_spatial_mean(const void* x, float* out, int B, int HW, int C, int ldo, i
 int e4t_spatial_mean_bwd(const float* g, const void* base, void* dx, int B, int HW, int C, int ldg, int coff, e4t_stream stream);
 int e4t_timestep_embedding(const long long* t, void* out /* bf16 [B][dim] = [cos|sin] */, int B, int dim, e4t_stream stream); /* unet_2d_condition.py:461 */
 int e4t_clip_preprocess(const float* pixels_nchw, void* patches /* bf16 [B*g*g][Kpad] */, int B, int Hin, int Win, int S, int P, int Kpad, e4t_stream stream); /* encoder.py:131-139 + patchify */
+/* Data path (pretrain_e4t.py:137-144 make_transforms = SmallestMaxSize(interpolation=3: cv2.INTER_AREA) -> RandomCrop ->
+ * HorizontalFlip, and :174-177 image/127.5-1, HWC->CHW): a batch of raw decoded uint8 RGB images in one device pool ->
+ * out fp32 [B][3][S][S].  table: int64 [B][8] (device) = {byte offset of the image in pool, H, W, newH, newW (the
+ * SmallestMaxSize dims), crop y0, crop x0 (in the resized image), flip}.  Byte-exact INTER_AREA (area / area-fast /
+ * enlarging fixed-point branches); only the cropped window is computed. */
+int e4t_image_prep(const void* pool, const long long* table, float* out, int B, int S, e4t_stream stream);
 /* in-place row softmax of a bf16 matrix [rows][ld] over the first L columns (fp32 math); L % 8 == 0, L <= 16384 */
 int e4t_softmax_rows(void* x, long long rows, int L, int ld, e4t_stream stream);
 /* 3x3/pad-1 im2col of a 3-channel NCHW fp32 image -> bf16 [B*H*W][32], column (ky*3+kx)*3+c, columns 27..31 zero */

@@ -93,6 +93,40 @@ def synthetic_batches(args, dev, rank, world):
         step += 1
 
 
+def image_batches(args, dev, rank, world):
+    """real images (reference: E4TDataset + DataLoader, pretrain_e4t.py:147-180,284-291) through e4t.data: the host only
+    decodes; SmallestMaxSize(INTER_AREA)/crop/flip/normalise run in one kernel per batch, prefetched under the step"""
+    from e4t.data import DeviceLoader, E4TDataset
+    ds = E4TDataset(args.train_image_dataset, resolution=args.resolution)
+    loader = DeviceLoader(ds, args.train_batch_size, shuffle=True, num_workers=args.dataloader_num_workers, device=dev,
+                          rank=rank, world=world, seed=args.seed or 0)
+    if len(loader) == 0:
+        raise SystemExit(f"{len(ds)} images are fewer than one global batch")
+    tok = None
+    tdir = os.path.join(args.pretrained_model_name_or_path or "", "tokenizer")
+    if os.path.isdir(tdir):
+        from transformers import CLIPTokenizer
+        tok = CLIPTokenizer.from_pretrained(tdir)
+        tok.add_tokens(args.placeholder_token)
+        pid = tok.convert_tokens_to_ids(args.placeholder_token)
+    else:
+        print("no tokenizer directory under --pretrained_model_name_or_path: prompts fall back to fixed-length random token ids")
+    templates = TEMPLATES[args.prompt_template]
+    g = torch.Generator(device=dev).manual_seed((args.seed or 0) * 100003 + rank)
+    B = args.train_batch_size
+    while True:
+        for batch in loader:
+            if tok is not None:
+                prompts = [t.format(placeholder_token=args.placeholder_token) for t in random.choices(templates, k=B)]
+                ids = tok(prompts, padding="max_length", truncation=True, max_length=tok.model_max_length, return_tensors="pt").input_ids
+                pidx = torch.tensor([r.index(pid) for r in ids.tolist()])
+                ids, pidx = ids.to(dev), pidx.to(dev)
+            else:
+                ids = torch.randint(1000, 40000, (B, 77), generator=g, device=dev)
+                pidx = torch.randint(1, 12, (B,), generator=g, device=dev)
+            yield batch["pixel_values"], ids, pidx
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,10 +156,13 @@ def main():
     lr = args.learning_rate * (args.train_batch_size * world if args.scale_lr else 1)
     tr = E4TTrainer(unet, enc, text, vae, lr=lr, domain_embed_scale=args.domain_embed_scale, reg_lambda=args.reg_lambda,
                     prediction_type=args.prediction_type, class_token_id=1125, device=dev)
-    if not args.synthetic_data:
-        raise SystemExit("only --synthetic_data is available in this build: the reference's HF-streaming / webdataset / "
-                         "albumentations loaders (pretrain_e4t.py:137-352) are host-side I/O outside the hot-path scope")
-    data = synthetic_batches(args, dev, rank, world)
+    if args.synthetic_data:
+        data = synthetic_batches(args, dev, rank, world)
+    elif args.train_image_dataset and not (args.webdataset or args.iterable_dataset):
+        data = image_batches(args, dev, rank, world)
+    else:
+        raise SystemExit("give --train_image_dataset <dir[::dir]> (decoded on the host, resized/cropped on the GPU) or "
+                         "--synthetic_data; the webdataset / HF-streaming sources need packages that are not in this image")
 
     def save(step):
         if rank != 0:

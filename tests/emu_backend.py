@@ -312,6 +312,21 @@ class EmuBackend:
         ang = t.float()[:, None] * freq[None]
         return self._act(torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1))
 
+    def image_prep(self, pool, table, B, S, out=None):
+        import numpy as np
+        import image_prep_oracle as ipo
+        pool_np = pool.cpu().numpy()
+        res = []
+        for off, H, W, nH, nW, y0, x0, flip in table.cpu().tolist():
+            img = pool_np[off:off + H * W * 3].reshape(H, W, 3)
+            assert (nH, nW) == ipo.smallest_max_size_dims(H, W, S) or (nH, nW) == (H, W)
+            res.append(torch.from_numpy(ipo.image_prep(img, S, y0, x0, bool(flip))))
+        r = torch.stack(res).to(pool.device)
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
     def clip_preprocess(self, pixels, S, P, Kpad):
         x = F.interpolate(pixels.float(), size=(S, S), mode="bicubic", align_corners=True)
         x = (x + 1.0) / 2.0

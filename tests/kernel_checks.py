@@ -357,6 +357,42 @@ def check_wo(hip, emu, dev, ops_mod):
     return out
 
 
+def check_image_prep(hip, emu, dev):
+    """data path (N2): byte-exact against the numpy restatement of SmallestMaxSize(INTER_AREA)+crop+flip+normalise,
+    every resize branch (untouched / integer box / 2x2 / general area / enlarging fixed point), ragged sizes in one batch"""
+    import numpy as np
+    import image_prep_oracle as ipo
+    sys_rng = np.random.default_rng(7)
+    res = []
+    for S, dims in ((64, [(128, 192), (192, 192), (97, 131), (40, 55), (64, 80), (65, 64), (64, 64), (201, 77)]),
+                    (512, [(1024, 1536), (1536, 1536), (700, 933), (300, 400), (512, 640), (513, 700), (2048, 2731), (1200, 512)])):
+        samples = []
+        for i, (H, W) in enumerate(dims):
+            img = sys_rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            nh, nw = ipo.smallest_max_size_dims(H, W, S)
+            y0, x0 = ipo.random_crop_origin(nh, nw, S, sys_rng.random(), sys_rng.random())
+            samples.append(dict(image=img, plan=(nh, nw, y0, x0, i & 1)))
+        offs, total = [], 0
+        for smp in samples:
+            offs.append(total)
+            total += (smp["image"].size + 15) // 16 * 16
+        pool = np.zeros(total, np.uint8)
+        table = []
+        for smp, off in zip(samples, offs):
+            im = smp["image"]
+            pool[off:off + im.size] = im.reshape(-1)
+            table.append([off, im.shape[0], im.shape[1], *smp["plan"]])
+        d_pool = torch.from_numpy(pool).to(dev)
+        d_table = torch.tensor(table, dtype=torch.int64, device=dev)
+        got = hip.image_prep(d_pool, d_table, len(samples), S).cpu()
+        for i, smp in enumerate(samples):
+            nh, nw, y0, x0, flip = smp["plan"]
+            want = torch.from_numpy(ipo.image_prep(smp["image"], S, y0, x0, bool(flip)))
+            H, W = smp["image"].shape[:2]
+            res.append((f"image_prep S={S} {H}x{W}->{nh}x{nw} flip={flip}", float((got[i] - want).abs().max()), 0.0))
+    return res
+
+
 def all_checks(hip, emu, dev, ops_mod):
     yield "probe", lambda: check_probe(hip, emu, dev)
     yield "gemm", lambda: check_gemm(hip, emu, dev)
@@ -365,3 +401,4 @@ def all_checks(hip, emu, dev, ops_mod):
     yield "norms", lambda: check_norms(hip, emu, dev)
     yield "streaming", lambda: check_streaming(hip, emu, dev)
     yield "wo", lambda: check_wo(hip, emu, dev, ops_mod)
+    yield "image_prep", lambda: check_image_prep(hip, emu, dev)
