@@ -191,3 +191,68 @@ class VAEEncoder(nn.Module):
     def encode_sample(self, x, eps):
         mean, logvar = self.quant_conv(self.encoder(x)).float().chunk(2, dim=1)
         return (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * eps) * self.scaling_factor
+
+
+# ------------------------------------------------------------------------------------------------
+class _VUp(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class _VUpBlock(nn.Module):
+    def __init__(self, cin, cout, n, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([_VRes(cin if j == 0 else cout, cout) for j in range(n)])
+        self.upsamplers = nn.ModuleList([_VUp(cout)]) if up else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return self.upsamplers[0](x) if self.upsamplers is not None else x
+
+
+class _VDecoder(nn.Module):
+    def __init__(self, boc, latent, out_channels, layers_per_block):
+        super().__init__()
+        rev = tuple(reversed(boc))
+        self.conv_in = nn.Conv2d(latent, rev[0], 3, padding=1)
+        self.mid_block = _VMid(rev[0])
+        blocks, c = [], rev[0]
+        for i, co in enumerate(rev):
+            blocks.append(_VUpBlock(c, co, layers_per_block + 1, i < len(rev) - 1))
+            c = co
+        self.up_blocks = nn.ModuleList(blocks)
+        self.conv_norm_out = nn.GroupNorm(32, c, eps=1e-6)
+        self.conv_out = nn.Conv2d(c, out_channels, 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for b in self.up_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(x)))
+
+
+class VAEDecoder(nn.Module):
+    """AutoencoderKL.decode(latents / scaling_factor).sample and the pipeline's decode_latents
+    (pipeline_stable_diffusion_e4t.py:226,237); key names of the diffusers checkpoint (post_quant_conv, decoder.*)."""
+
+    def __init__(self, block_out_channels=(128, 256, 512, 512), latent_channels=4, out_channels=3, layers_per_block=2,
+                 scaling_factor=0.18215):
+        super().__init__()
+        self.scaling_factor = scaling_factor
+        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
+        self.decoder = _VDecoder(tuple(block_out_channels), latent_channels, out_channels, layers_per_block)
+
+    @torch.no_grad()
+    def decode(self, latents):
+        w = self.post_quant_conv.weight
+        return self.decoder(self.post_quant_conv((latents / self.scaling_factor).to(w.dtype)))
+
+    @torch.no_grad()
+    def decode_latents(self, latents):
+        """-> float32 [B, H, W, 3] in [0, 1]"""
+        return (self.decode(latents).float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous()

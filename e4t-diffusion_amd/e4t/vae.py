@@ -13,6 +13,7 @@ from __future__ import annotations
 import torch
 
 from . import _C, ops
+from .frozen import VAEDecoder as _TorchVAEDecoder
 from .frozen import VAEEncoder as _TorchVAEEncoder
 
 
@@ -113,3 +114,109 @@ class VAEEncoder(_TorchVAEEncoder):
     def encode_sample(self, x, eps):
         mean, logvar = self.moments(x)
         return (mean + torch.exp(0.5 * logvar) * eps) * self.scaling_factor
+
+
+def _attention_1head(be, h, B, T, gn, qkv, proj):
+    """diffusers 0.14 AttentionBlock at one head: GN -> q|k|v (one GEMM) -> scores GEMM -> in-place row softmax -> P.V -> proj + x"""
+    Cw = h.shape[1]
+    n, _ = be.groupnorm_fwd(h, None, gn[0], gn[1], B, T, 32, 1e-6, False)
+    x = be.gemm(n, qkv[0], bias=qkv[1]).view(B, T, 3 * Cw)
+    q, k, v = x[:, :, :Cw], x[:, :, Cw:2 * Cw], x[:, :, 2 * Cw:]
+    s = be.gemm(q, k, alpha=Cw ** -0.5)
+    be.softmax_rows_(s)
+    vt = torch.stack([be.transpose(v[b]) for b in range(B)])
+    o = be.gemm(s, vt).view(B * T, Cw)
+    return be.gemm(o, proj[0], bias=proj[1], residual=h, colstats=True)
+
+
+class VAEDecoder(_TorchVAEDecoder):
+    """AutoencoderKL.decode on the HIP kernels (inference row N4: pipeline_stable_diffusion_e4t.py:226,237 ->
+    StableDiffusionPipeline.decode_latents).  Same parameters / key names as ``frozen.VAEDecoder``.
+      post_quant_conv (1x1, 4 -> 4) with 1/scaling_factor folded in: one GEMM whose output is already the 64-channel
+        zero-padded NHWC operand of conv_in;
+      Upsample2D: nearest x2 is a gather mode of the 3x3 conv (E4T_CONV_UP2) — the 4x larger map is never written;
+      conv_out (128 -> 3): output channels padded to 8, written as fp32 NHWC = the layout decode_latents returns."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._cache = None
+
+    def _prepare(self):
+        key = (self.post_quant_conv.weight.data_ptr(), self.post_quant_conv.weight._version)
+        if self._cache is not None and self._cache["key"] == key:
+            return self._cache
+        be, act = ops.backend(), ops.ACT
+        c = {"key": key}
+        dev = self.post_quant_conv.weight.device
+
+        def conv(m):
+            wf, _ = be.conv_weight_prepare(m.weight, want_dgrad=False)
+            return wf, m.bias.detach().float().contiguous()
+
+        def lin(w, b):
+            return w.detach().reshape(w.shape[0], -1).float().to(act).contiguous(), b.detach().float().contiguous()
+
+        def res(r):
+            d = dict(n1=(r.norm1.weight.detach().float(), r.norm1.bias.detach().float()), c1=conv(r.conv1),
+                     n2=(r.norm2.weight.detach().float(), r.norm2.bias.detach().float()), c2=conv(r.conv2))
+            d["sc"] = lin(r.conv_shortcut.weight, r.conv_shortcut.bias) if r.conv_shortcut is not None else None
+            return d
+
+        L = self.post_quant_conv.weight.shape[0]
+        wpq = torch.zeros((64, 8), dtype=torch.float32, device=dev)
+        wpq[:L, :L] = self.post_quant_conv.weight.detach().float().reshape(L, L) / self.scaling_factor
+        bpq = torch.zeros(64, dtype=torch.float32, device=dev)
+        bpq[:L] = self.post_quant_conv.bias.detach().float()
+        c["pq"] = (wpq.to(act).contiguous(), bpq)
+        dec = self.decoder
+        c["conv_in"] = conv(dec.conv_in)                                   # Cin padded to 64 by conv_weight_prepare
+        mid, at = dec.mid_block, dec.mid_block.attentions[0]
+        c["mid"] = dict(r0=res(mid.resnets[0]), r1=res(mid.resnets[1]),
+                        gn=(at.group_norm.weight.detach().float(), at.group_norm.bias.detach().float()),
+                        qkv=lin(torch.cat([at.query.weight, at.key.weight, at.value.weight], 0), torch.cat([at.query.bias, at.key.bias, at.value.bias], 0)),
+                        proj=lin(at.proj_attn.weight, at.proj_attn.bias))
+        c["up"] = [dict(res=[res(r) for r in blk.resnets], us=conv(blk.upsamplers[0].conv) if blk.upsamplers is not None else None)
+                   for blk in dec.up_blocks]
+        c["norm_out"] = (dec.conv_norm_out.weight.detach().float(), dec.conv_norm_out.bias.detach().float())
+        wo = dec.conv_out.weight.detach()
+        O = wo.shape[0]
+        wo8 = torch.zeros((8,) + tuple(wo.shape[1:]), dtype=wo.dtype, device=dev)
+        wo8[:O] = wo
+        bo8 = torch.zeros(8, dtype=torch.float32, device=dev)
+        bo8[:O] = dec.conv_out.bias.detach().float()
+        c["conv_out"] = (be.conv_weight_prepare(wo8, want_dgrad=False)[0], bo8, O)
+        self._cache = c
+        return c
+
+    @torch.no_grad()
+    def decode_nhwc(self, latents):
+        """latents (B,4,h,w) (scaled, as the scheduler leaves them) -> fp32 [B, 8h, 8w, 3] image in ~[-1, 1]"""
+        be, act = ops.backend(), ops.ACT
+        c = self._prepare()
+        B, L, H, W = latents.shape
+        z = torch.zeros((B * H * W, 8), dtype=act, device=latents.device)
+        z[:, :L] = latents.permute(0, 2, 3, 1).reshape(B * H * W, L)
+        h = be.gemm(z, c["pq"][0], bias=c["pq"][1])                                           # [B*H*W, 64], channels >= 4 are zero
+        h = be.conv3x3(h, c["conv_in"][0], B, H, W, H, W, _C.CONV_S1, bias=c["conv_in"][1], colstats=True)
+        m = c["mid"]
+        h = VAEEncoder._res(be, h, B, H, W, m["r0"])
+        h = _attention_1head(be, h, B, H * W, m["gn"], m["qkv"], m["proj"])
+        h = VAEEncoder._res(be, h, B, H, W, m["r1"])
+        for blk in c["up"]:
+            for r in blk["res"]:
+                h = VAEEncoder._res(be, h, B, H, W, r)
+            if blk["us"] is not None:
+                h = be.conv3x3(h, blk["us"][0], B, H, W, 2 * H, 2 * W, _C.CONV_UP2, bias=blk["us"][1], colstats=True)
+                H, W = 2 * H, 2 * W
+        n, _ = be.groupnorm_fwd(h, None, c["norm_out"][0], c["norm_out"][1], B, H * W, 32, 1e-6, True)
+        w8, b8, O = c["conv_out"]
+        y = be.conv3x3(n, w8, B, H, W, H, W, _C.CONV_S1, bias=b8, out_dtype=torch.float32)   # [B*H*W, 8] fp32
+        return y.view(B, H, W, 8)[..., :O]
+
+    @torch.no_grad()
+    def decode(self, latents):
+        return self.decode_nhwc(latents).permute(0, 3, 1, 2)
+
+    @torch.no_grad()
+    def decode_latents(self, latents):
+        return (self.decode_nhwc(latents) / 2 + 0.5).clamp(0, 1).contiguous()

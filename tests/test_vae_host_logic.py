@@ -32,3 +32,19 @@ def test_native_vae_matches_torch_and_oracle(emu_fp32):
     z_ref = ref.encode_sample(x, eps)
     torch.testing.assert_close(z_torch, z_ref, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(z_nat, z_ref, rtol=2e-4, atol=2e-5)
+
+
+def test_native_vae_decoder_matches_torch_and_oracle(emu_fp32):
+    from e4t.vae import VAEDecoder
+    torch.manual_seed(1)
+    boc = (64, 128, 128)
+    nat = VAEDecoder(block_out_channels=boc).requires_grad_(False)
+    ref = orc.VAEDecoder(block_out_channels=boc)
+    ref.load_state_dict(nat.state_dict())                    # same key names as the diffusers checkpoint
+    z = torch.randn(2, 4, 8, 8) * 0.18215
+    want = ref.decode_latents(z)
+    torch.testing.assert_close(super(VAEDecoder, nat).decode_latents(z), want, rtol=1e-4, atol=1e-5)
+    got = nat.decode_latents(z)
+    assert got.shape == (2, 32, 32, 3) and got.dtype == torch.float32
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(nat.decode(z), ref.decode(z), rtol=2e-4, atol=5e-5)
