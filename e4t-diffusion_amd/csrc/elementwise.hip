@@ -310,6 +310,38 @@ extern "C" int e4t_add(const void* a, const void* b, void* y, long long n, e4t_s
   E4T_CHECK_LAUNCH("add_kernel");
   return 0;
 }
+// Classifier-free guidance + one linear scheduler update in a single pass (pipeline_stable_diffusion_e4t.py:209-214):
+//   eps = cfg ? u + g*(c - u) : pred ;  out = c_sample*sample + c_pred*eps (+ c_noise*noise)
+// coef = {g, c_sample, c_pred, c_noise} lives in device memory so a captured hipGraph of the step can be replayed with
+// new coefficients.  pred may be given in the UNet's NHWC output layout ([B][HW][C]); sample / noise / out are NCHW.
+__global__ __launch_bounds__(256) void guided_step_kernel(const float* __restrict__ pred, const float* __restrict__ sample, const float* __restrict__ noise,
+                                                          float* __restrict__ out, const float* __restrict__ coef, int B, int C, int HW, int cfg, int nhwc) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n = (long long)B * C * HW;
+  if (i >= n) return;
+  const float g = coef[0], cs = coef[1], cp = coef[2], cn = coef[3];
+  long long j = i;
+  if (nhwc) {
+    const int p = (int)(i % HW), c = (int)((i / HW) % C), b = (int)(i / ((long long)HW * C));
+    j = ((long long)b * HW + p) * C + c;
+  }
+  float e = pred[j];
+  if (cfg) {
+    const float t = pred[j + n];
+    e = e + g * (t - e);
+  }
+  float o = cs * sample[i] + cp * e;
+  if (noise) o += cn * noise[i];
+  out[i] = o;
+}
+extern "C" int e4t_guided_step(const float* pred, const float* sample, const float* noise, float* out, const float* coef,
+                               int B, int C, int HW, int cfg, int pred_nhwc, e4t_stream s) {
+  E4T_REQUIRE(pred && sample && out && coef && B > 0 && C > 0 && HW > 0, "guided_step: bad arguments");
+  const long long n = (long long)B * C * HW;
+  hipLaunchKernelGGL(guided_step_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, (hipStream_t)s, pred, sample, noise, out, coef, B, C, HW, cfg, pred_nhwc);
+  E4T_CHECK_LAUNCH("guided_step_kernel");
+  return 0;
+}
 extern "C" int e4t_transpose(const void* in, void* out, int batch, int R, int C, int ldi, int ldo, long long bsi, long long bso, e4t_stream s) {
   E4T_REQUIRE(in && out && batch > 0 && R > 0 && C > 0 && ldi >= C && ldo >= R, "transpose: bad arguments");
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 64), cdiv(R, 64), batch), dim3(256), 0, (hipStream_t)s, (const bf16_t*)in, (bf16_t*)out, R, C, ldi, ldo, bsi, bso);

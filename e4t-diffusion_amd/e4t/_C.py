@@ -82,6 +82,7 @@ SIGNATURES = {
     "e4t_spatial_mean_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "e4t_timestep_embedding": (i32, [vp, vp, i32, i32, vp]),
     "e4t_clip_preprocess": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "e4t_guided_step": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "e4t_image_prep": (i32, [vp, vp, vp, i32, i32, vp]),
     "e4t_softmax_rows": (i32, [vp, i64, i32, i32, vp]),
     "e4t_im2col3_rgb": (i32, [vp, vp, i32, i32, i32, vp]),

@@ -87,6 +87,22 @@ class CLIPTextModel(nn.Module):
     def get_input_embeddings(self):
         return self.text_model.embeddings.token_embedding
 
+    def resize_token_embeddings(self, new_num_tokens: int):
+        """transformers' PreTrainedModel.resize_token_embeddings for the input embedding: keep the existing rows, new rows
+        N(0, 0.02) (the reference grows the table by the placeholder token, pipeline_stable_diffusion_e4t.py:53)"""
+        old = self.text_model.embeddings.token_embedding
+        n_old, w = old.weight.shape
+        if new_num_tokens == n_old:
+            return old
+        new = nn.Embedding(new_num_tokens, w, device=old.weight.device, dtype=old.weight.dtype)
+        new.weight.data.normal_(mean=0.0, std=0.02)
+        k = min(n_old, new_num_tokens)
+        new.weight.data[:k] = old.weight.data[:k]
+        new.weight.requires_grad_(old.weight.requires_grad)
+        self.text_model.embeddings.token_embedding = new
+        self.config["vocab_size"] = new_num_tokens
+        return new
+
     def forward(self, input_ids=None, inputs_embeds=None):
         tm = self.text_model
         if inputs_embeds is None:
@@ -244,6 +260,7 @@ class VAEDecoder(nn.Module):
                  scaling_factor=0.18215):
         super().__init__()
         self.scaling_factor = scaling_factor
+        self.block_out_channels = tuple(block_out_channels)
         self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
         self.decoder = _VDecoder(tuple(block_out_channels), latent_channels, out_channels, layers_per_block)
 

@@ -470,6 +470,19 @@ class HipBackend:
         _C.check(self.lib.e4t_clip_preprocess(_ptr(pixels), _ptr(out), B, Hin, Win, S, P, Kpad, _stream()), "e4t_clip_preprocess")
         return out
 
+    def guided_step(self, pred, sample, coef, noise=None, cfg=True, pred_nhwc=False, out=None):
+        """out = c_sample*sample + c_pred*(cfg ? u + g*(c-u) : pred) (+ c_noise*noise); coef = device fp32 [g, c_sample, c_pred, c_noise]"""
+        B, Cn = sample.shape[0], sample.shape[1]
+        HW = sample.numel() // (B * Cn)
+        assert pred.dtype == f32 and sample.dtype == f32 and coef.dtype == f32 and coef.numel() == 4
+        assert pred.is_contiguous() and sample.is_contiguous() and pred.numel() == sample.numel() * (2 if cfg else 1)
+        assert noise is None or (noise.dtype == f32 and noise.is_contiguous() and noise.shape == sample.shape)
+        if out is None:
+            out = torch.empty_like(sample)
+        _C.check(self.lib.e4t_guided_step(_ptr(pred), _ptr(sample), _ptr(noise), _ptr(out), _ptr(coef), B, Cn, HW, int(cfg), int(pred_nhwc), _stream()),
+                 "e4t_guided_step")
+        return out
+
     def image_prep(self, pool, table, B, S, out=None):
         """raw uint8 RGB images packed in `pool` + int64 [B,8] plan `table` (both on the device) -> fp32 [B,3,S,S]"""
         assert pool.dtype == torch.uint8 and table.dtype == torch.int64 and table.shape == (B, 8) and table.is_contiguous()

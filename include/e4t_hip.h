@@ -203,6 +203,13 @@ int e4t_spatial_mean(const void* x, float* out, int B, int HW, int C, int ldo, i
 int e4t_spatial_mean_bwd(const float* g, const void* base, void* dx, int B, int HW, int C, int ldg, int coff, e4t_stream stream);
 int e4t_timestep_embedding(const long long* t, void* out /* bf16 [B][dim] = [cos|sin] */, int B, int dim, e4t_stream stream); /* unet_2d_condition.py:461 */
 int e4t_clip_preprocess(const float* pixels_nchw, void* patches /* bf16 [B*g*g][Kpad] */, int B, int Hin, int Win, int S, int P, int Kpad, e4t_stream stream); /* encoder.py:131-139 + patchify */
+/* Sampling loop glue (pipeline_stable_diffusion_e4t.py:209-214): classifier-free guidance eps = u + g*(c-u) over
+ * pred = [uncond | cond] (cfg = 1; cfg = 0: pred is eps) fused with a linear scheduler update
+ * out = c_sample*sample + c_pred*eps (+ c_noise*noise, noise may be NULL) — DDIM for epsilon and v prediction is of this
+ * form.  coef: DEVICE float[4] = {g, c_sample, c_pred, c_noise} (so a captured graph replays with new values).
+ * pred_nhwc = 1: pred is [B(*2)][HW][C] (the UNet's native output); sample/noise/out are [B][C][HW] fp32. */
+int e4t_guided_step(const float* pred, const float* sample, const float* noise, float* out, const float* coef,
+                    int B, int C, int HW, int cfg, int pred_nhwc, e4t_stream stream);
 /* Data path (pretrain_e4t.py:137-144 make_transforms = SmallestMaxSize(interpolation=3: cv2.INTER_AREA) -> RandomCrop ->
  * HorizontalFlip, and :174-177 image/127.5-1, HWC->CHW): a batch of raw decoded uint8 RGB images in one device pool ->
  * out fp32 [B][3][S][S].  table: int64 [B][8] (device) = {byte offset of the image in pool, H, W, newH, newW (the

@@ -312,6 +312,24 @@ class EmuBackend:
         ang = t.float()[:, None] * freq[None]
         return self._act(torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1))
 
+    def guided_step(self, pred, sample, coef, noise=None, cfg=True, pred_nhwc=False, out=None):
+        g, cs, cp, cn = coef.tolist()
+        B, Cn = sample.shape[0], sample.shape[1]
+        p = pred.reshape((2 if cfg else 1) * B, -1)
+        if pred_nhwc:
+            p = p.view(p.shape[0], -1, Cn).permute(0, 2, 1)
+        p = p.reshape((-1,) + tuple(sample.shape[1:]))
+        if cfg:
+            u, c = p.chunk(2)
+            p = u + g * (c - u)
+        r = cs * sample + cp * p
+        if noise is not None:
+            r = r + cn * noise
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
     def image_prep(self, pool, table, B, S, out=None):
         import numpy as np
         import image_prep_oracle as ipo

@@ -260,6 +260,16 @@ def check_streaming(hip, emu, dev):
     for M, Cn in [(37, 64), (5000, 320), (65536, 320), (1232, 2560), (300, 8)]:
         xs = rnd(g, M, Cn + 8, dev=dev)[:, :Cn]                      # strided view
         out.append((f"colsum {M}x{Cn}", rel(hip.colsum(xs), emu.colsum(xs)), 1e-3))
+    for B, Cn, HW, cfg, nhwc, noise in [(2, 4, 4096, True, True, False), (3, 4, 100, True, False, True), (1, 4, 9216, False, True, True), (2, 4, 37, False, False, False)]:
+        pred = torch.randn(((2 if cfg else 1) * B * Cn * HW,), generator=g, device=dev)
+        x = torch.randn((B, Cn, HW), generator=g, device=dev)
+        nz = torch.randn((B, Cn, HW), generator=g, device=dev) if noise else None
+        coef = torch.tensor([7.5, 1.0123, -0.0456, 0.3], dtype=f32, device=dev)
+        got = hip.guided_step(pred, x, coef, noise=nz, cfg=cfg, pred_nhwc=nhwc)
+        out.append((f"guided_step B{B} HW{HW} cfg={cfg} nhwc={nhwc}", rel(got, emu.guided_step(pred, x, coef, noise=nz, cfg=cfg, pred_nhwc=nhwc)), 1e-6))
+    x2 = x.clone()
+    hip.guided_step(pred, x2, coef, cfg=False, pred_nhwc=False, out=x2)          # in place on the sample, as the pipeline uses it
+    out.append(("guided_step in place", rel(x2, emu.guided_step(pred, x, coef, cfg=False)), 1e-6))
     acc = torch.ones(320, dtype=f32, device=dev)
     xs = rnd(g, 700, 320, dev=dev)
     hip.colsum(xs, out=acc, accumulate=True)
