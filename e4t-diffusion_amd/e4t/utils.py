@@ -45,3 +45,41 @@ def save_config(args_dict, save_dir):
     os.makedirs(save_dir, exist_ok=True)
     with open(os.path.join(save_dir, "config.json"), "w") as f:
         json.dump(args_dict, f, indent=2, default=str)
+
+
+class WhitespaceTokenizer:
+    """Offline stand-in with the CLIPTokenizer call surface the pipeline uses (no vocabulary files can be fetched here):
+    whitespace words -> ids (unknown words are added on the fly), BOS/EOS, padding to model_max_length.  For smoke runs,
+    tests and benchmarks with random-init weights only."""
+    model_max_length = 9
+
+    def __init__(self, base_size: int = 100, model_max_length: int = 9):
+        self.base_size, self.model_max_length = base_size, model_max_length      # CLIP: 49408 tokens, 77 positions
+        self.vocab = {"<bos>": 1, "<eos>": 2, "a": 5, "photo": 6, "of": 7, "art": 11, "painting": 12}
+
+    def __len__(self):
+        return self.base_size + sum(1 for v in self.vocab.values() if v >= self.base_size)
+
+    def add_tokens(self, tok):
+        if tok in self.vocab:
+            return 0
+        self.vocab[tok] = len(self)
+        return 1
+
+    def convert_tokens_to_ids(self, tok):
+        return self.vocab[tok]
+
+    def __call__(self, text, padding=None, truncation=None, max_length=None, return_tensors=None, add_special_tokens=True):
+        texts = [text] if isinstance(text, str) else text
+        rows = []
+        for t in texts:
+            ids = [self.vocab[w] if w in self.vocab else self.vocab.setdefault(w, 20 + (sum(map(ord, w)) % 70)) for w in t.split()]
+            if add_special_tokens:
+                ids = [1] + ids + [2]
+            if padding == "max_length":
+                ids = (ids + [2] * max_length)[:max_length]
+            rows.append(ids)
+
+        class R:
+            input_ids = torch.tensor(rows, dtype=torch.long)
+        return R()

@@ -60,7 +60,11 @@ def parse_args():
     p.add_argument("--mixed_precision", type=str, default="bf16", choices=["no", "fp16", "bf16"])
     p.add_argument("--enable_xformers_memory_efficient_attention", action="store_true")
     p.add_argument("--checkpointing_steps", type=int, default=10000)
-    p.add_argument("--log_steps", type=int, default=10 ** 9)
+    p.add_argument("--log_steps", type=int, default=10 ** 9, help="sample images every N steps (the reference also samples at step 1)")
+    p.add_argument("--save_sample_prompt", type=str, default="a photo of *s,a photo of *s in the style of monet")
+    p.add_argument("--n_save_sample", type=int, default=4)
+    p.add_argument("--save_guidance_scale", type=float, default=7.5)
+    p.add_argument("--save_inference_steps", type=int, default=50)
     p.add_argument("--report_to", type=str, default="none")
     p.add_argument("--local_rank", type=int, default=-1)
     p.add_argument("--resume_from_checkpoint", type=str, default=None)
@@ -172,9 +176,53 @@ def main():
         save_e4t_unet(unet, d)
         save_e4t_encoder(enc, d)
 
+    pipe_parts = {}
+
+    @torch.no_grad()
+    def sample(images, step):
+        """qualitative logging (reference pretrain_e4t.py:452-513): for every prompt x a few training images, run the E4T
+        pipeline and write input-<step>.png / sample-<step>.png grids under <output_dir>/samples"""
+        from PIL import Image
+        from e4t.pipeline_stable_diffusion_e4t import StableDiffusionE4TPipeline
+        from e4t.schedulers import DDIMScheduler
+        from e4t.utils import WhitespaceTokenizer
+        from e4t.vae import VAEDecoder
+        from inference import image_grid
+        if not pipe_parts:
+            tdir = os.path.join(args.pretrained_model_name_or_path or "", "tokenizer")
+            if os.path.isdir(tdir):
+                from transformers import CLIPTokenizer
+                tok = CLIPTokenizer.from_pretrained(tdir)
+            else:
+                tok = WhitespaceTokenizer(base_size=49408, model_max_length=77)
+            tok.add_tokens(args.placeholder_token)
+            with torch.device(dev):
+                dec = VAEDecoder().requires_grad_(False)
+            f = os.path.join(args.pretrained_model_name_or_path or "", "vae.pt")
+            if os.path.exists(f):
+                dec.load_state_dict(torch.load(f, map_location="cpu"), strict=False)
+            pipe_parts.update(tok=tok, dec=dec, sched=DDIMScheduler.stable_diffusion(args.prediction_type))
+        x = torch.clamp((images + 1.0) / 2.0, min=0.0, max=1.0)
+        pils = [Image.fromarray((255.0 * xi.permute(1, 2, 0).cpu().numpy()).astype("uint8")) for xi in x]
+        pils = random.sample(pils, min(len(pils), args.n_save_sample))
+        was_training = unet.training
+        pipe = StableDiffusionE4TPipeline(vae=pipe_parts["dec"], text_encoder=text, tokenizer=pipe_parts["tok"], unet=unet, e4t_encoder=enc,
+                                          scheduler=pipe_parts["sched"], e4t_config=args, already_added_placeholder_token=True)
+        prompts = args.save_sample_prompt.split(",")
+        outs = [pipe(pr, guidance_scale=args.save_guidance_scale, num_inference_steps=args.save_inference_steps, image=im,
+                     height=args.resolution, width=args.resolution).images[0] for pr in prompts for im in pils]
+        d = os.path.join(args.output_dir, "samples")
+        os.makedirs(d, exist_ok=True)
+        image_grid(pils, rows=1, cols=len(pils)).save(os.path.join(d, f"input-{step}.png"))
+        image_grid(outs, rows=len(prompts), cols=len(pils)).save(os.path.join(d, f"sample-{step}.png"))
+        unet.train(was_training)
+
     t0 = time.perf_counter()
     for step in range(1, args.max_train_steps + 1):
-        loss, ld, lr_ = tr.train_step(*next(data))
+        batch = next(data)
+        loss, ld, lr_ = tr.train_step(*batch)
+        if step % args.log_steps == 0 and rank == 0:
+            sample(batch[0], step)
         if step % 10 == 0 or step == 1:
             torch.cuda.synchronize()
             if rank == 0:

@@ -63,7 +63,7 @@ def test_pipeline_graph_replay_equals_eager(hip_env):
     """tiny models on the real kernels: the hipGraph-replayed denoising loop must reproduce the eager loop (same kernels, same
     order -> bit-identical latents), and both stay close to the fp32 CPU oracle loop."""
     import e4t_oracle as orc
-    from test_pipeline_host_logic import WordTokenizer
+    from word_tokenizer import WordTokenizer
     from test_train_step_host_logic import build
     from e4t.pipeline_stable_diffusion_e4t import StableDiffusionE4TPipeline
     from e4t.schedulers import DDIMScheduler

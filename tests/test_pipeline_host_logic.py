@@ -8,41 +8,7 @@ import torch
 import e4t_oracle as orc
 from test_unet_host_logic import emu_fp32  # noqa: F401
 from test_train_step_host_logic import build, TEXT_CFG
-
-
-class WordTokenizer:
-    """minimal stand-in for CLIPTokenizer: whitespace words -> ids, BOS/EOS, padding to model_max_length"""
-    model_max_length = 9
-
-    def __init__(self):
-        self.vocab = {"<bos>": 1, "<eos>": 2, "a": 5, "photo": 6, "of": 7, "art": 11, "painting": 12}
-
-    def __len__(self):
-        return 100 + sum(1 for v in self.vocab.values() if v >= 100)
-
-    def add_tokens(self, tok):
-        if tok in self.vocab:
-            return 0
-        self.vocab[tok] = len(self)
-        return 1
-
-    def convert_tokens_to_ids(self, tok):
-        return self.vocab[tok]
-
-    def __call__(self, text, padding=None, truncation=None, max_length=None, return_tensors=None, add_special_tokens=True):
-        texts = [text] if isinstance(text, str) else text
-        rows = []
-        for t in texts:
-            ids = [self.vocab[w] for w in t.split()]
-            if add_special_tokens:
-                ids = [1] + ids + [2]
-            if padding == "max_length":
-                ids = (ids + [2] * max_length)[:max_length]
-            rows.append(ids)
-
-        class R:
-            input_ids = torch.tensor(rows, dtype=torch.long)
-        return R()
+from word_tokenizer import WordTokenizer
 
 
 def test_ddim_linear_coefficients_match_stepwise_form():

@@ -9,7 +9,7 @@ from bench import build_models
 from e4t.pipeline_stable_diffusion_e4t import StableDiffusionE4TPipeline
 from e4t.schedulers import DDIMScheduler
 from e4t.vae import VAEDecoder
-from test_pipeline_host_logic import WordTokenizer
+from word_tokenizer import WordTokenizer
 
 dev = torch.device("cuda:0")
 steps = int(os.environ.get("STEPS", "50"))
@@ -17,7 +17,7 @@ unet, enc, text, _ = build_models(dev, "sd14", seed=0)
 unet.requires_grad_(False); enc.requires_grad_(False)
 with torch.device(dev):
     vae = VAEDecoder().requires_grad_(False)
-tok = WordTokenizer(); tok.model_max_length = 77
+tok = WordTokenizer(base_size=49408, model_max_length=77)
 pipe = StableDiffusionE4TPipeline(vae=vae, text_encoder=text, tokenizer=tok, unet=unet, e4t_encoder=enc, scheduler=DDIMScheduler.stable_diffusion(),
                                   e4t_config=dict(placeholder_token="*s", domain_class_token="art", domain_embed_scale=0.1), already_added_placeholder_token=False)
 image = torch.rand(1, 3, 512, 512) * 2 - 1
