@@ -62,11 +62,25 @@ def main():
     lr = args.learning_rate * (args.train_batch_size if args.scale_lr else 1)
     tr = E4TTrainer(unet, enc, text, vae, lr=lr, domain_embed_scale=args.domain_embed_scale, reg_lambda=args.reg_lambda,
                     class_token_id=1125, device=dev, tuning=True, max_grad_norm=args.max_grad_norm)
-    if not args.synthetic_data:
-        raise SystemExit("only --synthetic_data is available in this build (image decoding is host-side I/O outside the hot path)")
     B, res = args.train_batch_size, args.resolution
     g = torch.Generator(device=dev).manual_seed(args.seed or 0)
-    image = torch.rand((1, 3, res, res), generator=g, device=dev) * 2 - 1
+    if args.synthetic_data:
+        image = torch.rand((1, 3, res, res), generator=g, device=dev) * 2 - 1
+    elif args.train_image_path:
+        # tuning_e4t.py:174-181: make_transforms(resolution, random_crop=True) on the one training image; decode on the host,
+        # SmallestMaxSize(INTER_AREA) / crop / flip / normalise in the data-path kernel
+        import random
+
+        import numpy as np
+        from PIL import Image
+        from e4t import ops
+        from e4t.data import make_transforms, pack_batch
+        rgb = np.ascontiguousarray(np.asarray(Image.open(args.train_image_path).convert("RGB"), dtype=np.uint8))
+        plan = make_transforms(res, random_crop=True).plan(rgb.shape[0], rgb.shape[1], random.Random(args.seed))
+        pool, table, _ = pack_batch([dict(image=rgb, plan=plan)], res)
+        image = ops.backend().image_prep(pool.to(dev), table.to(dev), 1, res)
+    else:
+        raise SystemExit("give --train_image_path <file> or --synthetic_data")
     pixels = image.expand(B, -1, -1, -1).contiguous()                       # tuning_e4t.py:266
     latents = tr.encode_latents(pixels, torch.randn((B, 4, res // 8, res // 8), generator=g, device=dev))   # once, :268-269
     ids = torch.randint(1000, 40000, (1, 77), generator=g, device=dev).expand(B, -1).contiguous()
