@@ -1,13 +1,12 @@
-"""The two FROZEN components inside the training step that SURVEY.md §2 marks out of the hot-path
-scope (#8 CLIP text encoder, #15 VAE encoder; "next" rows N3 / N1 of §8f).  They run on stock
-PyTorch-ROCm ops (bf16, on the GPU) exactly as the reference runs them through transformers /
-diffusers — they are NOT part of the hand-written kernel path and are reported separately in the
-bench.  Module / parameter names follow the HF checkpoints (CLIPTextModel, AutoencoderKL.encoder) so real
-weights load by key; here they are randomly initialised (no network).
+"""Stock-PyTorch twins of the frozen components around the UNet: the CLIP text encoder, the
+AutoencoderKL encoder (#15) and decoder.  They define the module trees / parameter names of the HF checkpoints
+(CLIPTextModel, AutoencoderKL.encoder / .decoder / quant convs) so real weights load by key, and they are the fp32 parity
+references of the kernel-driven subclasses in ``text.py`` and ``vae.py`` (tests/test_model_gpu.py, test_vae_host_logic.py,
+test_text_host_logic.py).  The training step and the sampling pipeline run the subclasses, not these forward()s; the one
+exception is a *trainable* text encoder (never the case in the reference's scripts), which ``text.py`` hands to this class.
 
-CLIPTextModel accepts ``inputs_embeds`` like the reference's patched class
-(e4t/models/modeling_clip.py:9-82) — the installed transformers 5.x no longer has the internals that file
-monkey-patches, so an equivalent is needed anyway.
+CLIPTextModel accepts ``inputs_embeds`` like the reference's patched class (e4t/models/modeling_clip.py:9-82) — the
+installed transformers 5.x no longer has the internals that file monkey-patches, so an equivalent is needed anyway.
 """
 from __future__ import annotations
 

@@ -1,4 +1,5 @@
-"""smoke(): one small invocation of the whole hot path on cuda:0 through the HIP kernels, checked against
+"""The check behind __graft_entry__.smoke() (kept under tests/: it needs the oracle, which product code must not import).
+One small invocation of the whole hot path on cuda:0 through the HIP kernels, checked against
 the CPU fp32 oracle (the oracle is only the checker here; see oracle/e4t_oracle.py header)."""
 from __future__ import annotations
 
@@ -16,12 +17,12 @@ def rel(a, b):
 
 def run(dev, verbose=True):
     import e4t_oracle as orc                      # checker only
-    from . import ops
-    from .encoder import E4TEncoder
-    from .frozen import CLIPTextModel
-    from .text import CLIPTextModel as NativeCLIPTextModel
-    from .models.unet_2d_condition import UNet2DConditionModel
-    from .trainer import E4TTrainer
+    from e4t import ops
+    from e4t.encoder import E4TEncoder
+    from e4t.frozen import CLIPTextModel
+    from e4t.text import CLIPTextModel as NativeCLIPTextModel
+    from e4t.models.unet_2d_condition import UNet2DConditionModel
+    from e4t.trainer import E4TTrainer
 
     assert isinstance(ops.backend(), ops.HipBackend), "smoke must run on the HIP backend"
     torch.manual_seed(0)

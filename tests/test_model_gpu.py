@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_smoke_step_matches_oracle(hip_env):
-    from e4t import smoke
+    import smoke_step as smoke
     errs = smoke.run(torch.device("cuda:0"), verbose=False)
     assert errs["loss_diff"] < 2e-2
 
