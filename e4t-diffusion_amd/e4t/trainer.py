@@ -82,6 +82,8 @@ class E4TTrainer:
         self._side, self._vision = None, None
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        # E4T_FORCE_COMM=1: run the collective path even in a 1-rank group (exercises the RCCL calls / stream ordering on one GPU)
+        self._comm = self.world > 1 or (os.environ.get("E4T_FORCE_COMM") == "1" and torch.distributed.is_available() and torch.distributed.is_initialized())
         self.step_count = 0
         self.acp = ddpm_alphas_cumprod(device=self.device)
         self.max_grad_norm = max_grad_norm
@@ -112,7 +114,7 @@ class E4TTrainer:
             self.class_embed = emb(torch.tensor([class_token_id], device=self.device))[0].float()
             ids = empty_prompt_ids if empty_prompt_ids is not None else torch.zeros((1, 77), dtype=torch.long, device=self.device)
             self.ctx_for_e4t = text_encoder(input_ids=ids.to(self.device))[0].detach()
-        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.world > 1 and self.device.type == "cuda") else None
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self._comm and self.device.type == "cuda") else None
 
     # ------------------------------------------------------------------------------------------------
     def add_noise(self, x0, noise, t):
@@ -180,7 +182,7 @@ class E4TTrainer:
     def _setup_overlap(self, named, n_first):
         self._works, self._done = [], set()
         self.regions = None
-        if self.world <= 1 or self.tuning:
+        if not self._comm or self.tuning:
             return
         params = self.flat.params
         idx_unet = next((i for i, (n, _) in enumerate(named) if n.startswith("unet.")), None)
@@ -223,7 +225,7 @@ class E4TTrainer:
             self._works.append(torch.distributed.all_reduce(g[o:min(o + bucket, b)], group=self.pg, async_op=True))
 
     def all_reduce_grads(self):
-        if self.world <= 1:
+        if not self._comm:
             return
         if self.regions is None:
             g = self.flat.grad
