@@ -14,7 +14,8 @@ per GPU that pipeline is the bottleneck, so here the split is different:
 Same public names and argument meaning as the reference (``make_transforms``, ``E4TDataset``); ``E4TDataset.__getitem__``
 returns the raw image plus its transform plan instead of an already transformed tensor, and ``DeviceLoader`` replaces
 ``torch.utils.data.DataLoader`` + ``accelerator.prepare`` (rank r of ``world`` takes every world-th batch, as
-accelerate's BatchSamplerShard does).
+accelerate's BatchSamplerShard does).  ``TarShardDataset`` is the ``--webdataset`` source (:303-340) without the webdataset
+package: the loader pulls still-encoded images from resampled tar shards and decodes them in its thread pool.
 """
 from __future__ import annotations
 
@@ -116,6 +117,131 @@ class E4TDataset:
         return dict(image=image, plan=self.processor.plan(image.shape[0], image.shape[1], rng))
 
 
+def braceexpand(pattern: str):
+    """The subset of bash brace expansion shard lists use (reference: braceexpand.braceexpand, pretrain_e4t.py:186):
+    numeric ranges ``{000..127}`` (zero padding kept) and comma lists ``{a,b}``, nested / repeated left to right."""
+    i = pattern.find("{")
+    if i < 0:
+        return [pattern]
+    depth, j = 0, i
+    while j < len(pattern):
+        depth += pattern[j] == "{"
+        depth -= pattern[j] == "}"
+        if depth == 0:
+            break
+        j += 1
+    if depth != 0:
+        return [pattern]
+    head, body, tail = pattern[:i], pattern[i + 1:j], pattern[j + 1:]
+    if ".." in body and "," not in body and "{" not in body:
+        lo, hi = body.split("..")[:2]
+        width = max(len(lo), len(hi)) if (lo.startswith("0") or hi.startswith("0")) else 0
+        step = 1 if int(hi) >= int(lo) else -1
+        alts = [str(v).zfill(width) for v in range(int(lo), int(hi) + step, step)]
+    else:
+        alts, depth, cur = [], 0, ""
+        for ch in body:
+            if ch == "," and depth == 0:
+                alts.append(cur)
+                cur = ""
+            else:
+                depth += ch == "{"
+                depth -= ch == "}"
+                cur += ch
+        alts.append(cur)
+        if len(alts) == 1:                          # "{x}" is literal in bash
+            return [head + "{" + a + "}" + t for a in braceexpand(body) for t in braceexpand(tail)]
+    return [head + a2 + t for a in alts for a2 in braceexpand(a) for t in braceexpand(tail)]
+
+
+def get_dataset_size(shards: str):
+    """(number of samples or None, number of shards) from sizes.json / <shard>_stats.json (pretrain_e4t.py:183-211)"""
+    import json
+    shards_list = []
+    for s in shards.split("::"):
+        shards_list += braceexpand(s)
+    sizes_filename = os.path.join(os.path.dirname(shards), "sizes.json")
+    if os.path.exists(sizes_filename):
+        with open(sizes_filename) as f:
+            sizes = json.load(f)
+        total = sum(int(sizes[os.path.basename(shard)]) for shard in shards_list)
+    else:
+        total = 0
+        for shard in shards_list:
+            jp = shard.replace(".tar", "_stats.json")
+            if os.path.exists(jp):
+                with open(jp) as f:
+                    st = json.load(f)
+                total += int(st["n_data"] if "n_data" in st else st["successes"])
+            else:
+                print(f"Not Found {jp}")
+    return total, len(shards_list)
+
+
+class TarShardDataset:
+    """The reference's ``--webdataset`` source (pretrain_e4t.py:303-318) on the standard library: tar shards whose members
+    ``<key>.<ext>`` form samples; shards are drawn at random with replacement for ever (``wds.ResampledShards``), samples
+    without a ``jpg`` member are skipped (``filter_webdataset``), a shuffle buffer of 1000 decorrelates neighbours
+    (``wds.shuffle(1000)``), unreadable shards / members are reported and skipped (``wds.warn_and_continue``).  Items are
+    the still-encoded image bytes: decoding happens in the loader's thread pool, resize/crop/flip/normalise on the GPU."""
+
+    def __init__(self, shards: str, resolution=512, shuffle_buffer=1000, image_key="jpg"):
+        self.shards = []
+        for s in shards.split("::"):
+            self.shards += braceexpand(s)
+        if not self.shards:
+            raise ValueError("no shards")
+        self.processor = make_transforms(resolution, random_crop=True)
+        self.shuffle_buffer, self.image_key = shuffle_buffer, image_key
+
+    def _samples(self, path):
+        import tarfile
+        try:
+            with tarfile.open(path) as tf:
+                key, cur = None, {}
+                for m in tf:
+                    if not m.isfile():
+                        continue
+                    base = os.path.basename(m.name)
+                    k, _, ext = base.partition(".")
+                    k = os.path.join(os.path.dirname(m.name), k)
+                    if k != key:
+                        if cur:
+                            yield cur
+                        key, cur = k, {}
+                    cur[ext.lower()] = tf.extractfile(m).read()
+                if cur:
+                    yield cur
+        except Exception as e:                      # warn_and_continue
+            print(f"[TarShardDataset] skipping {path}: {e!r}")
+
+    def iter_items(self, rank=0, world=1, seed=0, epoch=0):
+        rng = random.Random((seed * 1000003 + epoch) * 4099 + rank)
+        buf = []
+        while True:
+            for smp in self._samples(rng.choice(self.shards)):
+                data = smp.get(self.image_key)
+                if data is None:
+                    continue
+                if len(buf) < self.shuffle_buffer:
+                    buf.append(data)
+                    continue
+                j = rng.randrange(len(buf))
+                buf[j], data = data, buf[j]
+                yield data
+            if buf and len(buf) < self.shuffle_buffer and len(self.shards) == 1:
+                rng.shuffle(buf)                    # tiny single-shard sets: do not starve, hand the buffer out
+                yield from buf
+                buf = []
+
+    def __getitem__(self, item, rng=random):
+        import io
+
+        from PIL import Image
+        image = np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(item)).convert("RGB"), dtype=np.uint8))
+        return dict(image=image, plan=self.processor.plan(image.shape[0], image.shape[1], rng))
+
+
 class _Slot:
     """one in-flight batch: pinned staging + device buffers (grown on demand, reused)"""
 
@@ -185,9 +311,15 @@ class DeviceLoader:
             raise NotImplementedError("a ragged last batch is not supported (the reference's webdataset loader also drops it)")
 
     def __len__(self):
+        if hasattr(self.ds, "iter_items"):
+            raise TypeError("an iterable (tar-shard) source has no length: it is resampled for ever")
         return len(self.ds) // (self.B * self.world)
 
     def _indices(self):
+        if hasattr(self.ds, "iter_items"):          # stream of still-encoded items, B at a time; bad images are skipped in _produce
+            it = self._items = self.ds.iter_items(self.rank, self.world, self.seed, self.epoch)
+            while True:
+                yield [next(it) for _ in range(self.B)]
         n = len(self.ds)
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed * 1000003 + self.epoch)
@@ -199,12 +331,24 @@ class DeviceLoader:
             b = i * self.world + self.rank
             yield perm[b * self.B:(b + 1) * self.B]
 
+    def _load(self, item, rng):
+        try:
+            return self.ds.__getitem__(item, rng)
+        except Exception as e:
+            if not hasattr(self.ds, "iter_items"):
+                raise
+            print(f"[DeviceLoader] skipping a sample: {e!r}")          # wds.warn_and_continue
+            return None
+
     def _produce(self, slot, idxs, rng):
         plans_rng = [random.Random(rng.getrandbits(64)) for _ in idxs]        # per-sample streams: thread-order independent
         if self.pool is not None:
-            samples = list(self.pool.map(lambda a: self.ds.__getitem__(a[0], a[1]), zip(idxs, plans_rng)))
+            samples = list(self.pool.map(lambda a: self._load(a[0], a[1]), zip(idxs, plans_rng)))
         else:
-            samples = [self.ds.__getitem__(i, r) for i, r in zip(idxs, plans_rng)]
+            samples = [self._load(i, r) for i, r in zip(idxs, plans_rng)]
+        for k in range(len(samples)):               # stream sources: an undecodable image is replaced by the next item
+            while samples[k] is None:
+                samples[k] = self._load(next(self._items), plans_rng[k])
         nbytes = sum((s["image"].size + 15) // 16 * 16 for s in samples)
         if slot.event is not None:
             slot.event.synchronize()                     # the consumer's step that used this slot's output has been enqueued and finished
@@ -226,7 +370,7 @@ class DeviceLoader:
 
     def __iter__(self):
         rng = random.Random(self.seed * 7919 + self.epoch * 104729 + self.rank)
-        batches = list(self._indices())
+        batches = self._indices() if hasattr(self.ds, "iter_items") else list(self._indices())
         self.epoch += 1
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()

@@ -100,11 +100,16 @@ def synthetic_batches(args, dev, rank, world):
 def image_batches(args, dev, rank, world):
     """real images (reference: E4TDataset + DataLoader, pretrain_e4t.py:147-180,284-291) through e4t.data: the host only
     decodes; SmallestMaxSize(INTER_AREA)/crop/flip/normalise run in one kernel per batch, prefetched under the step"""
-    from e4t.data import DeviceLoader, E4TDataset
-    ds = E4TDataset(args.train_image_dataset, resolution=args.resolution)
+    from e4t.data import DeviceLoader, E4TDataset, TarShardDataset, get_dataset_size
+    if args.webdataset:
+        n, nshards = get_dataset_size(args.train_image_dataset)
+        print(f"Loading webdataset with {nshards} shards. (num_samples: {n})")
+        ds = TarShardDataset(args.train_image_dataset, resolution=args.resolution)
+    else:
+        ds = E4TDataset(args.train_image_dataset, resolution=args.resolution)
     loader = DeviceLoader(ds, args.train_batch_size, shuffle=True, num_workers=args.dataloader_num_workers, device=dev,
                           rank=rank, world=world, seed=args.seed or 0)
-    if len(loader) == 0:
+    if not args.webdataset and len(loader) == 0:
         raise SystemExit(f"{len(ds)} images are fewer than one global batch")
     tok = None
     tdir = os.path.join(args.pretrained_model_name_or_path or "", "tokenizer")
@@ -162,11 +167,11 @@ def main():
                     prediction_type=args.prediction_type, class_token_id=1125, device=dev)
     if args.synthetic_data:
         data = synthetic_batches(args, dev, rank, world)
-    elif args.train_image_dataset and not (args.webdataset or args.iterable_dataset):
+    elif args.train_image_dataset and not args.iterable_dataset:
         data = image_batches(args, dev, rank, world)
     else:
-        raise SystemExit("give --train_image_dataset <dir[::dir]> (decoded on the host, resized/cropped on the GPU) or "
-                         "--synthetic_data; the webdataset / HF-streaming sources need packages that are not in this image")
+        raise SystemExit("give --train_image_dataset <dir[::dir]>, --webdataset --train_image_dataset <shards{000..NNN}.tar>, or "
+                         "--synthetic_data; HF-hub streaming (--iterable_dataset) needs network access")
 
     def save(step):
         if rank != 0:

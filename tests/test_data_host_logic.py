@@ -129,3 +129,61 @@ def test_pack_batch_rejects_bad_window():
         pack_batch([dict(image=img, plan=(64, 80, 0, 17, 0))], 64)
     pool, table, total = pack_batch([dict(image=img, plan=(64, 80, 0, 16, 1)), dict(image=img[:70], plan=(64, 91, 0, 0, 0))], 64)
     assert table.tolist() == [[0, 80, 100, 64, 80, 0, 16, 1], [24000, 70, 100, 64, 91, 0, 0, 0]] and total == 24000 + 21008
+
+
+def test_braceexpand_and_dataset_size(tmp_path):
+    import json
+    from e4t.data import braceexpand, get_dataset_size
+    assert braceexpand("s/{000..002}.tar") == ["s/000.tar", "s/001.tar", "s/002.tar"]
+    assert braceexpand("s/{8..10}.tar") == ["s/8.tar", "s/9.tar", "s/10.tar"]
+    assert braceexpand("x{a,b}{1..2}") == ["xa1", "xa2", "xb1", "xb2"]
+    assert braceexpand("plain.tar") == ["plain.tar"] and braceexpand("k{x}.tar") == ["k{x}.tar"]
+    pat = str(tmp_path / "{00..01}.tar")
+    (tmp_path / "00_stats.json").write_text(json.dumps({"successes": 7}))
+    (tmp_path / "01_stats.json").write_text(json.dumps({"n_data": 5, "successes": 99}))
+    assert get_dataset_size(pat) == (12, 2)
+    (tmp_path / "sizes.json").write_text(json.dumps({"00.tar": 3, "01.tar": 4}))
+    assert get_dataset_size(pat) == (7, 2)
+
+
+def test_tar_shard_source_end_to_end_cpu(tmp_path, emu_fp32):
+    import io
+    import tarfile
+    from e4t.data import DeviceLoader, TarShardDataset
+    rng = np.random.default_rng(2)
+    imgs = {}
+    for s in range(2):
+        with tarfile.open(tmp_path / f"shard-{s}.tar", "w") as tf:
+            def add(name, data):
+                ti = tarfile.TarInfo(name)
+                ti.size = len(data)
+                tf.addfile(ti, io.BytesIO(data))
+            for i in range(5):
+                a = rng.integers(0, 256, (70 + 9 * i, 90 + 5 * s, 3), dtype=np.uint8)
+                b = io.BytesIO()
+                Image.fromarray(a).save(b, format="PNG")          # lossless, stored under the "jpg" key like a webdataset shard
+                key = f"{s}{i:04d}"
+                add(f"{key}.jpg", b.getvalue())
+                add(f"{key}.txt", b"a caption")
+                imgs[a.shape[:2]] = a
+            add(f"{s}9998.txt", b"caption without an image")                        # filtered: no jpg member
+            add(f"{s}9999.jpg", b"this is not an image")                            # skipped with a warning at decode time
+    ds = TarShardDataset(str(tmp_path / "shard-{0..1}.tar"), resolution=64, shuffle_buffer=4)
+    assert len(ds.shards) == 2
+    ds.processor.random_crop, ds.processor.flip_p = False, 0.0
+    ld = DeviceLoader(ds, batch_size=3, num_workers=2, device="cpu", seed=1)
+    with pytest.raises(TypeError):
+        len(ld)
+    seen = set()
+    for k, batch in enumerate(ld):
+        px = batch["pixel_values"]
+        assert px.shape == (3, 3, 64, 64)
+        for j in range(3):          # every output is the oracle transform of one of the stored images
+            hit = [hw for hw, a in imgs.items()
+                   if np.array_equal(px[j].numpy(), ipo.image_prep(a, 64, (ipo.smallest_max_size_dims(*hw, 64)[0] - 64) // 2,
+                                                                   (ipo.smallest_max_size_dims(*hw, 64)[1] - 64) // 2, False))]
+            assert len(hit) == 1
+            seen.add(hit[0])
+        if k == 11:
+            break
+    assert len(seen) >= 8           # resampled shards + shuffle buffer reach (almost) every image within 36 draws
