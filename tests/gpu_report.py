@@ -6,7 +6,7 @@ import traceback
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-sys.path[:0] = [os.path.join(ROOT, "e4t-diffusion_amd"), HERE]
+sys.path[:0] = [os.path.join(ROOT, "e4t-diffusion_amd"), HERE, os.path.join(ROOT, "oracle")]
 
 import torch  # noqa: E402
 from e4t import ops  # noqa: E402

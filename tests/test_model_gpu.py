@@ -99,3 +99,37 @@ def test_pipeline_graph_replay_equals_eager(hip_env):
     assert rel < 3e-2, rel
     img = pipe("a painting of *s", latents=lat0[:1].clone(), height=32, width=32, num_inference_steps=2, image=image).images
     assert img[0].size == (32, 32)
+
+
+def test_training_step_is_bitwise_deterministic(hip_env):
+    """SURVEY §8c parity protocol: run-to-run determinism of the native path.  No kernel uses atomics (split-K, column
+    reductions and the attention backward all reduce in a fixed order), so two runs from the same state must agree bit
+    for bit — losses and every trained parameter after two optimiser steps."""
+    from test_train_step_host_logic import TEXT_CFG, build
+    from e4t.text import CLIPTextModel
+    from e4t.trainer import E4TTrainer
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    batches = [(torch.rand(B, 3, 64, 64, generator=g) * 2 - 1, torch.randn(B, 4, 16, 16, generator=g) * 0.18215,
+                torch.randn(B, 4, 16, 16, generator=g), torch.randint(0, 1000, (B,), generator=g), torch.randint(1, 99, (B, 9), generator=g))
+               for _ in range(2)]
+    pidx = torch.tensor([2, 4], device=dev)
+
+    def run():
+        _, _, n_unet, n_enc, text_t = build(seed=0)
+        text = CLIPTextModel(**TEXT_CFG).requires_grad_(False)
+        text.load_state_dict(text_t.state_dict())
+        n_unet.to(dev), n_enc.to(dev), text.to(dev)
+        tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev), device=dev)
+        losses = []
+        for px, lat, noise, t, ids in batches:
+            out = tr.train_step(px.to(dev), ids.to(dev), pidx, noise=noise.to(dev), timesteps=t.to(dev), latents=lat.to(dev))
+            losses.append(torch.stack([o.detach().float() for o in out]).cpu())
+        torch.cuda.synchronize()
+        return torch.stack(losses), tr.flat.data.detach().cpu().clone()
+
+    l0, p0 = run()
+    l1, p1 = run()
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
