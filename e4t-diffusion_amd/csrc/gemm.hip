@@ -891,6 +891,238 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   write_tile<64, 64, 2, 2>(p, *(f32x16(*)[2][2])(acc + 2), smem, wave, lane, m0 + wr * 128 + 64, n0 + wc * 64);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 512 x 128 ("tall") ping-pong tile: the same phase machine with the operand roles exchanged, for outputs that are only
+// 128 columns wide (the VAE's 128-channel 3x3 convs at 512^2: M = 4.2 M rows, N = 128 — a 256-wide tile would be half empty
+// and the 128 x 128 tile reaches 680 TF/s there).
+//   * 8 waves = 2 groups (wr, 256 rows each) x 4 row slices (wc, 64 rows), wave tile 64 x 128 (2 x 4 accumulators);
+//   * phases = (k 0-31 | 32-63) x (columns 0-63 | 64-127): B fragments are read every phase, A fragments when nh == 0;
+//   * quarters: A = 512 rows x 32 k = 32 KiB (4 DMA instructions per wave), B = 128 rows x 32 k = 8 KiB (1 instruction);
+//     two buffers x two k-halves x (A + B) = 160 KiB = the whole LDS of a CU.  Any 4 consecutive quarters are 2 A + 2 B =
+//     10 instructions per wave, hence vmcnt(10) where the square kernel has vmcnt(8).  Issue order per K-tile:
+//     A-hi(t+1), B-hi(t+1), A-lo(t+2), B-lo(t+2) in phases 0..3 — every slot is re-staged 2 phases after its last read.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_pt_kernel(GemmArgs p) {
+  constexpr int BM = 512, BN = 128, HK = 32;
+  constexpr int QA = BM * HK, QB = BN * HK;              // elements per A / B quarter
+  constexpr int HALF = QA + QB;                          // one k-half of a buffer: [A | B]
+  constexpr int SMEM = 4 * HALF;                         // 81920 elements = 160 KiB
+  static_assert(8 * 64 * (64 + 8) <= SMEM, "epilogue staging must fit");
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  int tile_x, tile_y;
+  xcd_tile(tile_x, tile_y, p.group_m);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+
+  const int nkt = p.K / BK;
+  const int bz = blockIdx.z / p.splitk, sz = blockIdx.z - bz * p.splitk;
+  p.A += bz * p.strideA;
+  if (p.A2) p.A2 += bz * p.strideA;
+  p.B += bz * p.strideB;
+  if (p.bias) p.bias += bz * p.strideBias;
+  if (!p.reduce_batch) {
+    if (p.flags & E4T_OUT_F32) p.C = (float*)p.C + bz * p.strideC;
+    else p.C = (bf16_t*)p.C + bz * p.strideC;
+  }
+  const int kt_begin = sz * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nkt) kt_end = nkt;
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFF0000u;
+  // DMA: one wave-instruction = 16 rows x 64 B.  A: wave w feeds quarter rows 64w + 16j + (lane >> 2), j = 0..3; B: rows 16w + (lane >> 2)
+  const int drow = lane >> 2, dslot = lane & 3;
+  long long a_base[4];
+  int a_oy[4], a_ox[4], a_kc[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = wave * 64 + j * 16 + drow;
+    a_kc[j] = (dslot ^ ((r >> 2) & 3)) * 8;
+    const int gr = m0 + r;
+    a_ok[j] = gr < p.M;
+    if (MODE == 0) {
+      a_base[j] = (long long)gr; a_oy[j] = a_ox[j] = 0;
+    } else {
+      const int hw = p.Hout * p.Wout;
+      const int b = gr / hw;
+      const int rem = gr - b * hw;
+      a_oy[j] = rem / p.Wout;
+      a_ox[j] = rem - a_oy[j] * p.Wout;
+      a_base[j] = (long long)b * p.Hin * p.Win;
+    }
+  }
+  unsigned b_vo;
+  {
+    const int r = wave * 16 + drow;
+    const int kc = (dslot ^ ((r >> 2) & 3)) * 8;
+    const int gn = n0 + r;
+    b_vo = gn < p.N ? (unsigned)(((size_t)gn * p.ldb + kc) * 2) : OOB;
+  }
+  unsigned a_vo[4];
+  int a_so = 0, b_so = 0;
+  bool a_second = false;
+  auto place_a = [&](int k0) {
+    if (MODE == 0) {
+      int ld = p.lda, koff = k0;
+      a_second = k0 >= p.K1;
+      if (a_second) { ld = p.lda2; koff = k0 - p.K1; }
+      a_so = koff * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a_vo[j] = a_ok[j] ? (unsigned)((a_base[j] * ld + a_kc[j]) * 2) : OOB;
+    } else {
+      const int tap = k0 / p.Cin;
+      const int ci0 = k0 - tap * p.Cin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      a_so = ci0 * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int iy, ix;
+        bool ok = a_ok[j];
+        if (p.mode == E4T_CONV_S1) {
+          iy = a_oy[j] + ky - 1; ix = a_ox[j] + kx - 1;
+          ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        } else if (p.mode == E4T_CONV_S2) {
+          iy = 2 * a_oy[j] + ky - 1; ix = 2 * a_ox[j] + kx - 1;
+          ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        } else if (p.mode == E4T_CONV_UP2) {
+          iy = a_oy[j] + ky - 1; ix = a_ox[j] + kx - 1;
+          ok = ok && iy >= 0 && iy < 2 * p.Hin && ix >= 0 && ix < 2 * p.Win;
+          iy >>= 1; ix >>= 1;
+        } else if (p.mode == E4T_CONV_S2A) {
+          iy = 2 * a_oy[j] + ky; ix = 2 * a_ox[j] + kx;
+          ok = ok && iy < p.Hin && ix < p.Win;
+        } else {
+          const int sy = a_oy[j] + ky - 1, sx = a_ox[j] + kx - 1;
+          ok = ok && sy >= 0 && sx >= 0 && !(sy & 1) && !(sx & 1);
+          iy = sy >> 1; ix = sx >> 1;
+          ok = ok && iy < p.Hin && ix < p.Win;
+        }
+        a_vo[j] = ok ? (unsigned)(((a_base[j] + (long long)iy * p.Win + ix) * p.Cin + a_kc[j]) * 2) : OOB;
+      }
+    }
+  };
+  auto issue_a = [&](int kt, bool hi, bf16_t* dst) {
+    const int k0 = kt * BK;
+    const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
+    if (fresh) place_a(k0);
+    else a_so += HK * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 64 + j * 16) * HK);
+  };
+  auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
+    if (!hi && kt == kt_begin) b_so = kt * BK * 2;
+    else b_so += HK * 2;
+    buf_dma16(rs_b, b_vo, b_so, dst + (wave * 16) * HK);
+  };
+
+  f32x16 acc[2][2][2];          // [column half][row block][column block]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+  const int frow = lane & 31, fhi = lane >> 5;
+  int a_off[2][2], b_off[4][2];     // fragment offsets inside a quarter (elements), [block][k-step of the half]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = wr * 256 + wc * 64 + i * 32 + frow;
+      a_off[i][ks] = r * HK + (((ks * 2 + fhi) ^ ((r >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = j * 32 + frow;
+      b_off[j][ks] = r * HK + (((ks * 2 + fhi) ^ ((r >> 2) & 3)) * 8);
+    }
+  }
+  // buffer b = smem + 2b * HALF: [lo: A | B][hi: A | B]
+  issue_a(kt_begin, false, smem);
+  issue_b(kt_begin, false, smem + QA);
+  issue_a(kt_begin, true, smem + HALF);
+  issue_b(kt_begin, true, smem + HALF + QA);
+  if (kt_begin + 1 < kt_end) {
+    issue_a(kt_begin + 1, false, smem + 2 * HALF);
+    issue_b(kt_begin + 1, false, smem + 2 * HALF + QA);
+    wait_vmcnt<10>();              // 15 issued: the two lo quarters of the first K-tile have landed
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[2][2], bfr[2][2];
+  auto phase = [&](auto Bc, auto Pc, int kt) {
+    constexpr int b = decltype(Bc)::value, ph = decltype(Pc)::value;
+    constexpr int kh = ph >> 1, nh = ph & 1;
+    bf16_t* const buf = smem + b * 2 * HALF;
+    bf16_t* const other = smem + (b ^ 1) * 2 * HALF;
+    const bf16_t* const qa = buf + kh * HALF;
+    const bf16_t* const qb = qa + QA;
+    // ---- L segment ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = *(const bf16x8*)(qb + b_off[nh * 2 + j][ks]);
+    if (nh == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(qa + a_off[i][ks]);
+    }
+    bool staged;
+    if (ph == 0)      { staged = kt + 1 < kt_end; if (staged) issue_a(kt + 1, true, other + HALF); }
+    else if (ph == 1) { staged = kt + 1 < kt_end; if (staged) issue_b(kt + 1, true, other + HALF + QA); }
+    else if (ph == 2) { staged = kt + 2 < kt_end; if (staged) issue_a(kt + 2, false, buf); }
+    else              { staged = kt + 2 < kt_end; if (staged) issue_b(kt + 2, false, buf + QA); }
+    if (staged) wait_vmcnt<10>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M segment ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[nh][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[nh][i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+  if (wr == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier interval behind group 0
+  {
+    int kt = kt_begin;
+    for (; kt + 2 <= kt_end; kt += 2) {
+      phase(I0{}, I0{}, kt); phase(I0{}, I1{}, kt); phase(I0{}, I2{}, kt); phase(I0{}, I3{}, kt);
+      phase(I1{}, I0{}, kt + 1); phase(I1{}, I1{}, kt + 1); phase(I1{}, I2{}, kt + 1); phase(I1{}, I3{}, kt + 1);
+    }
+    if (kt < kt_end) { phase(I0{}, I0{}, kt); phase(I0{}, I1{}, kt); phase(I0{}, I2{}, kt); phase(I0{}, I3{}, kt); }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  __syncthreads();   // every fragment read and every DMA is done before the epilogue reuses the LDS
+  write_tile<64, 64, 2, 2>(p, acc[0], smem, wave, lane, m0 + wr * 256 + wc * 64, n0);
+  __syncthreads();
+  write_tile<64, 64, 2, 2>(p, acc[1], smem, wave, lane, m0 + wr * 256 + wc * 64, n0 + 64);
+}
+
 #ifdef PP_TRACE
 }  // namespace
 extern "C" int e4t_debug_pp_trace(unsigned long long* out) {
@@ -1046,7 +1278,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   int tile = tile_hint;
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
-  if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512) {
+  if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512 && tile != 640) {
     // measured on MI355X (tools/sweep_small.py): 128x128 wins from one full round of the 256 CUs, and already from
     // a quarter round when K is long (3x3 convs at the 16x16 / 8x8 levels) if split-K fills the chip
     const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch;
@@ -1060,9 +1292,17 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     static const bool no_pp = getenv("E4T_GEMM_NOPP") != nullptr;     // A/B switch
     if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && p.K % BK == 0 && nkt >= (conv ? 16 : 32) && (!p.A2 || p.K1 % BK == 0) &&
         (long long)cdiv(p.M, 256) * (p.N / 256) * batch >= 512) tile = 512;
+    // The 512 x 128 variant of the same machine (tile code 640) is NOT chosen automatically: on the shapes it was built for
+    // (the VAE's 128-channel convs, K = 1152 = 18 K-tiles) it measured 526 vs 588 TF/s for the 128 x 128 tile — one 160-KiB
+    // workgroup per CU leaves nothing to overlap its (large) epilogue and prologue with, and 18 K-tiles do not amortise
+    // them (tools/ab_pt.py).  E4T_GEMM_PT=1 turns the automatic choice on for experiments.
+    static const bool auto_pt = getenv("E4T_GEMM_PT") != nullptr;
+    if (auto_pt && allow256 && tile == 128 && p.N % 128 == 0 && p.N % 256 != 0 && p.K % BK == 0 && nkt >= 16 && !p.A2 &&
+        (long long)cdiv(p.M, 512) * (p.N / 128) * batch >= 512) tile = 640;
   }
   if (tile == 256 && !allow256) tile = 128;
   if (tile == 160 && !allow256) tile = 128;
+  if (tile == 640 && (!allow256 || p.A2)) tile = 128;
   // The DMA kernels address their operands through buffer resources (32-bit byte offsets): operands beyond 4 GB fall back to
   // the register-staged kernel.  The ping-pong kernel additionally needs whole K-tiles.
   bool buf_ok = true;
@@ -1073,10 +1313,12 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     else { ab = ((unsigned long long)(p.M - 1) * p.lda + p.K1) * 2; if (p.A2) a2b = ((unsigned long long)(p.M - 1) * p.lda2 + (p.K - p.K1)) * 2; }
     buf_ok = ab < lim && a2b < lim && bb < lim;
     if (tile == 512 && (!allow256 || !buf_ok || p.K % BK != 0 || (p.A2 && p.K1 % BK != 0))) tile = 128;
+    if (tile == 640 && (!buf_ok || p.K % BK != 0)) tile = 128;
     p.a_bytes = (unsigned)(buf_ok ? ab : 0); p.a2_bytes = (unsigned)(buf_ok ? a2b : 0); p.b_bytes = (unsigned)(buf_ok ? bb : 0);
     if (!buf_ok && tile != 64) tile = 128;       // the register-staged fallback exists as 128x128 and 64x64 only
   }
-  const int tm = tile == 160 ? 128 : (tile == 512 ? 256 : tile), tn = tile == 256 ? 128 : (tile == 512 ? 256 : tile);   // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong
+  // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong, 640 = 512x128 ping-pong
+  const int tm = tile == 160 ? 128 : (tile == 512 ? 256 : (tile == 640 ? 512 : tile)), tn = tile == 256 ? 128 : (tile == 512 ? 256 : (tile == 640 ? 128 : tile));
   const int gx = cdiv(p.N, tn), gy = cdiv(p.M, tm);
   // --- split-K: only when the grid underfills the chip and K is long ---
   int splitk = splitk_req;
@@ -1122,6 +1364,10 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_pp_kernel<0>), grid, block, 0, st, p);
+    } else if (tile == 640) {
+      block = dim3(512);
+      if (conv) hipLaunchKernelGGL((gemm_pt_kernel<1>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_pt_kernel<0>), grid, block, 0, st, p);
     } else if (tile == 256) {
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3>), grid, block, 0, st, p);

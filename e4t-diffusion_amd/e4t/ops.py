@@ -9,6 +9,7 @@ never installs another backend: with no GPU / no built library every call raises
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -59,20 +60,25 @@ def _rowmajor(t: torch.Tensor, name: str):
 
 
 
+_AUTO_PT = os.environ.get("E4T_GEMM_PT") is not None      # mirror of the launcher's opt-in switch for the 512x128 tile
+
+
 def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch, conv=False):
     """Mirror of launch_gemm()'s tile / split-K heuristic (csrc/gemm.hip) -> workspace bytes it will want."""
     cd = lambda a, b: (a + b - 1) // b
     nkt = cd(K, 64)
-    if tile not in (64, 128, 256, 160, 512):
+    if tile not in (64, 128, 256, 160, 512, 640):
         t128 = cd(M, 128) * cd(N, 128) * nb
         tile = 128 if (t128 >= 256 or (nkt >= 32 and t128 >= 64)) else 64
         if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
             tile = 160
         if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= (16 if conv else 32) and cd(M, 256) * (N // 256) * nb >= 512:
             tile = 512
-    if tile == 512 and K % 64:
+        if _AUTO_PT and tile == 128 and N % 128 == 0 and N % 256 and K % 64 == 0 and nkt >= 16 and cd(M, 512) * (N // 128) * nb >= 512:
+            tile = 640          # opt-in (E4T_GEMM_PT=1): measured slower than 128x128 on the shapes it targets
+    if tile in (512, 640) and K % 64:
         tile = 128
-    tn, tm = {256: 128, 512: 256}.get(tile, tile), {160: 128, 512: 256}.get(tile, tile)
+    tn, tm = {256: 128, 512: 256, 640: 128}.get(tile, tile), {160: 128, 512: 256, 640: 512}.get(tile, tile)
     tiles = cd(N, tn) * cd(M, tm) * nb
     if splitk <= 0:
         splitk = 1
@@ -144,7 +150,7 @@ class HipBackend:
     @staticmethod
     def _tile(M, N, K, nb, tile, conv=False):
         """Mirror of launch_gemm()'s tile choice (csrc/gemm.hip), used only to label bench.py's per-kernel timings."""
-        if tile in (64, 128, 256, 160, 512):
+        if tile in (64, 128, 256, 160, 512, 640):
             return tile
         cd = lambda a, b: (a + b - 1) // b
         t128 = cd(M, 128) * cd(N, 128) * nb
@@ -153,6 +159,8 @@ class HipBackend:
             tile = 160
         if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= (16 if conv else 32) and cd(M, 256) * (N // 256) * nb >= 512:
             tile = 512
+        if _AUTO_PT and tile == 128 and N % 128 == 0 and N % 256 and K % 64 == 0 and cd(K, 64) >= 16 and cd(M, 512) * (N // 128) * nb >= 512:
+            tile = 640
         return tile
 
     # ------------------------------------------------------------------ workspaces

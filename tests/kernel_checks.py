@@ -54,6 +54,7 @@ def check_gemm(hip, emu, dev):
         (700, 320, 1280, 256, 2), (900, 320, 384, 160, 1), (300, 480, 128, 160, 2), (513, 200, 72, 160, 1),
         (512, 512, 512, 512, 1), (700, 520, 256, 512, 1), (300, 256, 64, 512, 1), (1000, 300, 128, 512, 1), (513, 1000, 1152, 512, 2),
         (2048, 1280, 1920, 512, 0), (257, 64, 192, 512, 1),
+        (1024, 128, 512, 640, 1), (700, 128, 1152, 640, 1), (1300, 384, 256, 640, 1), (513, 100, 64, 640, 1), (2048, 128, 2048, 640, 0), (4096, 128, 4096, 640, 3),
     ]
     for i, (M, N, K, tile, sk) in enumerate(cases):
         g = gen(10 + i, dev)
@@ -130,6 +131,8 @@ def check_conv(hip, emu, dev):
         (3, 24, 24, 64, 320, CONV_S1, 24, 24, 512, 1), (2, 32, 32, 128, 256, CONV_S1, 32, 32, 512, 1), (2, 16, 16, 256, 512, CONV_S1, 16, 16, 512, 2),
         (3, 16, 16, 64, 128, CONV_S2, 8, 8, 512, 1), (2, 8, 8, 64, 64, CONV_UP2, 16, 16, 512, 1), (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 512, 1),
         (1, 64, 64, 128, 128, 5, 32, 32, 512, 1),
+        (2, 32, 32, 128, 128, CONV_S1, 32, 32, 640, 1), (1, 48, 40, 64, 128, CONV_S1, 48, 40, 640, 1), (3, 16, 16, 128, 384, CONV_S1, 16, 16, 640, 2),
+        (1, 64, 64, 128, 128, 5, 32, 32, 640, 1), (2, 16, 16, 128, 128, CONV_UP2, 32, 32, 640, 1), (2, 32, 32, 128, 128, CONV_S2, 16, 16, 640, 1),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
         g = gen(50 + i, dev)
