@@ -236,8 +236,12 @@ class StableDiffusionE4TPipeline:
                 if callback is not None and i % callback_steps == 0:
                     callback(i, timesteps[i], latents)
         else:
-            extra = {"eta": eta} if isinstance(sch, DDIMScheduler) else {}
-            if isinstance(sch, DDIMScheduler) and generator is not None:
+            import inspect
+            accepted = set(inspect.signature(sch.step).parameters)          # prepare_extra_step_kwargs of the reference's base class
+            extra = {}
+            if "eta" in accepted:
+                extra["eta"] = eta
+            if "generator" in accepted and generator is not None:
                 extra["generator"] = generator
             for i, t in enumerate(timesteps):
                 pred = self._model_step(latents, t, s)

@@ -6,7 +6,7 @@
 optionally text_encoder.pt); the base Stable Diffusion weights are read from the directory named in its config
 (state dicts unet.pt / vae.pt / text_encoder.pt and a tokenizer/ folder) — there is no hub access here.  With
 --random_init everything is randomly initialised and an offline whitespace tokenizer is used (smoke runs, benchmarks).
-Only the DDIM sampler of the reference's six is built.
+All six samplers of the reference are available; DDIM additionally has the fused, graph-replayed update.
 """
 import argparse
 import json
@@ -40,7 +40,7 @@ def parse_args():
     p.add_argument("--height", type=int, default=512)
     p.add_argument("--width", type=int, default=512)
     p.add_argument("--seed", type=int, default=None)
-    p.add_argument("--scheduler_type", type=str, choices=["ddim"], default="ddim")
+    p.add_argument("--scheduler_type", type=str, choices=["ddim", "plms", "lms", "euler", "euler_ancestral", "dpm_solver++"], default="ddim")
     p.add_argument("--enable_xformers_memory_efficient_attention", action="store_true")
     p.add_argument("--random_init", action="store_true", help="random weights + offline tokenizer (no checkpoint needed)")
     p.add_argument("--unet_variant", type=str, default="sd14", choices=["sd14", "sd21"])

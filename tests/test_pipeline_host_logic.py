@@ -101,3 +101,24 @@ def test_pipeline_argument_errors(emu_fp32):
         from e4t.pipeline_stable_diffusion_e4t import StableDiffusionE4TPipeline
         StableDiffusionE4TPipeline(vae=pipe.vae, text_encoder=text, tokenizer=tok, unet=n_unet, e4t_encoder=n_enc, scheduler=pipe.scheduler,
                                    e4t_config=dict(placeholder_token="*s", domain_class_token="art", domain_embed_scale=0.1))
+
+
+@pytest.mark.parametrize("name", ["plms", "lms", "euler", "euler_ancestral", "dpm_solver++"])
+def test_pipeline_runs_every_sampler(emu_fp32, name):
+    """the generic path (scale_model_input / step(...).prev_sample / PLMS's extra timestep) end to end on the tiny models"""
+    from e4t.schedulers import SCHEDULER_MAPPING
+    from e4t.vae import VAEDecoder
+    r_unet, r_enc, n_unet, n_enc, text = build()
+    torch.manual_seed(3)
+    vae = VAEDecoder(block_out_channels=(64, 64)).requires_grad_(False)
+    pipe, tok = _pipeline(n_unet, n_enc, text, vae)
+    pipe.scheduler = SCHEDULER_MAPPING[name].stable_diffusion()
+    g = torch.Generator().manual_seed(5)
+    image = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    calls = []
+    out = pipe("a painting of *s", height=32, width=32, num_inference_steps=4, guidance_scale=3.0, image=image, output_type="latent",
+               generator=torch.Generator().manual_seed(1), callback=lambda i, t, l: calls.append(float(t))).images
+    assert out.shape == (1, 4, 16, 16) and torch.isfinite(out).all()
+    assert len(calls) == (5 if name == "plms" else 4)
+    with pytest.raises(ValueError, match="graph replay"):
+        pipe("a painting of *s", height=32, width=32, num_inference_steps=2, image=image, use_graph=True)
