@@ -2,6 +2,9 @@
 import os
 import re
 
+import pytest
+import torch
+
 from e4t import _C
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,3 +64,18 @@ def test_descriptor_structs_match_the_header(tmp_path):
         assert got[(cname, "sizeof")] == C.sizeof(cls), (cname, got[(cname, "sizeof")], C.sizeof(cls))
         for fname, _ in cls._fields_:
             assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No CPU / PyTorch fallback: without libe4t_hip.so the binding raises, and so does the first use of the op backend."""
+    from e4t import _C, ops
+    monkeypatch.setattr(_C, "_lib", None)
+    monkeypatch.setattr(_C, "LIB_PATH", str(tmp_path / "libe4t_hip.so"))
+    with pytest.raises(_C.E4TError, match="no CPU / PyTorch fallback"):
+        _C.load()
+    monkeypatch.setattr(ops, "_backend", None)
+    with pytest.raises(_C.E4TError):
+        ops.backend()
+    from e4t.vae import VAEEncoder
+    with pytest.raises(_C.E4TError):
+        VAEEncoder(block_out_channels=(64, 64)).moments(torch.zeros(1, 3, 16, 16))
