@@ -18,7 +18,6 @@ What runs instead of the reference's ops:
 """
 from __future__ import annotations
 
-from typing import Optional
 
 import torch
 from torch import nn

@@ -7,7 +7,6 @@ in Python; tokens of a transformer block are the same matrix (no NCHW<->NLC perm
 """
 from __future__ import annotations
 
-from typing import Optional
 
 import torch
 

@@ -6,7 +6,7 @@ from __future__ import annotations
 
 from torch import nn
 
-from .resnet import Downsample2D, FMap, ResnetBlock2D, Upsample2D
+from .resnet import Downsample2D, ResnetBlock2D, Upsample2D
 from .transformer_2d import Transformer2DModel
 
 

@@ -14,7 +14,7 @@ text encoder -> UNet full pass -> MSE + lambda * |e|^2 -> backward -> AdamW.
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import contextlib
 import os
