@@ -222,7 +222,7 @@ def main():
         image_grid(outs, rows=len(prompts), cols=len(pils)).save(os.path.join(d, f"sample-{step}.png"))
         unet.train(was_training)
 
-    t0 = time.perf_counter()
+    t_mark, step_mark = time.perf_counter(), 0
     for step in range(1, args.max_train_steps + 1):
         batch = next(data)
         loss, ld, lr_ = tr.train_step(*batch)
@@ -230,10 +230,11 @@ def main():
             sample(batch[0], step)
         if step % 10 == 0 or step == 1:
             torch.cuda.synchronize()
-            if rank == 0:
-                dt = time.perf_counter() - t0
+            now = time.perf_counter()
+            if rank == 0:                                   # rate over the window since the previous report (step 1 includes warm-up)
                 print(f"step {step}: train/loss {float(loss):.5f} loss_diff {float(ld):.5f} loss_reg {float(lr_):.5f} "
-                      f"lr {lr:.3e}  {args.train_batch_size * world * step / dt:.1f} img/s", flush=True)
+                      f"lr {lr:.3e}  {args.train_batch_size * world * (step - step_mark) / (now - t_mark):.1f} img/s", flush=True)
+            t_mark, step_mark = now, step
         if step % args.checkpointing_steps == 0:
             save(step)
     if world > 1:
