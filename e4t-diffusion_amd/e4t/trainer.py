@@ -214,8 +214,10 @@ class E4TTrainer:
         else:
             self._head_last = 0
 
-    def _reduce_region(self, key):
-        if self.regions is None or key in self._done or not self._armed:
+    def _reduce_region(self, key, force=False):
+        """enqueue the all-reduce of one region; during the backward only while a synchronising step is armed, `force` for the
+        sweep after the backward that picks up whatever no hook announced"""
+        if self.regions is None or key in self._done or not (self._armed or force):
             return
         self._done.add(key)
         a, b = self.regions[key]
@@ -234,7 +236,7 @@ class E4TTrainer:
                 torch.distributed.all_reduce(g[o:o + bucket], group=self.pg)
             return
         for key in ("U", "H", "D"):           # whatever was not triggered during the backward
-            self._reduce_region(key)
+            self._reduce_region(key, force=True)
         for w in self._works:
             w.wait()
         self._works, self._done = [], set()
@@ -256,8 +258,27 @@ class E4TTrainer:
     def zero_grad(self):
         self.flat.grad.zero_()
 
-    def train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None):
-        """Full step.  Random draws may be passed in (parity tests) or are sampled on the device."""
+    # ---- training state (accelerator.save_state / load_state of the reference, pretrain_e4t.py:536-558,659-663) ----------
+    def state_dict(self):
+        return dict(params=self.flat.data.detach().cpu().clone(), exp_avg=self.exp_avg.cpu().clone(), exp_avg_sq=self.exp_avg_sq.cpu().clone(),
+                    step_count=self.step_count, lr=self.lr)
+
+    def load_state_dict(self, sd):
+        if sd["params"].numel() != self.flat.data.numel():
+            raise RuntimeError(f"training state holds {sd['params'].numel()} parameters, this trainer {self.flat.data.numel()}")
+        self.flat.data.copy_(sd["params"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step_count"])
+        self.flat.grad.zero_()
+        ops.bump_weights_epoch()                 # bf16 compute copies of the trainable weights are stale now
+
+    def train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None,
+                   sync=True, loss_scale=1.0):
+        """Full step.  Random draws may be passed in (parity tests) or are sampled on the device.
+        Gradient accumulation (``accelerator.accumulate``, pretrain_e4t.py:595): call with ``sync=False`` and
+        ``loss_scale=1/k`` for the first k-1 micro-batches — gradients accumulate locally, no collective, no optimiser step —
+        and with ``sync=True`` (same loss_scale) for the k-th."""
         dev = self.device
         B = pixel_values.shape[0]
         if latents is None:
@@ -270,14 +291,16 @@ class E4TTrainer:
         if timesteps is None:
             timesteps = torch.randint(0, self.acp.shape[0], (B,), device=dev).long()
         loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
-        self._armed = True
+        self._armed = bool(sync)             # micro-batches that only accumulate start no collectives
         self._head_pending = getattr(self, "_head_last", 0)
         Fn.set_inplace_param_grads(True)     # weight / bias gradients accumulate straight into the flat buffer (functional.py)
         try:
-            loss.backward()
+            (loss if loss_scale == 1.0 else loss * loss_scale).backward()
         finally:
             Fn.set_inplace_param_grads(False)
         self._armed = False
+        if not sync:
+            return loss.detach(), loss_diff.detach(), loss_reg.detach()
         self.all_reduce_grads()
         self.clip_grad_norm()
         self.optimizer_step()

@@ -49,7 +49,8 @@ def parse_args():
     p.add_argument("--train_batch_size", type=int, default=16)
     p.add_argument("--learning_rate", type=float, default=1e-6)
     p.add_argument("--scale_lr", action="store_true")
-    p.add_argument("--lr_scheduler", type=str, default="constant")
+    p.add_argument("--lr_scheduler", type=str, default="constant",
+                   choices=["linear", "cosine", "cosine_with_restarts", "polynomial", "constant", "constant_with_warmup"])
     p.add_argument("--lr_warmup_steps", type=int, default=0)
     p.add_argument("--gradient_accumulation_steps", type=int, default=1)
     p.add_argument("--max_train_steps", type=int, default=30000)
@@ -77,8 +78,8 @@ def parse_args():
         p.error("--use_8bit_adam (bitsandbytes) is CUDA-only and not part of the MI355X path; the fused fp32 AdamW kernel is used")
     if args.mixed_precision == "fp16":
         p.error("the native kernels compute in bf16 with fp32 accumulation; use --mixed_precision bf16")
-    if args.gradient_accumulation_steps != 1:
-        p.error("gradient accumulation > 1 is not wired into this script yet")
+    if args.gradient_accumulation_steps < 1:
+        p.error("--gradient_accumulation_steps must be >= 1")
     env_rank = int(os.environ.get("LOCAL_RANK", -1))
     if env_rank != -1:
         args.local_rank = env_rank
@@ -150,6 +151,7 @@ def main():
         random.seed(args.seed)
 
     from bench import build_models                               # same model factory as the benchmark
+    from e4t.optimization import LRSchedule
     from e4t.trainer import E4TTrainer
     from e4t.utils import save_config, save_e4t_encoder, save_e4t_unet
     unet, enc, text, vae = build_models(dev, args.unet_variant, seed=args.seed or 0)
@@ -173,13 +175,36 @@ def main():
         raise SystemExit("give --train_image_dataset <dir[::dir]>, --webdataset --train_image_dataset <shards{000..NNN}.tar>, or "
                          "--synthetic_data; HF-hub streaming (--iterable_dataset) needs network access")
 
-    def save(step):
+    ga = args.gradient_accumulation_steps
+    # reference :402-408: warm-up and horizon are given in micro-steps, and accelerate's scheduler wrapper advances the schedule
+    # once per PROCESS on every optimiser step (AcceleratedScheduler.step, split_batches=False) — mirrored below
+    sched = LRSchedule(args.lr_scheduler, lr, args.lr_warmup_steps * ga, args.max_train_steps * ga)
+    first_step = 1
+    if args.resume_from_checkpoint:                                                              # reference :536-558
+        path = args.resume_from_checkpoint
+        if path == "latest":
+            dirs = [d for d in (os.listdir(args.output_dir) if os.path.isdir(args.output_dir) else []) if d.startswith("checkpoint-")]
+            path = os.path.join(args.output_dir, max(dirs, key=lambda d: int(d.split("-")[1]))) if dirs else None
+        if path is None or not os.path.exists(os.path.join(path, "trainer_state.pt")):
+            print(f"Checkpoint '{args.resume_from_checkpoint}' does not exist. Starting a new training run.")
+        else:
+            print(f"Resuming from checkpoint {path}")
+            tr.load_state_dict(torch.load(os.path.join(path, "trainer_state.pt"), map_location="cpu"))
+            first_step = tr.step_count + 1
+            sched.step_count = tr.step_count * world
+
+    def save(step, state=False):
         if rank != 0:
             return
         d = os.path.join(args.output_dir, str(step))
         save_config(vars(args), d)
         save_e4t_unet(unet, d)
         save_e4t_encoder(enc, d)
+        if state:       # accelerator.save_state (:660-662): parameters + Adam moments + step, enough to resume bit for bit
+            cd = os.path.join(args.output_dir, f"checkpoint-{step}")
+            os.makedirs(cd, exist_ok=True)
+            torch.save(tr.state_dict(), os.path.join(cd, "trainer_state.pt"))
+            print(f"Saved state to {cd}")
 
     pipe_parts = {}
 
@@ -222,10 +247,14 @@ def main():
         image_grid(outs, rows=len(prompts), cols=len(pils)).save(os.path.join(d, f"sample-{step}.png"))
         unet.train(was_training)
 
-    t_mark, step_mark = time.perf_counter(), 0
-    for step in range(1, args.max_train_steps + 1):
-        batch = next(data)
-        loss, ld, lr_ = tr.train_step(*batch)
+    t_mark, step_mark = time.perf_counter(), first_step - 1
+    for step in range(first_step, args.max_train_steps + 1):
+        sched.apply(tr)
+        for micro in range(ga):          # accelerator.accumulate: k micro-batches, loss / k each, one optimiser step
+            batch = next(data)
+            loss, ld, lr_ = tr.train_step(*batch, sync=micro == ga - 1, loss_scale=1.0 / ga)
+        for _ in range(world):
+            sched.step()
         if step % args.log_steps == 0 and rank == 0:
             sample(batch[0], step)
         if step % 10 == 0 or step == 1:
@@ -233,10 +262,10 @@ def main():
             now = time.perf_counter()
             if rank == 0:                                   # rate over the window since the previous report (step 1 includes warm-up)
                 print(f"step {step}: train/loss {float(loss):.5f} loss_diff {float(ld):.5f} loss_reg {float(lr_):.5f} "
-                      f"lr {lr:.3e}  {args.train_batch_size * world * (step - step_mark) / (now - t_mark):.1f} img/s", flush=True)
+                      f"lr {tr.lr:.3e}  {args.train_batch_size * world * ga * (step - step_mark) / (now - t_mark):.1f} img/s", flush=True)
             t_mark, step_mark = now, step
         if step % args.checkpointing_steps == 0:
-            save(step)
+            save(step, state=True)
     if world > 1:
         dist.barrier()
     save(args.max_train_steps)

@@ -45,13 +45,15 @@ def _batch(rank):
                 pidx=torch.tensor([3]))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, unfreeze):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from e4t.trainer import E4TTrainer
     _, _, n_unet, n_enc, text = _build()
+    if unfreeze:
+        n_enc.clip_vision.requires_grad_(True)
     tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"))
     assert tr.world == world
     b = _batch(rank)
@@ -61,9 +63,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_accumulated_single_process(tmp_path):
+@pytest.mark.parametrize("unfreeze", [False, True], ids=["vit_frozen", "vit_trainable"])
+def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
+    """vit_trainable: no hook announces the head region during the backward, the post-backward sweep must reduce it"""
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), unfreeze), nprocs=world, join=True)
     p0, p1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(p0, p1), "ranks diverged after the all-reduced step"
     # single process: accumulate both batches' gradients, average inside AdamW
@@ -73,6 +77,8 @@ def test_two_rank_step_matches_accumulated_single_process(tmp_path):
     try:
         from e4t.trainer import E4TTrainer
         _, _, n_unet, n_enc, text = _build()
+        if unfreeze:
+            n_enc.clip_vision.requires_grad_(True)
         tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"))
         for r in range(world):
             b = _batch(r)
