@@ -16,11 +16,22 @@ before ``ln_post``), kornia resize (bicubic, align_corners=True, antialias=False
 ``F.interpolate(mode="bicubic", align_corners=True)``.
 
 PARITY PINNING.  The reference has no tests, golden vectors or fixtures for this path (SURVEY.md
-§4, §8c).  The only reference file that imports in the build container is e4t/weightoffsets.py;
-``WeightOffsets`` below is pinned bit-for-bit against it by tests/golden/weightoffsets_*.pt
-(generated by tests/golden/make_golden.py, which imports /root/reference).  Everything else is
-**parity unpinned**: anchored on the reference's call sites and on the one known answer the
-reference states (UNet encoder feature width 10880, e4t/models/unet_2d_condition.py:586).
+§4, §8c), so the fixtures were produced by running the reference itself in the build container:
+  * ``WeightOffsets`` is pinned bit-for-bit against e4t/weightoffsets.py (the one reference file that
+    imports as is): tests/golden/weightoffsets_*.pt, generator tests/golden/make_golden.py.
+  * ``CrossAttention`` (math and SDPA processors), the transformer / UNet blocks, ``UNet2DConditionModel``
+    (SD-1 and SD-2 style configs: 13 encoder maps, sample, python-int timestep path, gradients of all
+    96 x 9 weight-offset tensors) and ``E4TEncoder`` (output + every parameter gradient) are pinned against
+    the reference's own e4t/models/*.py and e4t/encoder.py, executed UNMODIFIED on stand-ins for their
+    third-party imports (tests/golden/shims, generator tests/golden/make_golden_models.py, fixtures
+    tests/golden/reference_*.pt, replayed by tests/test_reference_golden.py at rtol 2e-5).
+  * Still **parity unpinned**: the third-party leaves themselves (diffusers ResnetBlock2D /
+    Down/Upsample2D / Timesteps / TimestepEmbedding / AutoencoderKL / schedulers, the open_clip ViT, kornia's
+    resize) — the stand-ins use this file's restatements of them —, the CLIP text encoder
+    (e4t/models/modeling_clip.py needs transformers internals that no longer exist) and the training-step
+    glue of pretrain_e4t.py (needs accelerate/diffusers/datasets at import).  They are anchored on the
+    reference's call sites and on the known answer it states (UNet encoder feature width 10880,
+    e4t/models/unet_2d_condition.py:586).
 """
 from __future__ import annotations
 
@@ -425,7 +436,12 @@ class UNet2DConditionModel(nn.Module):
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)                # :285-287
 
     def forward(self, sample, timestep, encoder_hidden_states, return_encoder_outputs=False):
-        t = timestep.expand(sample.shape[0])
+        t = timestep
+        if not torch.is_tensor(t):                                                   # :446-455
+            t = torch.tensor([t], dtype=torch.float64 if isinstance(t, float) else torch.int64, device=sample.device)
+        elif t.dim() == 0:
+            t = t[None].to(sample.device)
+        t = t.expand(sample.shape[0])                                                # :458
         emb = self.time_embedding(timestep_embedding(t, self.cfg["block_out_channels"][0],
                                                      self.cfg["flip_sin_to_cos"], self.cfg["freq_shift"]))  # :461-468
         x = self.conv_in(sample)                                                     # :481

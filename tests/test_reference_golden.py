@@ -1,0 +1,90 @@
+"""CPU: the oracle against what THE REFERENCE'S OWN CODE computed (tests/golden/reference_*.pt, generated in the build
+container by tests/golden/make_golden_models.py, which runs /root/reference/e4t/models/*.py and e4t/encoder.py unmodified
+on stand-ins for their third-party imports).  This pins the oracle for everything the reference itself wrote — the
+weight-offset modulated attention processors (math and SDPA paths), transformer blocks, UNet block wiring, the 13-map
+early return, the sample output, the gradients of all 96 x 9 weight-offset tensors, the E4T encoder head — leaving only
+the restated third-party leaves (ResnetBlock2D, Down/Upsample2D, time embedding, the ViT, the bicubic resize) unpinned."""
+import os
+
+import pytest
+import torch
+
+import e4t_oracle as orc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def unpack(packed):
+    flat, spec = packed
+    out, o = {}, 0
+    for name, shape in spec:
+        n = 1
+        for d in shape:
+            n *= d
+        out[name] = flat[o:o + n].view(shape).clone()
+        o += n
+    assert o == flat.numel()
+    return out
+
+
+def close(a, b, what, rtol=2e-5, atol=2e-6):
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
+
+
+@pytest.mark.parametrize("variant", ["sd1", "sd2"])
+def test_unet_matches_reference_code(variant):
+    blob = torch.load(os.path.join(GOLD, "reference_unet.pt"))[variant]
+    unet = orc.UNet2DConditionModel(**blob["config"])
+    sd = unpack(blob["state_dict"])
+    missing, unexpected = unet.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected                                   # same parameter names as the reference's state dict
+    enc = unet(blob["sample"], blob["timestep"], blob["ctx"], return_encoder_outputs=True)["down_block_samples"]
+    assert len(enc) == 13 and sum(e.shape[1] for e in enc) == sum(e.shape[1] for e in blob["down_block_samples"])
+    for i, (a, b) in enumerate(zip(enc, blob["down_block_samples"])):
+        close(a, b, f"encoder map {i}")
+    out = unet(blob["sample"], blob["timestep"], blob["ctx"])
+    out = out.sample if hasattr(out, "sample") else out
+    close(out, blob["out"], "sample")
+    one = unet(blob["sample"][:1], 500, blob["ctx"][:1])
+    close(one.sample if hasattr(one, "sample") else one, blob["out_scalar_t"], "python-int timestep")
+    (out * blob["G"]).sum().backward()
+    want = unpack(blob["wo_grads"])
+    got = {n: p.grad for n, p in unet.named_parameters() if "wo" in n}
+    assert got.keys() == want.keys() and len(want) == 96 * 9
+    for n in want:
+        close(got[n], want[n], f"grad {n}", rtol=2e-4, atol=2e-6)
+    close(unet.conv_in.weight.grad, blob["grad_conv_in"], "grad conv_in", rtol=2e-4, atol=2e-5)      # the deepest gradient: fp32 summation order
+
+
+@pytest.mark.parametrize("kind", ["self", "cross"])
+def test_attention_processors_match_reference_code(kind):
+    blob = torch.load(os.path.join(GOLD, "reference_attention.pt"))[kind]
+    attn = orc.CrossAttention(**blob["kwargs"])
+    attn.load_state_dict(unpack(blob["state_dict"]), strict=True)
+    close(blob["math"]["out"], blob["sdpa"]["out"], "the reference's two processors agree with each other", rtol=1e-5, atol=1e-6)
+    y = attn(blob["x"], blob["ctx"])
+    close(y, blob["math"]["out"], "CrossAttnProcessor output")
+    close(y, blob["sdpa"]["out"], "AttnProcessor2_0 output")
+    y.square().sum().backward()
+    want = unpack(blob["sdpa"]["grads"])
+    for n, p in attn.named_parameters():
+        close(p.grad, want[n], f"grad {n}", rtol=2e-4, atol=2e-6)
+
+
+def test_e4t_encoder_matches_reference_code():
+    blob = torch.load(os.path.join(GOLD, "reference_encoder.pt"))
+    vit = dict(image_size=224, patch_size=56, width=8, layers=2, heads=2, mlp_ratio=2.0)
+    enc = orc.E4TEncoder(vit_cfg=vit, freeze_clip_vision=False, **blob["kwargs"])
+    sd = unpack(blob["state_dict"])
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k in ("mean", "std") for k in missing)   # the reference registers mean/std as non-persistent buffers
+    y = enc(blob["x"], tuple(blob["maps"]))
+    close(y, blob["out"], "domain embedding")
+    y.square().sum().backward()
+    want = unpack(blob["grads"])
+    got = {n: p.grad for n, p in enc.named_parameters() if p.grad is not None}
+    assert got.keys() == want.keys()
+    for n in want:
+        close(got[n], want[n], f"grad {n}", rtol=2e-4, atol=2e-6)
+    pre = orc.clip_preprocess(blob["x"]) if hasattr(orc, "clip_preprocess") else enc.preprocess(blob["x"])
+    close(pre[:, :, ::16, ::16], blob["preprocessed"], "CLIP input (224 x 224 bicubic, normalised)")
