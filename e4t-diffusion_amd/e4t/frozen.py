@@ -86,6 +86,14 @@ class CLIPTextModel(nn.Module):
     def get_input_embeddings(self):
         return self.text_model.embeddings.token_embedding
 
+    @property
+    def device(self):            # transformers' PreTrainedModel surface the reference's pipeline reads (pipeline_stable_diffusion_e4t.py:60,83)
+        return self.text_model.embeddings.token_embedding.weight.device
+
+    @property
+    def dtype(self):
+        return self.text_model.embeddings.token_embedding.weight.dtype
+
     def resize_token_embeddings(self, new_num_tokens: int):
         """transformers' PreTrainedModel.resize_token_embeddings for the input embedding: keep the existing rows, new rows
         N(0, 0.02) (the reference grows the table by the placeholder token, pipeline_stable_diffusion_e4t.py:53)"""

@@ -25,6 +25,10 @@ PARITY PINNING.  The reference has no tests, golden vectors or fixtures for this
     the reference's own e4t/models/*.py and e4t/encoder.py, executed UNMODIFIED on stand-ins for their
     third-party imports (tests/golden/shims, generator tests/golden/make_golden_models.py, fixtures
     tests/golden/reference_*.pt, replayed by tests/test_reference_golden.py at rtol 2e-5).
+  * ``e4t_sample`` (the denoising loop) is pinned against the reference's StableDiffusionE4TPipeline.__call__
+    (e4t/pipeline_stable_diffusion_e4t.py, run unmodified on a stand-in for the diffusers base pipeline, with the
+    reference UNet, a stand-in E4T encoder — the real one hard-codes the full-size 10880 features —, the torch CLIP
+    text twin and this file's DDIMScheduler): final latents with and without guidance.
   * Still **parity unpinned**: the third-party leaves themselves (diffusers ResnetBlock2D /
     Down/Upsample2D / Timesteps / TimestepEmbedding / AutoencoderKL / schedulers, the open_clip ViT, kornia's
     resize) — the stand-ins use this file's restatements of them —, the CLIP text encoder

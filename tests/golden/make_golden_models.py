@@ -14,7 +14,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path[:0] = [os.path.join(HERE, "shims"), "/root/reference", os.path.join(ROOT, "oracle")]
+sys.path[:0] = [os.path.join(HERE, "shims"), "/root/reference", os.path.join(ROOT, "oracle"), HERE]
+# NB: e4t-diffusion_amd/ must NOT be on sys.path here — its package is also called `e4t` and would shadow the reference's
 
 import torch  # noqa: E402
 
@@ -30,6 +31,7 @@ SD_MAP_CHANNELS = (320, 320, 320, 320, 640, 640, 640, 1280, 1280, 1280, 1280, 12
 
 def unet_fixture():
     from e4t.models.unet_2d_condition import UNet2DConditionModel           # the reference's class
+    assert sys.modules[UNet2DConditionModel.__module__].__file__.startswith("/root/reference/")
     cfg = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(8, 8, 16, 16), layers_per_block=2,
                cross_attention_dim=12, attention_head_dim=2, norm_num_groups=2, norm_eps=1e-5,
                down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
@@ -79,6 +81,7 @@ def attention_fixture():
 
 def encoder_fixture():
     from e4t.encoder import E4TEncoder                                       # the reference's class
+    assert sys.modules[E4TEncoder.__module__].__file__.startswith("/root/reference/")
     torch.manual_seed(4)
     enc = E4TEncoder(word_embedding_dim=24, arch="ViT-golden-test", version="none", n_odd_layers=9, freeze_clip_vision=False)
     g = torch.Generator().manual_seed(5)
@@ -92,11 +95,71 @@ def encoder_fixture():
                 x=x, maps=maps, out=y.detach(), grads=pack(grads), preprocessed=pre)
 
 
+def pipeline_fixture(unet_blob):
+    """the reference's StableDiffusionE4TPipeline.__call__ (pipeline_stable_diffusion_e4t.py:91-250) on: the reference UNet with
+    the 'sd1' fixture weights, a stand-in E4T encoder, this repository's torch CLIP text twin, the offline tokenizer and the
+    oracle's DDIM restatement behind the diffusers scheduler call surface"""
+    import types
+
+    import importlib.util
+
+    import e4t_oracle as orc
+    from e4t.models.unet_2d_condition import UNet2DConditionModel        # the reference's classes
+    from e4t.pipeline_stable_diffusion_e4t import StableDiffusionE4TPipeline
+
+    def native(name):            # single files of this repository's package, loaded under another name (no `e4t` clash)
+        spec = importlib.util.spec_from_file_location(f"native_{name}", os.path.join(ROOT, "e4t-diffusion_amd", "e4t", f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    CLIPTextModel, WhitespaceTokenizer = native("frozen").CLIPTextModel, native("utils").WhitespaceTokenizer
+    from standin import PROMPT, TEXT_CFG, StandInEncoder
+    for cls in (UNet2DConditionModel, StableDiffusionE4TPipeline):
+        assert sys.modules[cls.__module__].__file__.startswith("/root/reference/"), cls
+
+    class Sched(orc.DDIMScheduler):
+        def set_timesteps(self, n, device=None):
+            super().set_timesteps(n)
+
+        def step(self, model_output, timestep, sample, eta=0.0, generator=None):
+            return types.SimpleNamespace(prev_sample=super().step(model_output, timestep, sample, eta=eta))
+
+    cfg = unet_blob["config"]
+    unet = UNet2DConditionModel(**cfg)
+    flat, spec = unet_blob["state_dict"]
+    o, sd = 0, {}
+    for name, shape in spec:
+        n = int(torch.tensor(shape).prod()) if shape else 1
+        sd[name] = flat[o:o + n].view(shape)
+        o += n
+    unet.load_state_dict(sd)
+    torch.manual_seed(6)
+    text = CLIPTextModel(**dict(TEXT_CFG, hidden_size=cfg["cross_attention_dim"])).requires_grad_(False)
+    tok = WhitespaceTokenizer()
+    enc = StandInEncoder(sum(2 * c for c in cfg["block_out_channels"]) + cfg["block_out_channels"][0] + sum(cfg["block_out_channels"][:-1]) + cfg["block_out_channels"][-1],
+                         cfg["cross_attention_dim"])
+    vae = types.SimpleNamespace(config=types.SimpleNamespace(block_out_channels=(1, 1, 1, 1), scaling_factor=0.18215))
+    e4t_config = types.SimpleNamespace(placeholder_token="*s", domain_class_token="art", domain_embed_scale=0.1)
+    pipe = StableDiffusionE4TPipeline(vae=vae, text_encoder=text, tokenizer=tok, unet=unet, e4t_encoder=enc, scheduler=Sched(),
+                                      safety_checker=None, feature_extractor=None, e4t_config=e4t_config, requires_safety_checker=False)
+    g = torch.Generator().manual_seed(8)
+    image = torch.rand(1, 3, 16, 16, generator=g) * 2 - 1
+    lat0 = torch.randn(2, 4, 8, 8, generator=g)
+    res = {}
+    with torch.no_grad():
+        for gs in (1.0, 3.0):
+            res[gs] = pipe(PROMPT, height=64, width=64, num_inference_steps=3, guidance_scale=gs, num_images_per_prompt=2, latents=lat0.clone(),
+                           image=image, output_type="latent").images
+    return dict(text_state=pack(text.state_dict()), image=image, latents=lat0, steps=3, final=res, placeholder_id=tok.convert_tokens_to_ids("*s"))
+
+
 if __name__ == "__main__":
     import open_clip
     open_clip.TEST_ARCHS["ViT-golden-test"] = dict(image_size=224, patch_size=56, width=8, layers=2, heads=2, mlp_ratio=2.0)
-    for name, fn in (("unet", unet_fixture), ("attention", attention_fixture), ("encoder", encoder_fixture)):
-        blob = fn()
+    blobs = {}
+    for name, fn in (("unet", unet_fixture), ("attention", attention_fixture), ("encoder", encoder_fixture),
+                     ("pipeline", lambda: pipeline_fixture(blobs["unet"]["sd1"]))):
+        blobs[name] = fn()
         path = os.path.join(HERE, f"reference_{name}.pt")
-        torch.save(blob, path)
+        torch.save(blobs[name], path)
         print(f"{path}: {os.path.getsize(path) / 1e6:.2f} MB")

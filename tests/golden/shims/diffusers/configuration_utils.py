@@ -14,7 +14,14 @@ class ConfigMixin:
     config_name = None
 
     def register_to_config(self, **kwargs):
-        self._internal_dict = FrozenDict({**getattr(self, "_internal_dict", {}), **kwargs})
+        # diffusers <= 0.15 also mirrors every config entry as a plain attribute (`unet.in_channels`, which the reference's
+        # pipeline reads at pipeline_stable_diffusion_e4t.py:163)
+        for k, v in kwargs.items():
+            try:
+                object.__setattr__(self, k, v)
+            except AttributeError:
+                pass
+        object.__setattr__(self, "_internal_dict", FrozenDict({**self.__dict__.get("_internal_dict", {}), **kwargs}))
 
     @property
     def config(self):

@@ -88,3 +88,36 @@ def test_e4t_encoder_matches_reference_code():
         close(got[n], want[n], f"grad {n}", rtol=2e-4, atol=2e-6)
     pre = orc.clip_preprocess(blob["x"]) if hasattr(orc, "clip_preprocess") else enc.preprocess(blob["x"])
     close(pre[:, :, ::16, ::16], blob["preprocessed"], "CLIP input (224 x 224 bicubic, normalised)")
+
+
+@pytest.mark.parametrize("guidance", [1.0, 3.0])
+def test_sampling_loop_matches_reference_pipeline(guidance):
+    """oracle e4t_sample + DDIMScheduler against the reference's StableDiffusionE4TPipeline.__call__ (run on the reference UNet
+    with the 'sd1' fixture weights, a stand-in E4T encoder, the torch CLIP text twin and the offline tokenizer)"""
+    import sys
+    sys.path.insert(0, GOLD)
+    from standin import PROMPT, TEXT_CFG, StandInEncoder
+    from e4t.frozen import CLIPTextModel
+    from e4t.utils import WhitespaceTokenizer
+    ub = torch.load(os.path.join(GOLD, "reference_unet.pt"))["sd1"]
+    pb = torch.load(os.path.join(GOLD, "reference_pipeline.pt"))
+    cfg = ub["config"]
+    unet = orc.UNet2DConditionModel(**cfg)
+    unet.load_state_dict(unpack(ub["state_dict"]))
+    text = CLIPTextModel(**dict(TEXT_CFG, hidden_size=cfg["cross_attention_dim"])).requires_grad_(False)
+    tok = WhitespaceTokenizer()
+    assert tok.add_tokens("*s") == 1 and tok.convert_tokens_to_ids("*s") == pb["placeholder_id"]
+    text.resize_token_embeddings(len(tok))
+    text.load_state_dict(unpack(pb["text_state"]))
+    boc = cfg["block_out_channels"]
+    enc = StandInEncoder(sum(2 * c for c in boc) + boc[0] + sum(boc[:-1]) + boc[-1], cfg["cross_attention_dim"])
+    kw = dict(padding="max_length", truncation=True, max_length=tok.model_max_length, return_tensors="pt")
+    ids = tok(PROMPT, **kw).input_ids
+    idx = ids[0].tolist().index(pb["placeholder_id"])
+    with torch.no_grad():
+        emb = text.get_input_embeddings()(ids)
+        ctx0 = text(tok("", **kw).input_ids)[0]
+        class_embed = text.get_input_embeddings()(tok("art", add_special_tokens=False).input_ids[0])
+    got = orc.e4t_sample(unet, enc, lambda inputs_embeds: text(inputs_embeds=inputs_embeds)[0], orc.DDIMScheduler(), pb["image"], emb, idx,
+                         ctx0, class_embed, pb["latents"].clone(), num_inference_steps=pb["steps"], guidance_scale=guidance)
+    close(got, pb["final"][guidance], f"final latents, guidance {guidance}", rtol=1e-4, atol=1e-5)
