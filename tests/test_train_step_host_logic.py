@@ -246,3 +246,49 @@ def test_lr_schedules():
         seen.append(t.lr)
         s.step()
     assert seen[0] == 0.0 and seen[2] == 2e-4 and math.isclose(seen[4], 1e-4) and s.get_last_lr()[0] == 0.0
+
+
+def test_tuning_step_with_grad_clip_matches_oracle(emu_fp32):
+    """config C4 (tuning_e4t.py:139-147,266-338): every UNet parameter + the encoder head train, one image expanded to the
+    batch, global gradient-norm clipping at 1.0, AdamW — native flat-buffer step vs oracle + clip_grad_norm_ + torch AdamW."""
+    from e4t.trainer import E4TTrainer
+    r_unet, r_enc, n_unet, n_enc, text = build()
+    lr = 1e-3
+    tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=lr, reg_lambda=0.1, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long),
+                    device=torch.device("cpu"), tuning=True, max_grad_norm=1.0)
+    d = _data(1, 41)
+    B = 3
+    px, lat = d["px"].expand(B, -1, -1, -1).contiguous(), d["lat"].expand(B, -1, -1, -1).contiguous()
+    g = torch.Generator().manual_seed(42)
+    noise, t = torch.randn(B, 4, 16, 16, generator=g), torch.tensor([10, 500, 900])
+    ids, pidx = d["ids"].expand(B, -1).contiguous(), d["pidx"].expand(B).contiguous()
+    r_unet.requires_grad_(True)
+    params = [p for p in r_enc.parameters() if p.requires_grad] + list(r_unet.parameters())
+    opt = torch.optim.AdamW(params, lr=lr)
+    acp = orc.ddpm_alphas_cumprod()
+    with torch.no_grad():
+        class_embed = text.get_input_embeddings()(torch.tensor([11]))[0]
+        ctx0 = text(input_ids=torch.zeros(1, 9, dtype=torch.long))[0]
+        emb = text.get_input_embeddings()(ids)
+    loss, ld, lr_, _ = orc.e4t_losses(r_unet, r_enc, lambda inputs_embeds: text(inputs_embeds=inputs_embeds)[0], px, lat, noise, t, emb, pidx.tolist(),
+                                      ctx0, class_embed, acp, reg_lambda=0.1)
+    loss.backward()
+    total = torch.nn.utils.clip_grad_norm_(params, 1.0)
+    assert float(total) > 1.0                                  # the clip is active in this test
+    before = {n: p.detach().clone() for n, p in r_unet.named_parameters()}
+    opt.step()
+    out = tr.train_step(px, ids, pidx, noise=noise, timesteps=t, latents=lat)
+    torch.testing.assert_close(out[1], ld.detach(), rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(out[2], lr_.detach(), rtol=1e-3, atol=1e-5)
+    want = dict(r_unet.named_parameters())
+    moved = 0
+    for n, p in tr.unet.named_parameters():
+        upd_r, upd_n = want[n].detach() - before[n], p.detach() - before[n]
+        # Adam's first step is lr * sign-like: compare the update directions where the reference moved decisively
+        big = upd_r.abs() > 0.5 * lr
+        if big.any():
+            agree = (torch.sign(upd_r[big]) == torch.sign(upd_n[big])).float().mean()
+            assert float(agree) > 0.995, (n, float(agree))
+            moved += 1
+        assert float((p.detach() - want[n].detach()).abs().max()) <= 2.1 * lr, n
+    assert moved > 200
