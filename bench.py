@@ -151,12 +151,16 @@ def main():
     ips = B * world * args.steps / dt
 
     roof = None
-    if rank == 0 and not args.no_kernel_roofline:
-        # one extra, instrumented step (outside the timed region): HIP events around every MFMA-kernel launch
-        hip.prof = []
+    if not args.no_kernel_roofline:
+        # one extra, instrumented step (outside the timed region): HIP events around every MFMA-kernel launch.  EVERY rank
+        # runs it — a training step contains the gradient all-reduce, a collective rank 0 must not enter alone — and rank 0
+        # records and reports.
+        if rank == 0:
+            hip.prof = []
         tr.overlap_vision = False      # per-kernel durations must not include a concurrently running side stream
         tr.train_step(*batch(10_000))
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_kernel_roofline:
         agg = {}
         for key, fl, e0, e1 in hip.prof:
             a = agg.setdefault(key, [0.0, 0.0, 0])
