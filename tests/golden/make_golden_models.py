@@ -1,6 +1,6 @@
 """Generates tests/golden/reference_*.pt by RUNNING THE REFERENCE'S OWN CODE (build container only: needs /root/reference).
 
-    python tests/golden/make_golden_models.py
+    python tests/golden/make_golden_models.py [output_dir]
 
 /root/reference/e4t/models/{cross_attention,attention,transformer_2d,unet_2d_blocks,unet_2d_condition}.py and
 /root/reference/e4t/encoder.py are imported unmodified; `diffusers`, `kornia`, `open_clip` resolve to the stand-ins under
@@ -160,6 +160,6 @@ if __name__ == "__main__":
     for name, fn in (("unet", unet_fixture), ("attention", attention_fixture), ("encoder", encoder_fixture),
                      ("pipeline", lambda: pipeline_fixture(blobs["unet"]["sd1"]))):
         blobs[name] = fn()
-        path = os.path.join(HERE, f"reference_{name}.pt")
+        path = os.path.join(sys.argv[1] if len(sys.argv) > 1 else HERE, f"reference_{name}.pt")
         torch.save(blobs[name], path)
         print(f"{path}: {os.path.getsize(path) / 1e6:.2f} MB")

@@ -121,3 +121,28 @@ def test_sampling_loop_matches_reference_pipeline(guidance):
     got = orc.e4t_sample(unet, enc, lambda inputs_embeds: text(inputs_embeds=inputs_embeds)[0], orc.DDIMScheduler(), pb["image"], emb, idx,
                          ctx0, class_embed, pb["latents"].clone(), num_inference_steps=pb["steps"], guidance_scale=guidance)
     close(got, pb["final"][guidance], f"final latents, guidance {guidance}", rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/e4t"), reason="the reference checkout exists only in the build container")
+def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
+    """re-runs the generator (the reference's own code on the import stand-ins) and compares with the committed fixtures"""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH="")
+    subprocess.run([sys.executable, os.path.join(GOLD, "make_golden_models.py"), str(tmp_path)], check=True, env=env, capture_output=True, timeout=600)
+
+    def flat(x, out):
+        if torch.is_tensor(x):
+            out.append(x.detach().reshape(-1).double())
+        elif isinstance(x, dict):
+            for k in sorted(x, key=str):
+                flat(x[k], out)
+        elif isinstance(x, (list, tuple)):
+            for v in x:
+                flat(v, out)
+        return out
+    for name in ("unet", "attention", "encoder", "pipeline"):
+        a = torch.cat(flat(torch.load(os.path.join(GOLD, f"reference_{name}.pt")), []))
+        b = torch.cat(flat(torch.load(tmp_path / f"reference_{name}.pt"), []))
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=lambda m, name=name: f"{name}: {m}")
