@@ -29,6 +29,8 @@ PARITY PINNING.  The reference has no tests, golden vectors or fixtures for this
     (e4t/pipeline_stable_diffusion_e4t.py, run unmodified on a stand-in for the diffusers base pipeline, with the
     reference UNet, a stand-in E4T encoder — the real one hard-codes the full-size 10880 features —, the torch CLIP
     text twin and this file's DDIMScheduler): final latents with and without guidance.
+  * tests/golden/reference_{unet,encoder}_wide.pt hold reference outputs at widths the native modules support (weights
+    derived from the parameter names, not stored): tests compare the oracle AND the native modules with them directly.
   * Still **parity unpinned**: the third-party leaves themselves (diffusers ResnetBlock2D /
     Down/Upsample2D / Timesteps / TimestepEmbedding / AutoencoderKL / schedulers, the open_clip ViT, kornia's
     resize) — the stand-ins use this file's restatements of them —, the CLIP text encoder

@@ -58,6 +58,32 @@ def unet_fixture():
     return out
 
 
+def unet_wide_fixture():
+    """A UNet wide enough for the NATIVE modules (channel counts in multiples of 64): weights are a deterministic function of
+    the parameter names (standin.deterministic_fill), so only inputs and the reference's outputs are stored"""
+    from e4t.models.unet_2d_condition import UNet2DConditionModel           # the reference's class
+    from standin import deterministic_fill
+    assert sys.modules[UNet2DConditionModel.__module__].__file__.startswith("/root/reference/")
+    cfg = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(64, 64, 128, 128), layers_per_block=2,
+               cross_attention_dim=64, attention_head_dim=2, norm_num_groups=32, norm_eps=1e-5,
+               down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+               up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"))
+    unet = deterministic_fill(UNet2DConditionModel(**cfg), salt=11)
+    g = torch.Generator().manual_seed(12)
+    sample = torch.randn(2, 4, 8, 8, generator=g)
+    t = torch.tensor([41, 903])
+    ctx = torch.randn(2, 6, 64, generator=g)
+    G = torch.randn(2, 4, 8, 8, generator=g)
+    enc = unet(sample, t, ctx, return_encoder_outputs=True)["down_block_samples"]
+    full = unet(sample, t, ctx).sample
+    (full * G).sum().backward()
+    pick = [n for n, _ in unet.named_parameters() if ".wo_" in n and (n.endswith(".v") or n.endswith("linear1.bias") or n.endswith("linear_row.bias"))]
+    grads = {n: dict(unet.named_parameters())[n].grad.clone() for n in pick}
+    assert len(enc) == 13 and len(pick) == 96 * 3
+    return dict(config=cfg, salt=11, sample=sample, timestep=t, ctx=ctx, G=G, down_block_samples=[e.detach() for e in enc], out=full.detach(),
+                wo_grads=pack(grads))
+
+
 def attention_fixture():
     from e4t.models.cross_attention import AttnProcessor2_0, CrossAttention, CrossAttnProcessor
     out = {}
@@ -93,6 +119,23 @@ def encoder_fixture():
     pre = enc.preprocess(x).detach()[:, :, ::16, ::16].clone()          # a 14x14 sample of the 224x224 CLIP input
     return dict(kwargs=dict(word_embedding_dim=24, n_odd_layers=9), state_dict=pack(enc.state_dict()),
                 x=x, maps=maps, out=y.detach(), grads=pack(grads), preprocessed=pre)
+
+
+def encoder_wide_fixture():
+    """The reference E4TEncoder at a width the NATIVE encoder supports (ViT width 64), name-derived weights, outputs only"""
+    from e4t.encoder import E4TEncoder                                       # the reference's class
+    from standin import deterministic_fill
+    assert sys.modules[E4TEncoder.__module__].__file__.startswith("/root/reference/")
+    enc = deterministic_fill(E4TEncoder(word_embedding_dim=64, arch="ViT-golden-wide", version="none", n_odd_layers=9, freeze_clip_vision=False), salt=21)
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(2, 3, 40, 48, generator=g) * 2 - 1
+    maps = [torch.randn(2, c, 1 + (i % 2), 2, generator=g) for i, c in enumerate(SD_MAP_CHANNELS)]
+    y = enc(x, tuple(maps))
+    y.square().sum().backward()
+    pick = ["final_linear.weight", "feature_linear.bias", "first_linears.0.weight", "first_linears.8.bias", "unet_feature_embedder.2.weight",
+            "clip_vision.ln_post.weight", "clip_vision.transformer.resblocks.0.attn.in_proj_weight", "clip_vision.class_embedding"]
+    named = dict(enc.named_parameters())
+    return dict(kwargs=dict(word_embedding_dim=64, n_odd_layers=9), salt=21, x=x, maps=maps, out=y.detach(), grads=pack({n: named[n].grad.clone() for n in pick}))
 
 
 def pipeline_fixture(unet_blob):
@@ -156,8 +199,9 @@ def pipeline_fixture(unet_blob):
 if __name__ == "__main__":
     import open_clip
     open_clip.TEST_ARCHS["ViT-golden-test"] = dict(image_size=224, patch_size=56, width=8, layers=2, heads=2, mlp_ratio=2.0)
+    open_clip.TEST_ARCHS["ViT-golden-wide"] = dict(image_size=224, patch_size=56, width=64, layers=2, heads=2, mlp_ratio=2.0)
     blobs = {}
-    for name, fn in (("unet", unet_fixture), ("attention", attention_fixture), ("encoder", encoder_fixture),
+    for name, fn in (("unet", unet_fixture), ("unet_wide", unet_wide_fixture), ("attention", attention_fixture), ("encoder", encoder_fixture), ("encoder_wide", encoder_wide_fixture),
                      ("pipeline", lambda: pipeline_fixture(blobs["unet"]["sd1"]))):
         blobs[name] = fn()
         path = os.path.join(sys.argv[1] if len(sys.argv) > 1 else HERE, f"reference_{name}.pt")

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 import e4t_oracle as orc
+from test_unet_host_logic import emu_fp32  # noqa: F401
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -141,8 +142,58 @@ def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
             for v in x:
                 flat(v, out)
         return out
-    for name in ("unet", "attention", "encoder", "pipeline"):
+    for name in ("unet", "unet_wide", "attention", "encoder", "encoder_wide", "pipeline"):
         a = torch.cat(flat(torch.load(os.path.join(GOLD, f"reference_{name}.pt")), []))
         b = torch.cat(flat(torch.load(tmp_path / f"reference_{name}.pt"), []))
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=lambda m, name=name: f"{name}: {m}")
+
+
+def test_native_unet_matches_reference_code_directly(emu_fp32):
+    """The NATIVE UNet (host graph + hand-written backward orchestration, through the fp32 op emulation) against what the
+    reference's own UNet computed at a width the native modules support — no oracle in between.  Weights are a deterministic
+    function of the parameter names (tests/golden/standin.py), so the fixture holds only inputs and reference outputs."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from standin import deterministic_fill
+    from e4t.models.unet_2d_condition import UNet2DConditionModel
+    blob = torch.load(os.path.join(GOLD, "reference_unet_wide.pt"))
+    want_g = unpack(blob["wo_grads"])
+    for kind in ("oracle", "native"):
+        unet = deterministic_fill((orc.UNet2DConditionModel if kind == "oracle" else UNet2DConditionModel)(**blob["config"]), salt=blob["salt"])
+        enc = unet(blob["sample"], blob["timestep"], blob["ctx"], return_encoder_outputs=True)["down_block_samples"]
+        tol = dict(rtol=5e-5, atol=1e-5) if kind == "oracle" else dict(rtol=2e-3, atol=2e-4)      # native: bf16-free emulation, different op order
+        for i, (a, b) in enumerate(zip(enc, blob["down_block_samples"])):
+            close(a.float(), b, f"{kind} encoder map {i}", **tol)
+        out = unet(blob["sample"], blob["timestep"], blob["ctx"])
+        out = out.sample if hasattr(out, "sample") else out
+        close(out.float(), blob["out"], f"{kind} sample", **tol)
+        (out.float() * blob["G"]).sum().backward()
+        got = dict(unet.named_parameters())
+        for n, g in want_g.items():
+            close(got[n].grad, g, f"{kind} grad {n}", rtol=5e-3 if kind == "native" else 5e-4, atol=5e-4 if kind == "native" else 5e-6)
+
+
+def test_native_e4t_encoder_matches_reference_code_directly(emu_fp32):
+    """the NATIVE E4TEncoder (ViT on the op backend, grouped 129-slot-style head with its hand-written backward) through the
+    fp32 emulation against the reference's own E4TEncoder at ViT width 64 — name-derived weights, no oracle in between"""
+    import sys
+    sys.path.insert(0, GOLD)
+    from standin import deterministic_fill
+    from e4t.encoder import E4TEncoder
+    blob = torch.load(os.path.join(GOLD, "reference_encoder_wide.pt"))
+    vit = dict(image_size=224, patch_size=56, width=64, layers=2, heads=2, mlp_ratio=2.0)
+    want_g = unpack(blob["grads"])
+    for kind in ("oracle", "native"):
+        if kind == "oracle":
+            enc = orc.E4TEncoder(vit_cfg=vit, freeze_clip_vision=False, **blob["kwargs"])
+        else:
+            enc = E4TEncoder(arch="ViT-golden-wide", vit_cfg=vit, freeze_clip_vision=False, **blob["kwargs"])
+        deterministic_fill(enc, salt=blob["salt"])
+        y = enc(blob["x"], tuple(blob["maps"]))
+        tol = dict(rtol=5e-5, atol=1e-5) if kind == "oracle" else dict(rtol=2e-3, atol=2e-4)
+        close(y.float(), blob["out"], f"{kind} domain embedding", **tol)
+        y.float().square().sum().backward()
+        got = dict(enc.named_parameters())
+        for n, g in want_g.items():
+            close(got[n].grad, g, f"{kind} grad {n}", rtol=5e-3 if kind == "native" else 5e-4, atol=1e-3 if kind == "native" else 1e-5)
