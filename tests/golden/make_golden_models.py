@@ -196,13 +196,62 @@ def pipeline_fixture(unet_blob):
     return dict(text_state=pack(text.state_dict()), image=image, latents=lat0, steps=3, final=res, placeholder_id=tok.convert_tokens_to_ids("*s"))
 
 
+def pipeline_wide_fixture():
+    """the reference pipeline once more, at a UNet width the NATIVE pipeline can run (name-derived weights, outputs only)"""
+    import importlib.util
+    import types
+
+    import e4t_oracle as orc
+    from e4t.models.unet_2d_condition import UNet2DConditionModel
+    from e4t.pipeline_stable_diffusion_e4t import StableDiffusionE4TPipeline
+    from standin import PROMPT, TEXT_CFG, StandInEncoder, deterministic_fill
+
+    def native(name):
+        spec = importlib.util.spec_from_file_location(f"native_{name}", os.path.join(ROOT, "e4t-diffusion_amd", "e4t", f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    CLIPTextModel, WhitespaceTokenizer = native("frozen").CLIPTextModel, native("utils").WhitespaceTokenizer
+
+    class Sched(orc.DDIMScheduler):
+        def set_timesteps(self, n, device=None):
+            super().set_timesteps(n)
+
+        def step(self, model_output, timestep, sample, eta=0.0, generator=None):
+            return types.SimpleNamespace(prev_sample=super().step(model_output, timestep, sample, eta=eta))
+
+    cfg = dict(sample_size=8, in_channels=4, out_channels=4, block_out_channels=(64, 64, 128, 128), layers_per_block=2,
+               cross_attention_dim=64, attention_head_dim=2, norm_num_groups=32, norm_eps=1e-5,
+               down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+               up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"))
+    unet = deterministic_fill(UNet2DConditionModel(**cfg), salt=31)
+    tok = WhitespaceTokenizer()
+    tok.add_tokens("*s")
+    text = deterministic_fill(CLIPTextModel(**dict(TEXT_CFG, hidden_size=64, intermediate_size=128, vocab_size=len(tok))), salt=32).requires_grad_(False)
+    boc = cfg["block_out_channels"]
+    enc = StandInEncoder(sum(2 * c for c in boc) + boc[0] + sum(boc[:-1]) + boc[-1], 64)
+    vae = types.SimpleNamespace(config=types.SimpleNamespace(block_out_channels=(1, 1, 1, 1), scaling_factor=0.18215))
+    e4t_config = types.SimpleNamespace(placeholder_token="*s", domain_class_token="art", domain_embed_scale=0.1)
+    pipe = StableDiffusionE4TPipeline(vae=vae, text_encoder=text, tokenizer=tok, unet=unet, e4t_encoder=enc, scheduler=Sched(), safety_checker=None,
+                                      feature_extractor=None, e4t_config=e4t_config, requires_safety_checker=False, already_added_placeholder_token=True)
+    g = torch.Generator().manual_seed(33)
+    image = torch.rand(1, 3, 16, 16, generator=g) * 2 - 1
+    lat0 = torch.randn(2, 4, 8, 8, generator=g)
+    res = {}
+    with torch.no_grad():
+        for gs in (1.0, 4.0):
+            res[gs] = pipe(PROMPT, height=64, width=64, num_inference_steps=3, guidance_scale=gs, num_images_per_prompt=2, latents=lat0.clone(),
+                           image=image, output_type="latent").images
+    return dict(config=cfg, image=image, latents=lat0, steps=3, final=res)
+
+
 if __name__ == "__main__":
     import open_clip
     open_clip.TEST_ARCHS["ViT-golden-test"] = dict(image_size=224, patch_size=56, width=8, layers=2, heads=2, mlp_ratio=2.0)
     open_clip.TEST_ARCHS["ViT-golden-wide"] = dict(image_size=224, patch_size=56, width=64, layers=2, heads=2, mlp_ratio=2.0)
     blobs = {}
     for name, fn in (("unet", unet_fixture), ("unet_wide", unet_wide_fixture), ("attention", attention_fixture), ("encoder", encoder_fixture), ("encoder_wide", encoder_wide_fixture),
-                     ("pipeline", lambda: pipeline_fixture(blobs["unet"]["sd1"]))):
+                     ("pipeline", lambda: pipeline_fixture(blobs["unet"]["sd1"])), ("pipeline_wide", pipeline_wide_fixture)):
         blobs[name] = fn()
         path = os.path.join(sys.argv[1] if len(sys.argv) > 1 else HERE, f"reference_{name}.pt")
         torch.save(blobs[name], path)

@@ -142,7 +142,7 @@ def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
             for v in x:
                 flat(v, out)
         return out
-    for name in ("unet", "unet_wide", "attention", "encoder", "encoder_wide", "pipeline"):
+    for name in ("unet", "unet_wide", "attention", "encoder", "encoder_wide", "pipeline", "pipeline_wide"):
         a = torch.cat(flat(torch.load(os.path.join(GOLD, f"reference_{name}.pt")), []))
         b = torch.cat(flat(torch.load(tmp_path / f"reference_{name}.pt"), []))
         assert a.shape == b.shape
@@ -197,3 +197,32 @@ def test_native_e4t_encoder_matches_reference_code_directly(emu_fp32):
         got = dict(enc.named_parameters())
         for n, g in want_g.items():
             close(got[n].grad, g, f"{kind} grad {n}", rtol=5e-3 if kind == "native" else 5e-4, atol=1e-3 if kind == "native" else 1e-5)
+
+
+@pytest.mark.parametrize("guidance", [1.0, 4.0])
+def test_native_pipeline_matches_reference_pipeline_directly(emu_fp32, guidance):
+    """this repository's StableDiffusionE4TPipeline (native UNet + text encoder through the emulation, fused guidance/DDIM
+    update, per-call hoisting) against the final latents of the reference's pipeline __call__ on the same name-derived weights"""
+    import sys
+    sys.path.insert(0, GOLD)
+    from standin import PROMPT, TEXT_CFG, StandInEncoder, deterministic_fill
+    from e4t.models.unet_2d_condition import UNet2DConditionModel
+    from e4t.pipeline_stable_diffusion_e4t import StableDiffusionE4TPipeline
+    from e4t.schedulers import DDIMScheduler
+    from e4t.text import CLIPTextModel
+    from e4t.utils import WhitespaceTokenizer
+    blob = torch.load(os.path.join(GOLD, "reference_pipeline_wide.pt"))
+    cfg = blob["config"]
+    unet = deterministic_fill(UNet2DConditionModel(**cfg), salt=31).requires_grad_(False)
+    tok = WhitespaceTokenizer()
+    tok.add_tokens("*s")
+    text = deterministic_fill(CLIPTextModel(**dict(TEXT_CFG, hidden_size=64, intermediate_size=128, vocab_size=len(tok))), salt=32).requires_grad_(False)
+    boc = cfg["block_out_channels"]
+    enc = StandInEncoder(sum(2 * c for c in boc) + boc[0] + sum(boc[:-1]) + boc[-1], 64)
+    vae = type("V", (), {"block_out_channels": (1, 1, 1, 1)})()
+    pipe = StableDiffusionE4TPipeline(vae=vae, text_encoder=text, tokenizer=tok, unet=unet, e4t_encoder=enc, scheduler=DDIMScheduler.stable_diffusion(),
+                                      e4t_config=dict(placeholder_token="*s", domain_class_token="art", domain_embed_scale=0.1),
+                                      already_added_placeholder_token=True)
+    out = pipe(PROMPT, height=64, width=64, num_inference_steps=blob["steps"], guidance_scale=guidance, num_images_per_prompt=2,
+               latents=blob["latents"].clone(), image=blob["image"], output_type="latent", use_graph=False).images
+    close(out, blob["final"][guidance], f"final latents, guidance {guidance}", rtol=3e-3, atol=3e-4)
