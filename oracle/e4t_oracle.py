@@ -29,13 +29,16 @@ PARITY PINNING.  The reference has no tests, golden vectors or fixtures for this
     (e4t/pipeline_stable_diffusion_e4t.py, run unmodified on a stand-in for the diffusers base pipeline, with the
     reference UNet, a stand-in E4T encoder — the real one hard-codes the full-size 10880 features —, the torch CLIP
     text twin and this file's DDIMScheduler): final latents with and without guidance.
+  * ``e4t_losses`` + the optimiser step (the training-step glue, a11) are pinned against pretrain_e4t.py:561-584 and
+    :597-654 themselves: those lines are read from the file and exec'd verbatim in a prepared namespace (reference UNet,
+    stand-ins for accelerate / the diffusers scheduler and VAE objects); losses, model_pred, the domain embedding, every
+    weight-offset gradient and the post-AdamW parameters are replayed (tests/golden/reference_step.pt).
   * tests/golden/reference_{unet,encoder}_wide.pt hold reference outputs at widths the native modules support (weights
     derived from the parameter names, not stored): tests compare the oracle AND the native modules with them directly.
   * Still **parity unpinned**: the third-party leaves themselves (diffusers ResnetBlock2D /
     Down/Upsample2D / Timesteps / TimestepEmbedding / AutoencoderKL / schedulers, the open_clip ViT, kornia's
     resize) — the stand-ins use this file's restatements of them —, the CLIP text encoder
-    (e4t/models/modeling_clip.py needs transformers internals that no longer exist) and the training-step
-    glue of pretrain_e4t.py (needs accelerate/diffusers/datasets at import).  They are anchored on the
+    (e4t/models/modeling_clip.py needs transformers internals that no longer exist).  They are anchored on the
     reference's call sites and on the known answer it states (UNet encoder feature width 10880,
     e4t/models/unet_2d_condition.py:586).
 """

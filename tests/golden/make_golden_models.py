@@ -245,13 +245,107 @@ def pipeline_wide_fixture():
     return dict(config=cfg, image=image, latents=lat0, steps=3, final=res)
 
 
+def step_fixture(unet_blob):
+    """One pre-training step by EXECUTING THE REFERENCE'S OWN LINES: pretrain_e4t.py:561-584 (class embedding, ""-prompt context,
+    prompt templates) and :597-654 (the body of `with accelerator.accumulate(unet):` — latents, noise, timesteps, prompts, both UNet
+    passes, embedding injection, losses, backward, optimiser step) are read from the file, dedented and exec'd verbatim in a
+    namespace holding: the reference UNet ('sd1' fixture weights), a trainable stand-in E4T encoder, the torch CLIP text twin,
+    the offline tokenizer, and stand-ins for accelerate / the diffusers scheduler and VAE objects.  What the lines drew at random
+    and what they computed is recorded."""
+    import importlib.util
+    import random
+    import textwrap
+    import types
+
+    import torch.nn.functional as F
+
+    import e4t_oracle as orc
+    from e4t.models.unet_2d_condition import UNet2DConditionModel
+    from standin import TEXT_CFG, StandInEncoder
+
+    def native(name):
+        spec = importlib.util.spec_from_file_location(f"native_{name}", os.path.join(ROOT, "e4t-diffusion_amd", "e4t", f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    CLIPTextModel, WhitespaceTokenizer = native("frozen").CLIPTextModel, native("utils").WhitespaceTokenizer
+    lines = open("/root/reference/pretrain_e4t.py").read().splitlines()
+    prelude = textwrap.dedent("\n".join(lines[560:584]))          # file lines 561-584
+    body = textwrap.dedent("\n".join(lines[596:654]))             # file lines 597-654
+    assert prelude.lstrip().startswith("domain_class_token_id = tokenizer(") and body.startswith('pixel_values = batch["pixel_values"]')
+    assert body.rstrip().endswith("optimizer.zero_grad()")
+
+    cfg = unet_blob["config"]
+    unet = UNet2DConditionModel(**cfg)
+    flat, spec = unet_blob["state_dict"]
+    o, sd = 0, {}
+    for name, shape in spec:
+        n = int(torch.tensor(shape).prod()) if shape else 1
+        sd[name] = flat[o:o + n].view(shape)
+        o += n
+    unet.load_state_dict(sd)
+    for n, p in unet.named_parameters():                         # pretrain_e4t.py:262-278
+        p.requires_grad_("wo" in n)
+    d = cfg["cross_attention_dim"]
+    torch.manual_seed(9)
+    tok = WhitespaceTokenizer()
+    tok.add_tokens("*s")
+    text = CLIPTextModel(**dict(TEXT_CFG, hidden_size=d, vocab_size=len(tok))).requires_grad_(False)
+    boc = cfg["block_out_channels"]
+    enc = StandInEncoder(sum(2 * c for c in boc) + boc[0] + sum(boc[:-1]) + boc[-1], d)
+    enc.w.requires_grad_(True)
+    acp = orc.ddpm_alphas_cumprod()
+    sched = types.SimpleNamespace(config=types.SimpleNamespace(num_train_timesteps=1000, prediction_type="epsilon"),
+                                  add_noise=lambda x0, nz, t: orc.add_noise(x0, nz, t, acp), get_velocity=lambda x0, nz, t: orc.get_velocity(x0, nz, t, acp))
+
+    class VAE:                                                   # stand-in for AutoencoderKL: a fixed linear map of the pooled image
+        config = types.SimpleNamespace(scaling_factor=0.18215)
+        P = torch.randn(4, 3, generator=torch.Generator().manual_seed(10))
+
+        def encode(self, x):
+            z = torch.einsum("lc,bchw->blhw", self.P, F.avg_pool2d(x, 8))
+            return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: z))
+    params = [enc.w] + [p for n, p in unet.named_parameters() if "wo" in n]
+    optimizer = torch.optim.AdamW(params, lr=1e-3)
+    g = torch.Generator().manual_seed(11)
+    px = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    ns = dict(torch=torch, F=F, random=random, tokenizer=tok, text_encoder=text, unet=unet, e4t_encoder=enc, vae=VAE(), weight_dtype=torch.float32,
+              noise_scheduler=sched, optimizer=optimizer, lr_scheduler=types.SimpleNamespace(step=lambda: None),
+              accelerator=types.SimpleNamespace(device=torch.device("cpu"), backward=lambda loss: loss.backward()),
+              args=types.SimpleNamespace(domain_class_token="art", prompt_template="a photo of {placeholder_token}", placeholder_token="*s",
+                                         domain_embed_scale=0.1, reg_lambda=0.01),
+              placeholder_token_id=tok.convert_tokens_to_ids("*s"), batch=dict(pixel_values=px), print=lambda *a, **k: None)
+    exec(prelude, ns)
+    before = {n: p.detach().clone() for n, p in unet.named_parameters() if "wo" in n}
+    torch.manual_seed(12)
+    random.seed(12)
+    grads = {}
+    real_step = optimizer.step
+
+    def step_and_record():
+        grads.update({n: p.grad.clone() for n, p in unet.named_parameters() if "wo" in n})
+        grads["__enc_w"] = enc.w.grad.clone()
+        real_step()
+    optimizer.step = step_and_record
+    exec(body, ns)
+    after = {n: p.detach().clone() for n, p in unet.named_parameters() if "wo" in n}
+    moved = sum(float((after[n] - before[n]).abs().sum()) for n in after)
+    assert moved > 0 and all(p.grad is None or float(p.grad.abs().sum()) == 0 for p in params)
+    return dict(text_state=pack(text.state_dict()), vae_P=VAE.P, pixel_values=px, latents=ns["latents"].detach(), noise=ns["noise"], timesteps=ns["timesteps"],
+                input_ids=ns["input_ids"], placeholder_idxs=ns["placeholder_token_id_idxs"], class_embed=ns["class_embed"].detach(),
+                ctx_for_e4t=ns["encoder_hidden_states_for_e4t"].detach(), loss=ns["loss"].detach(), loss_diff=ns["loss_diff"].detach(),
+                loss_reg=ns["loss_reg"].detach(), model_pred=ns["model_pred"].detach(), domain_embed=ns["domain_embed"].detach(),
+                grads=pack(grads), params_after=pack(after), enc_w_after=enc.w.detach().clone())
+
+
 if __name__ == "__main__":
     import open_clip
     open_clip.TEST_ARCHS["ViT-golden-test"] = dict(image_size=224, patch_size=56, width=8, layers=2, heads=2, mlp_ratio=2.0)
     open_clip.TEST_ARCHS["ViT-golden-wide"] = dict(image_size=224, patch_size=56, width=64, layers=2, heads=2, mlp_ratio=2.0)
     blobs = {}
     for name, fn in (("unet", unet_fixture), ("unet_wide", unet_wide_fixture), ("attention", attention_fixture), ("encoder", encoder_fixture), ("encoder_wide", encoder_wide_fixture),
-                     ("pipeline", lambda: pipeline_fixture(blobs["unet"]["sd1"])), ("pipeline_wide", pipeline_wide_fixture)):
+                     ("pipeline", lambda: pipeline_fixture(blobs["unet"]["sd1"])), ("pipeline_wide", pipeline_wide_fixture),
+                     ("step", lambda: step_fixture(blobs["unet"]["sd1"]))):
         blobs[name] = fn()
         path = os.path.join(sys.argv[1] if len(sys.argv) > 1 else HERE, f"reference_{name}.pt")
         torch.save(blobs[name], path)

@@ -142,7 +142,7 @@ def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
             for v in x:
                 flat(v, out)
         return out
-    for name in ("unet", "unet_wide", "attention", "encoder", "encoder_wide", "pipeline", "pipeline_wide"):
+    for name in ("unet", "unet_wide", "attention", "encoder", "encoder_wide", "pipeline", "pipeline_wide", "step"):
         a = torch.cat(flat(torch.load(os.path.join(GOLD, f"reference_{name}.pt")), []))
         b = torch.cat(flat(torch.load(tmp_path / f"reference_{name}.pt"), []))
         assert a.shape == b.shape
@@ -226,3 +226,67 @@ def test_native_pipeline_matches_reference_pipeline_directly(emu_fp32, guidance)
     out = pipe(PROMPT, height=64, width=64, num_inference_steps=blob["steps"], guidance_scale=guidance, num_images_per_prompt=2,
                latents=blob["latents"].clone(), image=blob["image"], output_type="latent", use_graph=False).images
     close(out, blob["final"][guidance], f"final latents, guidance {guidance}", rtol=3e-3, atol=3e-4)
+
+
+def test_training_step_matches_reference_lines():
+    """oracle e4t_losses + torch AdamW against what pretrain_e4t.py:561-584,597-654 computed when those lines were executed
+    verbatim (tests/golden/make_golden_models.py::step_fixture): class embedding, ""-context, latents, both UNet passes, the
+    embedding injection, loss_diff / loss_reg / loss, every weight-offset gradient and the parameters after the optimiser step"""
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, GOLD)
+    from standin import TEXT_CFG, StandInEncoder
+    from e4t.frozen import CLIPTextModel
+    from e4t.utils import WhitespaceTokenizer
+    ub = torch.load(os.path.join(GOLD, "reference_unet.pt"))["sd1"]
+    sb = torch.load(os.path.join(GOLD, "reference_step.pt"))
+    cfg = ub["config"]
+    unet = orc.UNet2DConditionModel(**cfg)
+    unet.load_state_dict(unpack(ub["state_dict"]))
+    for n, p in unet.named_parameters():
+        p.requires_grad_("wo" in n)
+    d = cfg["cross_attention_dim"]
+    tok = WhitespaceTokenizer()
+    tok.add_tokens("*s")
+    text = CLIPTextModel(**dict(TEXT_CFG, hidden_size=d, vocab_size=len(tok))).requires_grad_(False)
+    text.load_state_dict(unpack(sb["text_state"]))
+    boc = cfg["block_out_channels"]
+    enc = StandInEncoder(sum(2 * c for c in boc) + boc[0] + sum(boc[:-1]) + boc[-1], d)
+    enc.w.requires_grad_(True)
+    # prelude (:561-584)
+    kw = dict(padding="max_length", truncation=True, max_length=tok.model_max_length, return_tensors="pt")
+    with torch.no_grad():
+        class_embed = text.get_input_embeddings()(tok("art", add_special_tokens=False).input_ids[0])
+        ctx0 = text(tok("", **kw).input_ids)[0]
+    close(class_embed, sb["class_embed"], "class embedding")
+    close(ctx0, sb["ctx_for_e4t"], '""-prompt context')
+    # the VAE stand-in's latents (:597-599) and the prompt the reference built (:609-616)
+    lat = torch.einsum("lc,bchw->blhw", sb["vae_P"], F.avg_pool2d(sb["pixel_values"], 8)) * 0.18215
+    close(lat, sb["latents"], "latents")
+    ids = tok(["a photo of *s"] * 2, **kw).input_ids
+    assert torch.equal(ids, sb["input_ids"]) and [r.index(tok.convert_tokens_to_ids("*s")) for r in ids.tolist()] == sb["placeholder_idxs"]
+    with torch.no_grad():
+        emb = text.get_input_embeddings()(ids)
+    params = [enc.w] + [p for n, p in unet.named_parameters() if "wo" in n]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    loss, ld, lr_, aux = orc.e4t_losses(unet, enc, lambda inputs_embeds: text(inputs_embeds=inputs_embeds)[0], sb["pixel_values"], lat, sb["noise"],
+                                        sb["timesteps"], emb, sb["placeholder_idxs"], ctx0, class_embed, orc.ddpm_alphas_cumprod(), reg_lambda=0.01)
+    close(aux["domain_embed"], sb["domain_embed"], "domain embedding")
+    pred = aux["pred"].sample if hasattr(aux["pred"], "sample") else aux["pred"]
+    close(pred, sb["model_pred"], "model_pred")
+    close(ld, sb["loss_diff"], "loss_diff")
+    close(lr_, sb["loss_reg"], "loss_reg")
+    close(loss, sb["loss"], "loss")
+    loss.backward()
+    want = unpack(sb["grads"])
+    close(enc.w.grad, want.pop("__enc_w"), "grad encoder", rtol=2e-4, atol=2e-6)
+    named = dict(unet.named_parameters())
+    for n, g in want.items():
+        close(named[n].grad, g, f"grad {n}", rtol=2e-4, atol=2e-6)
+    opt.step()
+    after = unpack(sb["params_after"])
+    bad = 0
+    for n, v in after.items():
+        bad += int(((named[n].detach() - v).abs() > 1e-5).sum())        # Adam's first step is sign-like: tolerate flips where |g| is rounding noise
+    assert bad <= 5, bad
+    assert int(((enc.w.detach() - sb["enc_w_after"]).abs() > 1e-5).sum()) <= 2
