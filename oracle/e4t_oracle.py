@@ -32,7 +32,9 @@ PARITY PINNING.  The reference has no tests, golden vectors or fixtures for this
   * ``e4t_losses`` + the optimiser step (the training-step glue, a11) are pinned against pretrain_e4t.py:561-584 and
     :597-654 themselves: those lines are read from the file and exec'd verbatim in a prepared namespace (reference UNet,
     stand-ins for accelerate / the diffusers scheduler and VAE objects); losses, model_pred, the domain embedding, every
-    weight-offset gradient and the post-AdamW parameters are replayed (tests/golden/reference_step.pt).
+    weight-offset gradient and the post-AdamW parameters are replayed (tests/golden/reference_step.pt); likewise the
+    domain-tuning step, tuning_e4t.py:266-269 and :272-338 (every UNet parameter trainable, global gradient-norm clip):
+    tests/golden/reference_tuning_step.pt.
   * tests/golden/reference_{unet,encoder}_wide.pt hold reference outputs at widths the native modules support (weights
     derived from the parameter names, not stored): tests compare the oracle AND the native modules with them directly.
   * Still **parity unpinned**: the third-party leaves themselves (diffusers ResnetBlock2D /

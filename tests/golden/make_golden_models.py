@@ -338,6 +338,101 @@ def step_fixture(unet_blob):
                 grads=pack(grads), params_after=pack(after), enc_w_after=enc.w.detach().clone())
 
 
+def tuning_step_fixture(unet_blob):
+    """One domain-tuning step by executing tuning_e4t.py's own lines: :266-269 (image expanded to the batch, latents once) and the
+    body of `with accelerator.accumulate(unet):` (:272-338: per-step class embedding and ""-context, both UNet passes, losses,
+    backward, global gradient-norm clipping, optimiser step) — every UNet parameter trains (:139-147)."""
+    import importlib.util
+    import itertools
+    import random
+    import textwrap
+    import types
+
+    import torch.nn.functional as F
+
+    import e4t_oracle as orc
+    from e4t.models.unet_2d_condition import UNet2DConditionModel
+    from standin import TEXT_CFG, StandInEncoder
+
+    def native(name):
+        spec = importlib.util.spec_from_file_location(f"native_{name}", os.path.join(ROOT, "e4t-diffusion_amd", "e4t", f"{name}.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    CLIPTextModel, WhitespaceTokenizer = native("frozen").CLIPTextModel, native("utils").WhitespaceTokenizer
+    lines = open("/root/reference/tuning_e4t.py").read().splitlines()
+    i0 = next(i for i, l in enumerate(lines) if l.strip() == "pixel_values = image.expand(args.train_batch_size, -1, -1, -1)")
+    iw = next(i for i, l in enumerate(lines) if l.strip() == "with accelerator.accumulate(unet):")
+    iz = next(i for i, l in enumerate(lines) if i > iw and l.strip() == "optimizer.zero_grad()")
+    prelude = textwrap.dedent("\n".join(lines[i0:i0 + 4]))
+    body = textwrap.dedent("\n".join(lines[iw + 1:iz + 1]))
+    assert (i0 + 1, iw + 2, iz + 1) == (266, 272, 338), (i0 + 1, iw + 2, iz + 1)      # the line numbers cited above
+
+    cfg = unet_blob["config"]
+    unet = UNet2DConditionModel(**cfg)
+    flat, spec = unet_blob["state_dict"]
+    o, sd = 0, {}
+    for name, shape in spec:
+        n = int(torch.tensor(shape).prod()) if shape else 1
+        sd[name] = flat[o:o + n].view(shape)
+        o += n
+    unet.load_state_dict(sd)
+    d = cfg["cross_attention_dim"]
+    torch.manual_seed(9)
+    tok = WhitespaceTokenizer()
+    tok.add_tokens("*s")
+    text = CLIPTextModel(**dict(TEXT_CFG, hidden_size=d, vocab_size=len(tok))).requires_grad_(False)
+    boc = cfg["block_out_channels"]
+    enc = StandInEncoder(sum(2 * c for c in boc) + boc[0] + sum(boc[:-1]) + boc[-1], d)
+    enc.w.requires_grad_(True)
+    acp = orc.ddpm_alphas_cumprod()
+    sched = types.SimpleNamespace(config=types.SimpleNamespace(num_train_timesteps=1000, prediction_type="epsilon"),
+                                  add_noise=lambda x0, nz, t: orc.add_noise(x0, nz, t, acp), get_velocity=lambda x0, nz, t: orc.get_velocity(x0, nz, t, acp))
+
+    class VAE:
+        config = types.SimpleNamespace(scaling_factor=0.18215)
+        P = torch.randn(4, 3, generator=torch.Generator().manual_seed(10))
+
+        def encode(self, x):
+            z = torch.einsum("lc,bchw->blhw", self.P, F.avg_pool2d(x, 8))
+            return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: z))
+    params = [enc.w] + list(unet.parameters())                  # tuning_e4t.py:139-144
+    optimizer = torch.optim.AdamW(params, lr=1e-3)
+    g = torch.Generator().manual_seed(13)
+    image = torch.rand(1, 3, 64, 64, generator=g) * 2 - 1
+    norms = []
+
+    def clip(ps, max_norm):
+        norms.append(torch.nn.utils.clip_grad_norm_(list(ps), max_norm))
+        return norms[-1]
+    ns = dict(torch=torch, F=F, random=random, itertools=itertools, tokenizer=tok, text_encoder=text, unet=unet, e4t_encoder=enc, vae=VAE(),
+              weight_dtype=torch.float32, noise_scheduler=sched, optimizer=optimizer, lr_scheduler=types.SimpleNamespace(step=lambda: None),
+              accelerator=types.SimpleNamespace(device=torch.device("cpu"), backward=lambda loss: loss.backward(), sync_gradients=True, clip_grad_norm_=clip),
+              args=types.SimpleNamespace(train_batch_size=3, train_text_encoder=False, domain_embed_scale=0.1, reg_lambda=0.1, max_grad_norm=1.0),
+              pretrained_args=types.SimpleNamespace(placeholder_token="*s"), prompt_templates=["a photo of {placeholder_token}"],
+              placeholder_token_id=tok.convert_tokens_to_ids("*s"), domain_class_token_id=tok("art", add_special_tokens=False).input_ids[0], image=image)
+    exec(prelude, ns)
+    torch.manual_seed(14)
+    random.seed(14)
+    pick = ["conv_in.weight", "conv_out.bias", "down_blocks.0.resnets.0.conv1.weight", "down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k.weight",
+            "mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj.weight", "up_blocks.3.attentions.2.transformer_blocks.0.attn1.wo_q.linear_row.weight",
+            "up_blocks.1.resnets.0.norm1.weight", "time_embedding.linear_1.weight", "mid_block.attentions.0.transformer_blocks.0.attn1.to_q.weight"]
+    grads, real_step = {}, optimizer.step
+
+    def step_and_record():
+        named = dict(unet.named_parameters())
+        grads.update({n: named[n].grad.clone() for n in pick})
+        grads["__enc_w"] = enc.w.grad.clone()
+        real_step()
+    optimizer.step = step_and_record
+    exec(body, ns)
+    named = dict(unet.named_parameters())
+    assert len(norms) == 1 and float(norms[0]) > 1.0               # the clip was active
+    return dict(text_state=pack(text.state_dict()), vae_P=VAE.P, image=image, latents=ns["latents"].detach(), noise=ns["noise"], timesteps=ns["timesteps"],
+                input_ids=ns["input_ids"], placeholder_idxs=ns["placeholder_token_id_idxs"], loss=ns["loss"].detach(), loss_diff=ns["loss_diff"].detach(),
+                loss_reg=ns["loss_reg"].detach(), total_norm=norms[0].detach(), grads=pack(grads), params_after=pack({n: named[n].detach().clone() for n in pick}))
+
+
 if __name__ == "__main__":
     import open_clip
     open_clip.TEST_ARCHS["ViT-golden-test"] = dict(image_size=224, patch_size=56, width=8, layers=2, heads=2, mlp_ratio=2.0)
@@ -345,7 +440,7 @@ if __name__ == "__main__":
     blobs = {}
     for name, fn in (("unet", unet_fixture), ("unet_wide", unet_wide_fixture), ("attention", attention_fixture), ("encoder", encoder_fixture), ("encoder_wide", encoder_wide_fixture),
                      ("pipeline", lambda: pipeline_fixture(blobs["unet"]["sd1"])), ("pipeline_wide", pipeline_wide_fixture),
-                     ("step", lambda: step_fixture(blobs["unet"]["sd1"]))):
+                     ("step", lambda: step_fixture(blobs["unet"]["sd1"])), ("tuning_step", lambda: tuning_step_fixture(blobs["unet"]["sd1"]))):
         blobs[name] = fn()
         path = os.path.join(sys.argv[1] if len(sys.argv) > 1 else HERE, f"reference_{name}.pt")
         torch.save(blobs[name], path)

@@ -142,7 +142,7 @@ def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
             for v in x:
                 flat(v, out)
         return out
-    for name in ("unet", "unet_wide", "attention", "encoder", "encoder_wide", "pipeline", "pipeline_wide", "step"):
+    for name in ("unet", "unet_wide", "attention", "encoder", "encoder_wide", "pipeline", "pipeline_wide", "step", "tuning_step"):
         a = torch.cat(flat(torch.load(os.path.join(GOLD, f"reference_{name}.pt")), []))
         b = torch.cat(flat(torch.load(tmp_path / f"reference_{name}.pt"), []))
         assert a.shape == b.shape
@@ -290,3 +290,56 @@ def test_training_step_matches_reference_lines():
         bad += int(((named[n].detach() - v).abs() > 1e-5).sum())        # Adam's first step is sign-like: tolerate flips where |g| is rounding noise
     assert bad <= 5, bad
     assert int(((enc.w.detach() - sb["enc_w_after"]).abs() > 1e-5).sum()) <= 2
+
+
+def test_tuning_step_matches_reference_lines():
+    """oracle step with every UNet parameter trainable + clip_grad_norm_(1.0) + AdamW against tuning_e4t.py:266-269,272-338 exec'd
+    verbatim: latents of the expanded image, losses, the global gradient norm, clipped gradients and post-step parameters"""
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, GOLD)
+    from standin import TEXT_CFG, StandInEncoder
+    from e4t.frozen import CLIPTextModel
+    from e4t.utils import WhitespaceTokenizer
+    ub = torch.load(os.path.join(GOLD, "reference_unet.pt"))["sd1"]
+    sb = torch.load(os.path.join(GOLD, "reference_tuning_step.pt"))
+    cfg = ub["config"]
+    unet = orc.UNet2DConditionModel(**cfg)
+    unet.load_state_dict(unpack(ub["state_dict"]))
+    d = cfg["cross_attention_dim"]
+    tok = WhitespaceTokenizer()
+    tok.add_tokens("*s")
+    text = CLIPTextModel(**dict(TEXT_CFG, hidden_size=d, vocab_size=len(tok))).requires_grad_(False)
+    text.load_state_dict(unpack(sb["text_state"]))
+    boc = cfg["block_out_channels"]
+    enc = StandInEncoder(sum(2 * c for c in boc) + boc[0] + sum(boc[:-1]) + boc[-1], d)
+    enc.w.requires_grad_(True)
+    B = 3
+    px = sb["image"].expand(B, -1, -1, -1)
+    lat = torch.einsum("lc,bchw->blhw", sb["vae_P"], F.avg_pool2d(px, 8)) * 0.18215
+    close(lat, sb["latents"], "latents (computed once, :266-269)")
+    kw = dict(padding="max_length", truncation=True, max_length=tok.model_max_length, return_tensors="pt")
+    ids = tok(["a photo of *s"] * B, **kw).input_ids
+    assert torch.equal(ids, sb["input_ids"])
+    with torch.no_grad():
+        class_embed = text.get_input_embeddings()(tok("art", add_special_tokens=False).input_ids[0])
+        ctx0 = text(tok("", **kw).input_ids)[0]
+        emb = text.get_input_embeddings()(ids)
+    params = [enc.w] + list(unet.parameters())
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    loss, ld, lr_, _ = orc.e4t_losses(unet, enc, lambda inputs_embeds: text(inputs_embeds=inputs_embeds)[0], px, lat, sb["noise"], sb["timesteps"], emb,
+                                      sb["placeholder_idxs"], ctx0, class_embed, orc.ddpm_alphas_cumprod(), reg_lambda=0.1)
+    close(ld, sb["loss_diff"], "loss_diff")
+    close(lr_, sb["loss_reg"], "loss_reg")
+    close(loss, sb["loss"], "loss")
+    loss.backward()
+    total = torch.nn.utils.clip_grad_norm_(params, 1.0)
+    close(total, sb["total_norm"], "global gradient norm", rtol=1e-4, atol=1e-6)
+    want = unpack(sb["grads"])
+    close(enc.w.grad, want.pop("__enc_w"), "clipped grad encoder", rtol=3e-4, atol=3e-6)
+    named = dict(unet.named_parameters())
+    for n, g in want.items():
+        close(named[n].grad, g, f"clipped grad {n}", rtol=3e-4, atol=3e-6)
+    opt.step()
+    bad = sum(int(((named[n].detach() - v).abs() > 1e-5).sum()) for n, v in unpack(sb["params_after"]).items())
+    assert bad <= 5, bad
