@@ -37,10 +37,13 @@ PARITY PINNING.  The reference has no tests, golden vectors or fixtures for this
     tests/golden/reference_tuning_step.pt.
   * tests/golden/reference_{unet,encoder}_wide.pt hold reference outputs at widths the native modules support (weights
     derived from the parameter names, not stored): tests compare the oracle AND the native modules with them directly.
-  * Still **parity unpinned**: the third-party leaves themselves (diffusers ResnetBlock2D /
-    Down/Upsample2D / Timesteps / TimestepEmbedding / AutoencoderKL / schedulers, the open_clip ViT, kornia's
-    resize) — the stand-ins use this file's restatements of them —, the CLIP text encoder
-    (e4t/models/modeling_clip.py needs transformers internals that no longer exist).  They are anchored on the
+  * Two third-party leaves are pinned against third-party code that IS installed (transformers 5.x): the CLIP text
+    encoder against ``transformers.CLIPTextModel`` and the ViT against ``transformers.CLIPVisionModel`` (the same
+    architecture as open_clip's, weights mapped by name; pooled = post-LN of the class token, tokens before ln_post)
+    — tests/test_text_host_logic.py, tests/test_encoder_host_logic.py.
+  * Still **parity unpinned**: the diffusers leaves (ResnetBlock2D / Down/Upsample2D / Timesteps /
+    TimestepEmbedding / AutoencoderKL / schedulers) and kornia's resize (restated as the torch call it wraps) — the
+    stand-ins use this file's restatements of them.  They are anchored on the
     reference's call sites and on the known answer it states (UNet encoder feature width 10880,
     e4t/models/unet_2d_condition.py:586).
 """

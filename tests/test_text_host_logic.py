@@ -41,3 +41,40 @@ def test_trainable_text_encoder_falls_back_to_torch(emu_fp32):
     ids = torch.randint(0, 50, (2, 9))
     m(input_ids=ids)[0].sum().backward()
     assert m.text_model.encoder.layers[0].mlp.fc1.weight.grad is not None
+
+
+def test_text_encoder_matches_installed_transformers_clip():
+    """[3P] leaf pinned against the real third-party code that IS installed: transformers' CLIPTextModel (5.x: no `text_model.`
+    prefix in its keys and no inputs_embeds argument — the reason the reference's modeling_clip.py patch cannot import here).
+    Same weights by key -> same last_hidden_state for the torch twin, the oracle and (through the emulation) the native class;
+    the inputs_embeds entry point equals the input_ids one."""
+    transformers = pytest.importorskip("transformers")
+    import e4t_oracle as orc
+    from e4t.frozen import CLIPTextModel as Twin
+    for act, heads in (("quick_gelu", 2), ("gelu", 4)):
+        cfg = transformers.CLIPTextConfig(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=heads,
+                                          max_position_embeddings=9, hidden_act=act, bos_token_id=1, eos_token_id=2)
+        torch.manual_seed(0)
+        hf = transformers.CLIPTextModel(cfg).eval()
+        sd = {("" if k.startswith("text_model.") else "text_model.") + k: v for k, v in hf.state_dict().items()}
+        ids = torch.randint(3, 99, (2, 9), generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            want = hf(input_ids=ids).last_hidden_state
+        mine = dict(vocab_size=100, hidden_size=64, num_layers=2, num_heads=heads, intermediate_size=128, max_len=9, act=act)
+        twin = Twin(**mine)
+        missing, unexpected = twin.load_state_dict(sd, strict=False)
+        assert not missing and all("position_ids" in k for k in unexpected)
+        with torch.no_grad():
+            got = twin(input_ids=ids)[0]
+            via_embeds = twin(inputs_embeds=twin.get_input_embeddings()(ids))[0]
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(via_embeds, got, rtol=0, atol=0)
+        o = orc.CLIPTextModel(vocab=100, width=64, layers=2, heads=heads, mlp=128, max_len=9, act=act)
+        flat = {}
+        for k, v in hf.state_dict().items():          # the oracle keeps a flat naming: layers.i.{q_proj,...,fc1,fc2,layer_norm*}
+            k = k.replace("text_model.", "").replace("embeddings.", "").replace("encoder.layers.", "layers.").replace("self_attn.", "").replace("mlp.", "")
+            if "position_ids" not in k:
+                flat[k] = v
+        o.load_state_dict(flat)
+        with torch.no_grad():
+            torch.testing.assert_close(o(input_ids=ids), want, rtol=1e-5, atol=1e-5)
