@@ -27,67 +27,54 @@ import torch.distributed as dist  # noqa: E402
 HOT_FLOP_PER_IMAGE = {"sd14": 2.72e12, "sd21": 7.13e12}
 STEP_FLOP_PER_IMAGE = {"sd14": 3.86e12, "sd21": 9.83e12}   # incl. frozen VAE encode + text encoder
 MFMA_PEAK = 2.5e15                                         # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12                                          # HBM3E spec (6.3e12 achievable), same guide
 
 
 def build_models(dev, model, seed):
-    from e4t.encoder import E4TEncoder
-    from e4t.frozen import CLIP_TEXT_H, CLIP_TEXT_L
-    from e4t.text import CLIPTextModel          # CLIP text encoder on the HIP kernels
-    from e4t.vae import VAEEncoder
-    from e4t.models.unet_2d_condition import UNet2DConditionModel
-    torch.manual_seed(seed)
-    base = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
-                norm_num_groups=32, norm_eps=1e-5)
-    if model == "sd14":
-        ucfg = dict(base, cross_attention_dim=768, attention_head_dim=8)
-        tcfg, wdim = CLIP_TEXT_L, 768
-    else:
-        ucfg = dict(base, sample_size=96, cross_attention_dim=1024, attention_head_dim=(5, 10, 20, 20), use_linear_projection=True)
-        tcfg, wdim = CLIP_TEXT_H, 1024
-    with torch.device(dev):
-        unet = UNet2DConditionModel(**ucfg)
-        enc = E4TEncoder(word_embedding_dim=wdim, block_out_channels=ucfg["block_out_channels"], arch="ViT-H-14")
-        text = CLIPTextModel(**tcfg).requires_grad_(False)      # fp32 master weights; bf16 compute copies are made once
-        vae = VAEEncoder().requires_grad_(False)          # fp32 masters; the kernel path keeps its own bf16 copies
-    return unet, enc, text, vae
+    """the benchmark's models: e4t.builders (the factory the CLIs use too), token table incl. the placeholder row"""
+    from e4t.builders import build_models as _build
+    return _build(dev, model, seed, vocab_size=49409)
 
 
-def cpu_baseline(model, threads):
-    """The CPU oracle (a port of the reference's algorithm, oracle/e4t_oracle.py) timed on this box's host cores:
-    BASELINE config 1 — full-size UNet + ViT-H-14 encoder, B=1, fp32, ONE training step (fwd, bwd, AdamW)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import e4t_oracle as orc
+def cpu_baseline_and_parity(model, threads, dev):
+    """The CPU leg.  BASELINE config 1 — full-size UNet + ViT-H-14 encoder + text encoder + VAE encoder, B=1, fp32, one
+    training step (VAE encode, both UNet passes, E4T encoder, loss, backward, AdamW) of the oracle (oracle/e4t_oracle.py, a
+    port of the reference's algorithm) on this box's host cores: 1 warm-up + 1 timed step.
+
+    The warm-up step is not wasted: the SAME seeded weights and inputs first go through the native HIP path on the GPU
+    (B=1) and through a stock torch.autocast(bf16) run of the oracle, and the three are compared with the protocol of
+    tests/parity_step.py -> the `parity` block of the JSON line (loss, 13 encoder maps, every weight-offset / head gradient)."""
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import parity_step as ps                      # tests/: the oracle is the checker and the timed CPU baseline, nothing else
     torch.set_num_threads(threads)
-    torch.manual_seed(0)
-    cfg = orc.SD14_UNET_CONFIG if model == "sd14" else orc.SD21_UNET_CONFIG
-    wdim = cfg["cross_attention_dim"]
-    unet = orc.UNet2DConditionModel(**cfg)
-    enc = orc.E4TEncoder(word_embedding_dim=wdim)
-    tcfg = orc.CLIP_TEXT_L if model == "sd14" else orc.CLIP_TEXT_H
-    text = orc.CLIPTextModel(**tcfg).requires_grad_(False)
-    vae = orc.VAEEncoder().requires_grad_(False)
-    opt = torch.optim.AdamW(orc.trainable_parameters(unet, enc), lr=1e-6)
-    acp = orc.ddpm_alphas_cumprod()
-    res = 512 if model == "sd14" else 768
-    g = torch.Generator().manual_seed(0)
-    px = torch.rand(1, 3, res, res, generator=g) * 2 - 1
-    ids = torch.randint(0, 49000, (1, 77), generator=g)
-    with torch.no_grad():
-        class_embed = text.get_input_embeddings()(torch.tensor([1125]))[0]
-        ctx0 = text(input_ids=torch.zeros(1, 77, dtype=torch.long))
+    case = ps.cases()["full_sd14" if model == "sd14" else "full_sd21"]
+    o = ps.build_oracle(case)
+    n = ps.build_native(case, o, dev)
+    d = ps.make_data(case)
+    nat = ps.native_leg(case, n, d, dev)
+    del n
+    torch.cuda.empty_cache()
+    cal = ps.oracle_leg(case, o, d, dev=dev, autocast=True)
+    torch.cuda.empty_cache()
+    ref = ps.oracle_leg(case, o, d)                                   # CPU fp32: the reference answer = the warm-up step
+    rep = ps.compare(case, nat, ref, cal, verbose=False, strict=False)
+    par = dict(case=case.name, rule=rep["rule"], n_quantities=rep["n_quantities"], n_bad=rep["n_bad"], bad=rep["bad"])
+    for kind, key in (("losses", "loss_rel"), ("enc_maps", "enc_maps_rel"), ("grads", "grad_rel"), ("other", "latents_embed_rel")):
+        if kind in rep:
+            w, q = rep[kind]["worst"], rep[kind]["tightest"]
+            par[key] = dict(worst=w["native"], worst_name=w["name"], stock_autocast_same_quantity=w["autocast"],
+                            tightest_fraction_of_bound=q["used"], count=rep[kind]["count"])
+    # timed step, including the optimiser (pretrain_e4t.py:652-654)
+    import e4t_oracle as orc
+    opt = torch.optim.AdamW(orc.trainable_parameters(o["unet"], o["enc"]), lr=1e-6)
     t0 = time.perf_counter()
-    with torch.no_grad():
-        lat = vae.encode_sample(px, torch.randn(1, 4, res // 8, res // 8, generator=g))
-        emb = text.get_input_embeddings()(ids)
-    noise = torch.randn(lat.shape, generator=g)
-    t = torch.randint(0, 1000, (1,), generator=g)
-    loss, _, _, _ = orc.e4t_losses(unet, enc, lambda inputs_embeds: text(inputs_embeds=inputs_embeds), px, lat, noise, t, emb, [5], ctx0,
-                                   class_embed, acp)
-    loss.backward()
+    ps.oracle_leg(case, o, d, collect=False)
     opt.step()
     dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit="images/s", cores=threads, kind="port",
-                sample=f"oracle/e4t_oracle.py, full {model} UNet + ViT-H-14 encoder, B=1, fp32, 1 untimed-warmup-free training step ({dt:.1f} s)")
+    cpu = dict(value=1.0 / dt, unit="images/s", cores=threads, kind="port",
+               sample=f"oracle/e4t_oracle.py, full {model} UNet + ViT-H-14 encoder + CLIP text + VAE encoder, B=1, fp32, "
+                      f"1 warm-up + 1 timed training step incl. AdamW ({dt:.1f} s)")
+    return cpu, par
 
 
 def main():
@@ -115,7 +102,9 @@ def main():
     from e4t.trainer import E4TTrainer
     hip = ops.backend()     # raises when libe4t_hip.so is missing: no fallback
     unet, enc, text, vae = build_models(dev, args.model, seed=0)
-    tr = E4TTrainer(unet, enc, text, vae, lr=1e-6 * args.batch * world, class_token_id=1125, device=dev)
+    # tokenizer("") of CLIP: BOS + EOS padding (pretrain_e4t.py:565-583); class token "art" = one id of the table
+    empty_ids = torch.tensor([[49406] + [49407] * 76], device=dev)
+    tr = E4TTrainer(unet, enc, text, vae, lr=1e-6 * args.batch * world, class_token_id=1125, empty_prompt_ids=empty_ids, device=dev)
 
     B = args.batch
     res = 512 if args.model == "sd14" else 768
@@ -150,59 +139,81 @@ def main():
     dt = float(tmax)
     ips = B * world * args.steps / dt
 
-    roof = None
+    roof = roof_hbm = None
     if not args.no_kernel_roofline:
-        # one extra, instrumented step (outside the timed region): HIP events around every MFMA-kernel launch.  EVERY rank
-        # runs it — a training step contains the gradient all-reduce, a collective rank 0 must not enter alone — and rank 0
-        # records and reports.
+        # one extra, instrumented step (outside the timed region): HIP events around every instrumented launch, recorded on the
+        # stream the kernel is launched on, in the SAME configuration as the timed region and the rocprofv3 run (CLIP-ViT on its
+        # side stream).  EVERY rank runs it — a training step contains the gradient all-reduce, a collective rank 0 must not
+        # enter alone — and rank 0 records and reports.
         if rank == 0:
             hip.prof = []
-        tr.overlap_vision = False      # per-kernel durations must not include a concurrently running side stream
         tr.train_step(*batch(10_000))
         torch.cuda.synchronize()
     if rank == 0 and not args.no_kernel_roofline:
         agg = {}
-        for key, fl, e0, e1 in hip.prof:
-            a = agg.setdefault(key, [0.0, 0.0, 0])
-            a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+        for key, fl, nb, e0, e1 in hip.prof:
+            a = agg.setdefault(key, [0.0, 0.0, 0.0, 0])
+            a[0] += fl; a[1] += nb; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
         hip.prof = None
-        dom = max(agg, key=lambda k: agg[k][1])
-        fl, sec, n = agg[dom]
-        names = {"conv128": "gemm_dma_kernel<128,128,4,2,conv,2> (implicit-GEMM 3x3 conv, 8 waves)",
-                 "conv160": "gemm_dma_kernel<128,160,4,1,conv,2> (implicit-GEMM 3x3 conv)",
-                 "conv64": "gemm_dma_kernel<64,64,2,2,conv,2> (implicit-GEMM 3x3 conv)",
-                 "gemm128": "gemm_dma_kernel<128,128,4,2,dense,2>", "gemm160": "gemm_dma_kernel<128,160,4,1,dense,2>",
-                 "gemm64": "gemm_dma_kernel<64,64,2,2,dense,2>",
-                 "conv512": "gemm_pp_kernel<conv> (256x256 ping-pong implicit-GEMM 3x3 conv)", "gemm512": "gemm_pp_kernel<dense> (256x256 ping-pong)",
-                 "gemm_tn": "gemm_tn_kernel (weight gradients, contraction over rows)"}
-        # HBM bytes per launch of that kernel symbol from the TCC counters: collected offline with tools/pmc_traffic.sh on this
+        names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, 2>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, 2>",
+                 "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, 2>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2>",
+                 "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, 2>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, 2>",
+                 "conv512": "gemm_pp_kernel<1>", "gemm512": "gemm_pp_kernel<0>", "gemm_tn": "gemm_tn_kernel",
+                 "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true>", "gn_fwd_2pass": "gn_stats_kernel + gn_apply_kernel<true>",
+                 "gn_bwd": "gn_bwd_stats_kernel + gn_bwd_apply_kernel", "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel",
+                 "geglu_fwd": "geglu_fwd_kernel", "geglu_bwd": "geglu_bwd_kernel", "adamw": "adamw_kernel"}
+        # HBM bytes per launch of each kernel symbol from the TCC counters: collected offline with tools/profile_round.sh on this
         # very command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 as
-        # MI355X_MICROARCH.md prescribes; check: adamw_kernel comes out at 10.49 GB = 28 B x 374.5 M parameters)
-        traffic = None
-        sym = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, 2>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, 2>",
-               "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2>", "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, 2>",
-               "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, 2>", "conv512": "gemm_pp_kernel<1>", "gemm512": "gemm_pp_kernel<0>",
-               "gemm_tn": "gemm_tn_kernel"}.get(dom)
-        csv_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.csv")
-        if sym and os.path.exists(csv_path) and args.model == "sd14" and args.batch == 16:
-            for line in open(csv_path).read().splitlines()[1:]:
+        # MI355X_MICROARCH.md prescribes; check: adamw_kernel = 28 B x parameters) -> profiles/r02_pmc_traffic.csv, whose header
+        # line names the commit it was collected at; profiles/r02_roofline_per_shape.csv breaks it down per shape.
+        traffic_tab, traffic_src = {}, None
+        csv_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.csv")
+        if os.path.exists(csv_path) and args.model == "sd14" and args.batch == 16:
+            lines = open(csv_path).read().splitlines()
+            traffic_src = "profiles/r02_pmc_traffic.csv" + (" " + lines[0].lstrip("# ") if lines and lines[0].startswith("#") else "")
+            for line in lines:
+                if line.startswith("#") or line.startswith("kernel,"):
+                    continue
                 parts = line.rsplit(",", 4)
-                if parts[0] == sym:
-                    traffic = float(parts[4])
-        roof = dict(bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / sec / MFMA_PEAK, traffic=traffic,
-                    kernel=names.get(dom, dom), launches_per_step=n, avg_launch_ms=sec / n * 1e3,
-                    per_kernel={k: dict(tflops=v[0] / v[1] / 1e12, ms_per_step=v[1] * 1e3, launches=v[2]) for k, v in sorted(agg.items())},
-                    step_mfma_frac_necessary=ips * HOT_FLOP_PER_IMAGE[args.model] / (world * MFMA_PEAK),
-                    step_mfma_frac_whole_step=ips * STEP_FLOP_PER_IMAGE[args.model] / (world * MFMA_PEAK))
+                traffic_tab[parts[0]] = float(parts[4])
+        RIDGE = MFMA_PEAK / HBM_PEAK                 # 312 FLOP/B: below it a kernel cannot be MFMA-bound
+
+        def entry(key):
+            fl, nb, sec, n = agg[key]
+            intensity = fl / nb if nb else 0.0
+            d = dict(kernel=names.get(key, key), launches_per_step=n, avg_launch_ms=sec / n * 1e3, ms_per_step=sec * 1e3,
+                     algorithmic_flop_per_launch=fl / n, algorithmic_bytes_per_launch=nb / n, intensity_flop_per_byte=intensity)
+            if intensity >= RIDGE:
+                d.update(bound="mfma", achieved=fl / sec / 1e12, peak=MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / sec / MFMA_PEAK)
+            else:
+                d.update(bound="hbm", achieved=nb / sec / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=nb / sec / HBM_PEAK)
+                if fl:
+                    d["mfma_frac"] = fl / sec / MFMA_PEAK
+            d["traffic"] = traffic_tab.get(names.get(key))
+            if d["traffic"]:
+                d["traffic_over_algorithmic"] = d["traffic"] / (nb / n)
+            return d
+
+        dom = max(agg, key=lambda k: agg[k][2])
+        roof = entry(dom)
+        roof["traffic_source"] = traffic_src
+        roof["configuration"] = "in-step (ViT side stream on), events on the launch stream; same command as profiles/r02_step_kernel_stats.csv"
+        roof["per_kernel"] = {k: dict(tflops=v[0] / v[2] / 1e12, gbps=v[1] / v[2] / 1e9, ms_per_step=v[2] * 1e3, launches=v[3],
+                                      intensity=(v[0] / v[1] if v[1] else 0.0)) for k, v in sorted(agg.items())}
+        roof["step_mfma_frac_necessary"] = ips * HOT_FLOP_PER_IMAGE[args.model] / (world * MFMA_PEAK)
+        roof["step_mfma_frac_whole_step"] = ips * STEP_FLOP_PER_IMAGE[args.model] / (world * MFMA_PEAK)
+        pure_hbm = [k for k in agg if agg[k][0] == 0.0]
+        if pure_hbm:
+            roof_hbm = entry(max(pure_hbm, key=lambda k: agg[k][2]))
     if world > 1:
         dist.barrier()
 
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(os.cpu_count() or 8, 128)
         del tr, unet, enc, text, vae
         torch.cuda.empty_cache()
-        cpu = cpu_baseline(args.model, threads)
+        cpu, parity = cpu_baseline_and_parity(args.model, threads, dev)
 
     if rank == 0:
         out = dict(metric="E4T pretrain images/sec @512px bf16" if args.model == "sd14" else "E4T pretrain images/sec @768px bf16",
@@ -212,7 +223,7 @@ def main():
                                          else "SD-2.x UNet (ctx 1024, linear proj) + ViT-H-14 E4T encoder pretrain step, 768px"),
                                per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}", trainable="weight offsets + E4T head (ViT frozen)",
                                frozen_on_stock_torch="none (CLIP text encoder and VAE encoder run on the HIP kernels; only embedding lookups / loss glue are torch ops)", last_loss=float(loss)),
-                   roofline=roof, cpu_baseline=cpu)
+                   roofline=roof, roofline_hbm=roof_hbm, cpu_baseline=cpu, parity=parity)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -524,6 +524,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_
 
 template <int DH>
 int launch_fwd(const AttnArgs& p, int Bn, hipStream_t st) {
+  // algorithmic bytes: Q, K, V read once, O written once (bf16) + the fp32 log-sum-exp
+  E4T_LOG_LAUNCH("attn_fwd_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
+                 2.0 * Bn * p.H * DH * (2.0 * p.T + 2.0 * p.S) + 4.0 * Bn * p.H * p.T, 4.0 * Bn * p.H * (double)p.T * p.S * DH);
   hipLaunchKernelGGL((attn_fwd_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
   E4T_CHECK_LAUNCH("attn_fwd_kernel");
   return 0;
@@ -533,6 +536,14 @@ int launch_bwd(const AttnArgs& p, int Bn, hipStream_t st) {
   const long long total = (long long)Bn * p.H * p.T;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
+  if (e4t_launch_log_enabled()) {
+    const double el = (double)Bn * p.H * DH;      // elements per token row over all heads
+    E4T_LOG_LAUNCH("attn_delta_kernel<%d>|B%d H%d T%d|%.0f|0", DH, Bn, p.H, p.T, 4.0 * el * p.T + 4.0 * Bn * p.H * p.T);
+    E4T_LOG_LAUNCH("attn_bwd_dkv_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
+                   2.0 * el * (2.0 * p.T + 4.0 * p.S) + 8.0 * Bn * p.H * p.T, 8.0 * Bn * p.H * (double)p.T * p.S * DH);
+    E4T_LOG_LAUNCH("attn_bwd_dq_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
+                   2.0 * el * (3.0 * p.T + 2.0 * p.S) + 8.0 * Bn * p.H * p.T, 6.0 * Bn * p.H * (double)p.T * p.S * DH);
+  }
   hipLaunchKernelGGL((attn_delta_kernel<DH>), dim3(blocks), dim3(256), 0, st, p, Bn);
   E4T_CHECK_LAUNCH("attn_delta_kernel");
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH>), dim3(cdiv(p.S, 128), p.H, Bn), dim3(256), 0, st, p);

@@ -43,6 +43,16 @@ extern "C" void e4t_set_error(const char* msg);
     if (_e != hipSuccess) E4T_FAIL(-5, "%s: %s", name, hipGetErrorString(_e));    \
   } while (0)
 
+// ---- launch log (diagnostics): one text line per kernel launch — symbol | shape | algorithmic bytes | flops — so that a
+// rocprofv3 kernel trace / PMC collection of the same process can be joined per SHAPE (tools/roofline_report.py).
+// Off unless E4T_LAUNCH_LOG=<path> is set (or e4t_set_launch_log() was called); one branch per launch when off.
+extern "C" int e4t_launch_log_enabled(void);
+extern "C" void e4t_launch_logf(const char* fmt, ...);
+#define E4T_LOG_LAUNCH(...)                                          \
+  do {                                                               \
+    if (e4t_launch_log_enabled()) e4t_launch_logf(__VA_ARGS__);      \
+  } while (0)
+
 // ---- bf16 <-> f32 -------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // fp32 -> bf16, round-to-nearest-even.  Written as native __bf16 conversions so that hipcc emits gfx950's

@@ -11,6 +11,38 @@ extern "C" void e4t_set_error(const char* msg) {
 extern "C" const char* e4t_last_error(void) { return g_err; }
 extern "C" int e4t_version(void) { return 100; }
 
+// ---- launch log ------------------------------------------------------------------------------------
+#include <stdarg.h>
+#include <stdlib.h>
+static FILE* g_log = nullptr;
+static int g_log_state = -1;      // -1: environment not looked at yet
+extern "C" int e4t_set_launch_log(const char* path) {
+  if (g_log) { fclose(g_log); g_log = nullptr; }
+  g_log_state = 0;
+  if (path && path[0]) {
+    g_log = fopen(path, "w");
+    if (!g_log) E4T_FAIL(-2, "set_launch_log: cannot open %s", path);
+    g_log_state = 1;
+  }
+  return 0;
+}
+extern "C" int e4t_launch_log_enabled(void) {
+  if (g_log_state < 0) {
+    const char* p = getenv("E4T_LAUNCH_LOG");
+    if (p && p[0]) e4t_set_launch_log(p); else g_log_state = 0;
+  }
+  return g_log_state;
+}
+extern "C" void e4t_launch_logf(const char* fmt, ...) {
+  if (!g_log) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(g_log, fmt, ap);
+  va_end(ap);
+  fputc('\n', g_log);
+  fflush(g_log);
+}
+
 extern "C" int e4t_device_info(char* arch, int arch_len, int* cu_count) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) E4T_FAIL(-19, "device_info: no HIP device");

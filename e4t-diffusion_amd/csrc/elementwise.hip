@@ -287,12 +287,14 @@ int grid_for(long long work, int cap = 2048) {
 
 extern "C" int e4t_geglu_fwd(const void* u, void* h, long long M, int H, e4t_stream s) {
   E4T_REQUIRE(u && h && M > 0 && H > 0 && H % 8 == 0, "geglu_fwd: bad arguments");
+  E4T_LOG_LAUNCH("geglu_fwd_kernel|M%lld H%d|%.0f|0", M, H, 6.0 * (double)M * H);
   hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(M * (H / 8))), dim3(256), 0, (hipStream_t)s, (const bf16_t*)u, (bf16_t*)h, M, H);
   E4T_CHECK_LAUNCH("geglu_fwd_kernel");
   return 0;
 }
 extern "C" int e4t_geglu_bwd(const void* u, const void* dh, void* du, long long M, int H, e4t_stream s) {
   E4T_REQUIRE(u && dh && du && M > 0 && H > 0 && H % 8 == 0, "geglu_bwd: bad arguments");
+  E4T_LOG_LAUNCH("geglu_bwd_kernel|M%lld H%d|%.0f|0", M, H, 10.0 * (double)M * H);
   hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(M * (H / 8))), dim3(256), 0, (hipStream_t)s, (const bf16_t*)u, (const bf16_t*)dh, (bf16_t*)du, M, H);
   E4T_CHECK_LAUNCH("geglu_bwd_kernel");
   return 0;
@@ -390,6 +392,7 @@ extern "C" int e4t_adamw(float* p, const float* g, float* m, float* v, long long
   E4T_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
   E4T_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw: buffers must be 16-B aligned");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = sqrtf(1.f - powf(beta2, (float)step));
+  E4T_LOG_LAUNCH("adamw_kernel|n%lld|%.0f|0", (long long)n, 28.0 * (double)n);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
   E4T_CHECK_LAUNCH("adamw_kernel");
   return 0;

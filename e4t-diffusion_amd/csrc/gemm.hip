@@ -1359,6 +1359,26 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   const int stats_written = p.colstats != nullptr;
   dim3 grid(gx, gy, splitk * batch), block(256);
   static const bool use_dma = getenv("E4T_GEMM_REGSTAGE") == nullptr;   // A/B switch: register-staged reference kernel
+  if (e4t_launch_log_enabled()) {
+    // algorithmic bytes: every operand element once (conv: the input map once, not once per tap), the output once
+    const double osz = (p.flags & E4T_OUT_F32) ? 4.0 : 2.0;
+    const double a_el = conv ? (double)(p.M / ((long long)p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin : (double)p.M * p.K * batch;
+    double by = 2.0 * a_el + 2.0 * (double)p.N * p.K * (p.strideB || batch == 1 ? batch : 1) + osz * (double)p.M * p.N * (p.reduce_batch ? 1 : batch);
+    if (p.residual) by += ((p.flags & E4T_RES_F32) ? 4.0 : 2.0) * (double)p.M * p.N;
+    if (p.flags & E4T_ACCUM) by += osz * (double)p.M * p.N;
+    const char* sym = !(use_dma && buf_ok) ? "gemm_kernel" : tile == 512 ? (conv ? "gemm_pp_kernel<1>" : "gemm_pp_kernel<0>")
+                      : tile == 640 ? (conv ? "gemm_pt_kernel<1>" : "gemm_pt_kernel<0>")
+                      : tile == 256 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3>")
+                      : tile == 160 ? (conv ? "gemm_dma_kernel<128, 160, 4, 1, 1, 2>" : "gemm_dma_kernel<128, 160, 4, 1, 0, 2>")
+                      : tile == 128 ? (conv ? "gemm_dma_kernel<128, 128, 4, 2, 1, 2>" : "gemm_dma_kernel<128, 128, 4, 2, 0, 2>")
+                      : (conv ? "gemm_dma_kernel<64, 64, 2, 2, 1, 2>" : "gemm_dma_kernel<64, 64, 2, 2, 0, 2>");
+    if (conv) E4T_LOG_LAUNCH("%s|conv mode%d %dx%d->%dx%d Cin%d Cout%d M%d splitk%d|%.0f|%.0f", sym, p.mode, p.Hin, p.Win, p.Hout, p.Wout, p.Cin, p.N,
+                             p.M, splitk, by, 2.0 * p.M * p.N * (double)p.K);
+    else E4T_LOG_LAUNCH("%s|gemm M%d N%d K%d batch%d splitk%d flags%d|%.0f|%.0f", sym, p.M, p.N, p.K, batch, splitk, p.flags, by,
+                        2.0 * p.M * p.N * (double)p.K * batch);
+    if (p.ws) E4T_LOG_LAUNCH("splitk_reduce_kernel|M%d N%d nz%d|%.0f|0", p.M, p.N, p.reduce_batch ? splitk * batch : splitk,
+                             4.0 * (double)p.M * p.N * splitk * batch + osz * (double)p.M * p.N);
+  }
   if (use_dma && buf_ok) {
     if (tile == 512) {
       block = dim3(512);
@@ -1472,6 +1492,12 @@ extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
   p.fast_epi = !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
   hipStream_t st = (hipStream_t)stream;
+  if (e4t_launch_log_enabled()) {
+    const double osz = (p.flags & E4T_OUT_F32) ? 4.0 : 2.0;
+    E4T_LOG_LAUNCH("gemm_tn_kernel|gemm_tn M%d N%d K%d splitk%d flags%d|%.0f|%.0f", p.M, p.N, p.K, splitk, p.flags,
+                   2.0 * (double)p.K * (p.M + p.N) + osz * (double)p.M * p.N * ((p.flags & E4T_ACCUM) ? 2 : 1), 2.0 * p.M * p.N * (double)p.K);
+    if (p.ws) E4T_LOG_LAUNCH("splitk_reduce_kernel|M%d N%d nz%d|%.0f|0", p.M, p.N, splitk, 4.0 * (double)p.M * p.N * splitk + osz * (double)p.M * p.N);
+  }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, splitk), dim3(512), 0, st, p);
   E4T_CHECK_LAUNCH("gemm_tn_kernel");
   if (p.ws) {

@@ -49,6 +49,7 @@ SIGNATURES = {
     "e4t_version": (i32, []),
     "e4t_last_error": (C.c_char_p, []),
     "e4t_device_info": (i32, [C.c_char_p, i32, C.POINTER(i32)]),
+    "e4t_set_launch_log": (i32, [C.c_char_p]),
     "e4t_gemm_nt": (i32, [C.POINTER(GemmDesc), vp]),
     "e4t_gemm_tn": (i32, [C.POINTER(GemmDesc), vp]),
     "e4t_conv3x3": (i32, [C.POINTER(ConvDesc), vp]),

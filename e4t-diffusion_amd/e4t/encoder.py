@@ -228,6 +228,7 @@ class E4TEncoder(nn.Module):
         self._wstack = self._bstack = None
         self._stack_key = None
         self._gW = self._gB = None
+        self.on_backward_done = None      # trainer hook: every encoder gradient is final (starts the head's all-reduce)
 
     @property
     def dtype(self):
@@ -325,6 +326,11 @@ class E4TEncoder(nn.Module):
             m = m.reshape(-1, m.shape[-1])
             maps.append(m if m.dtype == act and m.is_contiguous() else m.to(act).contiguous())
         pooled = Fn.spatial_mean_cat(B, maps)                                              # [B, 10880] fp32
+        cb = self.on_backward_done
+        if cb is not None and torch.is_grad_enabled() and pooled.requires_grad:
+            # the gradient w.r.t. the pooled UNet features is the last thing the encoder's backward produces (the ViT tower,
+            # when trainable, is younger and therefore already done): every encoder gradient is final here
+            pooled.register_hook(lambda g: (cb(), None)[1])
         e0, e2 = self.unet_feature_embedder[0], self.unet_feature_embedder[2]
         u = Fn.linear(pooled.to(act), e0.weight, e0.bias, self._p0)
         u = Fn.linear(Fn.leaky_relu(u), e2.weight, e2.bias, self._p2)                      # [B, hid]

@@ -138,6 +138,7 @@ class UNet2DConditionModel(nn.Module):
         self._resblocks = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
         self._temb_cat, self._temb_rb = None, None
         self.share_prefix = False          # enabled by `with unet.shared_prefix():` around the two passes of one step
+        self.on_up_backward_done = None    # trainer hook: called in the backward once every gradient of up_blocks / conv_norm_out / conv_out is final
         self.wo_banks = [WOBank("up"), WOBank("mid_down")]
         for mod in self.up_blocks.modules():
             if isinstance(mod, CrossAttention):
@@ -221,8 +222,10 @@ class UNet2DConditionModel(nn.Module):
         assert H % (2 ** self.num_upsamplers) == 0 and W % (2 ** self.num_upsamplers) == 0
         dev = sample.device
         be = ops.backend()
-        for bank in self.wo_banks:
-            bank.begin(dev)
+        # the mid/down bank (shared by both passes of a step) opens now; the up bank only when the up blocks are reached, so
+        # that its backward node is YOUNGER than every mid/down node of this pass: autograd runs ready nodes youngest first,
+        # i.e. the up bank's gradients are final — and its all-reduce can start — the moment the backward leaves the up blocks
+        self.wo_banks[1].begin(dev)
         # 1. time embedding (unet_2d_condition.py:441-468)
         t = timestep
         if not torch.is_tensor(t):
@@ -270,6 +273,10 @@ class UNet2DConditionModel(nn.Module):
             self._clear_rb()
             return dict(down_block_samples=tuple(s.nchw() for s in skips + (m,)))
         # 5. up
+        self.wo_banks[0].begin(dev)
+        cb = self.on_up_backward_done
+        if cb is not None and torch.is_grad_enabled() and m.x.requires_grad:
+            m.x.register_hook(lambda g: (cb(), None)[1])      # gradient w.r.t. the mid-block output: every up-block gradient is final
         for blk in self.up_blocks:
             k = len(blk.resnets)
             s, skips = skips[-k:], skips[:-k]

@@ -134,9 +134,9 @@ class HipBackend:
     def __init__(self):
         self.lib = _C.load()
         self._ws = {}
-        self.prof = None   # bench.py: list of (kernel key, algorithmic flops, start event, end event) when enabled
+        self.prof = None   # bench.py: list of (kernel key, algorithmic flops, algorithmic bytes, start event, end event) when enabled
 
-    def _timed(self, key, flops, fn):
+    def _timed(self, key, flops, fn, nbytes=0.0):
         """Run one launch; when profiling is on, bracket it with events on the launch stream."""
         if self.prof is None:
             return fn()
@@ -144,7 +144,7 @@ class HipBackend:
         e0.record()
         r = fn()
         e1.record()
-        self.prof.append((key, flops, e0, e1))
+        self.prof.append((key, flops, float(nbytes() if callable(nbytes) else nbytes), e0, e1))
         return r
 
     @staticmethod
@@ -229,8 +229,11 @@ class HipBackend:
         st = _stream()
         cs = self._colstats_buf(out, M, N, colstats and not batched)
         d.colstats = _ptr(cs)
+        # algorithmic bytes: A, B once; C once (+ once more when read: residual / accumulate)
+        nbytes = lambda: (2.0 * nb * M * K + 2.0 * N * K * (nb if sB else 1) + out.element_size() * M * N * (1 if reduce_batch else nb) * (2 if accum else 1)
+                          + (residual.element_size() * M * N if residual is not None else 0))
         rc = self._timed(f"gemm{self._tile(M, N, K, nb, tile)}", 2.0 * M * N * K * nb,
-                         lambda: _C.check(self.lib.e4t_gemm_nt(C.byref(d), st), "e4t_gemm_nt"))
+                         lambda: _C.check(self.lib.e4t_gemm_nt(C.byref(d), st), "e4t_gemm_nt"), nbytes)
         if cs is not None and rc == 1:
             out._e4t_colstats = cs          # consumed by groupnorm_fwd (the GroupNorm of this activation skips its statistics pass)
         return out
@@ -257,7 +260,8 @@ class HipBackend:
         ws = self.workspace(4 * sk * M * N, a.device) if sk > 1 else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
-        self._timed("gemm_tn", 2.0 * M * N * K, lambda: _C.check(self.lib.e4t_gemm_tn(C.byref(d), st), "e4t_gemm_tn"))
+        self._timed("gemm_tn", 2.0 * M * N * K, lambda: _C.check(self.lib.e4t_gemm_tn(C.byref(d), st), "e4t_gemm_tn"),
+                    2.0 * K * (M + N) + out.element_size() * M * N * (2 if accum else 1))
         return out
 
     # ------------------------------------------------------------------ conv
@@ -286,8 +290,11 @@ class HipBackend:
         st = _stream()
         cs = self._colstats_buf(out, M, Cout, colstats)
         d.colstats = _ptr(cs)
+        # algorithmic bytes: the input map once (not once per tap), the weights once, the output once (+ residual)
+        nbytes = 2.0 * B * Hin * Win * Cin + 2.0 * Cout * 9 * Cin + out.element_size() * M * Cout * (2 if accum else 1) + \
+            (residual.element_size() * M * Cout if residual is not None else 0)
         rc = self._timed(f"conv{self._tile(M, Cout, 9 * Cin, 1, tile, conv=True)}", 2.0 * M * Cout * 9 * Cin,
-                         lambda: _C.check(self.lib.e4t_conv3x3(C.byref(d), st), "e4t_conv3x3"))
+                         lambda: _C.check(self.lib.e4t_conv3x3(C.byref(d), st), "e4t_conv3x3"), nbytes)
         if cs is not None and rc == 1:
             out._e4t_colstats = cs
         return out
@@ -314,7 +321,8 @@ class HipBackend:
         st = _stream()
         self._timed(f"attn_fwd{DH}", 4.0 * B * H * T * S * DH, lambda: _C.check(self.lib.e4t_attention_fwd(
             _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), B, H, T, S, DH, ldq, ldk, ldv, ldo,
-            T * ldq, S * ldk, S * ldv, T * ldo, float(scale), int(causal), st), "e4t_attention_fwd"))
+            T * ldq, S * ldk, S * ldv, T * ldo, float(scale), int(causal), st), "e4t_attention_fwd"),
+            2.0 * B * H * DH * (2 * T + 2 * S) + 4.0 * B * H * T)
         return out, lse
 
     def attention_bwd(self, q, k, v, o, do, lse, dq, dk, dv, B, H, T, S, DH, scale, causal=False):
@@ -326,7 +334,7 @@ class HipBackend:
         self._timed(f"attn_bwd{DH}", 10.0 * B * H * T * S * DH, lambda: _C.check(self.lib.e4t_attention_bwd(
             _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk),
             _ptr(dv), B, H, T, S, DH, ldq, ldk, ldv, ldo, T * ldq, S * ldk, S * ldv, T * ldo,
-            float(scale), int(causal), st), "e4t_attention_bwd"))
+            float(scale), int(causal), st), "e4t_attention_bwd"), 2.0 * B * H * DH * (4 * T + 4 * S) + 8.0 * B * H * T)
 
     # ------------------------------------------------------------------ norms
     def groupnorm_fwd(self, x1, x2, gamma, beta, B, HW, G, eps, silu):
@@ -342,11 +350,13 @@ class HipBackend:
         nblk, nch = HW // 32, self.lib.e4t_groupnorm_num_chunks(B, HW)
         if cs1 is not None and (x2 is None or cs2 is not None) and HW % 32 == 0 and nblk % min(nch, nblk) == 0:
             # the producers left per-32-row column statistics behind: no statistics pass over the activation(s)
-            _C.check(self.lib.e4t_groupnorm_fwd_cs(_ptr(x1), C1, _ptr(cs1), _ptr(x2), C2, _ptr(cs2), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats),
-                                                   B, HW, G, float(eps), int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_fwd_cs")
+            self._timed("gn_fwd_colstats", 0.0, lambda: _C.check(self.lib.e4t_groupnorm_fwd_cs(
+                _ptr(x1), C1, _ptr(cs1), _ptr(x2), C2, _ptr(cs2), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats),
+                B, HW, G, float(eps), int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_fwd_cs"), 4.0 * B * HW * Cn)
             return y, stats
-        _C.check(self.lib.e4t_groupnorm_fwd(_ptr(x1), C1, _ptr(x2), C2, _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), B, HW, G, float(eps),
-                                            int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_fwd")
+        self._timed("gn_fwd_2pass", 0.0, lambda: _C.check(self.lib.e4t_groupnorm_fwd(
+            _ptr(x1), C1, _ptr(x2), C2, _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), B, HW, G, float(eps),
+            int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_fwd"), 6.0 * B * HW * Cn)
         return y, stats
 
     def groupnorm_fwd_unfused(self, x1, x2, gamma, beta, B, HW, G, eps, silu):
@@ -374,8 +384,11 @@ class HipBackend:
         cpart = torch.empty((B * ch, Cn, 2), dtype=f32, device=x1.device) if want_param_grads else None
         nb = self.lib.e4t_groupnorm_workspace_bytes(B, HW, Cn, G, 0) + B * G * 8
         ws = self.workspace(nb, x1.device)
-        _C.check(self.lib.e4t_groupnorm_bwd(_ptr(x1), C1, _ptr(x2), C2, _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(add), _ptr(add2), _ptr(dx1),
-                                            _ptr(dx2), _ptr(cpart), B, HW, G, int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_bwd")
+        # two passes (statistics of dy.x_hat, then apply): x and dy twice, dx once, the fused residual gradients once
+        self._timed("gn_bwd", 0.0, lambda: _C.check(self.lib.e4t_groupnorm_bwd(
+            _ptr(x1), C1, _ptr(x2), C2, _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(add), _ptr(add2), _ptr(dx1),
+            _ptr(dx2), _ptr(cpart), B, HW, G, int(silu), _ptr(ws), ws.numel(), _stream()), "e4t_groupnorm_bwd"),
+            2.0 * B * HW * (5 * Cn + (C1 if add is not None else 0) + (C2 if add2 is not None else 0)))
         dgamma = dbeta = None
         if want_param_grads:
             s = cpart.sum(dim=0)          # tiny (chunks x C) reduction of kernel partials
@@ -387,14 +400,16 @@ class HipBackend:
         assert x.is_contiguous()
         y = torch.empty_like(x)
         stats = torch.empty((M, 2), dtype=f32, device=x.device) if need_stats else None
-        _C.check(self.lib.e4t_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), M, D, float(eps), _stream()), "e4t_layernorm_fwd")
+        self._timed("ln_fwd", 0.0, lambda: _C.check(self.lib.e4t_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), M, D, float(eps),
+                                                                           _stream()), "e4t_layernorm_fwd"), 4.0 * M * D)
         return y, stats
 
     def layernorm_bwd(self, x, dy, gamma, stats, want_param_grads=False, add=None):
         M, D = x.shape
         assert dy.is_contiguous() and (add is None or (add.is_contiguous() and add.shape == x.shape and add.dtype == x.dtype))
         dx = torch.empty_like(x)
-        _C.check(self.lib.e4t_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(stats), _ptr(add), _ptr(dx), M, D, _stream()), "e4t_layernorm_bwd")
+        self._timed("ln_bwd", 0.0, lambda: _C.check(self.lib.e4t_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(stats), _ptr(add), _ptr(dx), M, D,
+                                                                           _stream()), "e4t_layernorm_bwd"), 2.0 * M * D * (4 if add is not None else 3))
         dgamma = dbeta = None
         if want_param_grads:
             dgamma, dbeta = torch.empty(D, dtype=f32, device=x.device), torch.empty(D, dtype=f32, device=x.device)
@@ -421,12 +436,13 @@ class HipBackend:
     def geglu_fwd(self, u):
         M, H2 = u.shape
         h = torch.empty((M, H2 // 2), dtype=bf16, device=u.device)
-        _C.check(self.lib.e4t_geglu_fwd(_ptr(u), _ptr(h), M, H2 // 2, _stream()), "e4t_geglu_fwd")
+        self._timed("geglu_fwd", 0.0, lambda: _C.check(self.lib.e4t_geglu_fwd(_ptr(u), _ptr(h), M, H2 // 2, _stream()), "e4t_geglu_fwd"), 3.0 * M * H2)
         return h
 
     def geglu_bwd(self, u, dh):
         du = torch.empty_like(u)
-        _C.check(self.lib.e4t_geglu_bwd(_ptr(u), _ptr(dh), _ptr(du), u.shape[0], u.shape[1] // 2, _stream()), "e4t_geglu_bwd")
+        self._timed("geglu_bwd", 0.0, lambda: _C.check(self.lib.e4t_geglu_bwd(_ptr(u), _ptr(dh), _ptr(du), u.shape[0], u.shape[1] // 2, _stream()),
+                                                       "e4t_geglu_bwd"), 5.0 * u.shape[0] * u.shape[1])
         return du
 
     def unary(self, x, op, dy=None):
@@ -500,7 +516,8 @@ class HipBackend:
         return out
 
     def adamw(self, p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
-        _C.check(self.lib.e4t_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step, grad_scale, _stream()), "e4t_adamw")
+        self._timed("adamw", 0.0, lambda: _C.check(self.lib.e4t_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step,
+                                                                      grad_scale, _stream()), "e4t_adamw"), 28.0 * p.numel())
 
     def im2col_T(self, x, B, Hin, Win, Hout, Wout, mode):
         """bf16 [B*Hin*Win, C] -> [9*C, ld] with ld = B*Hout*Wout rounded up to 8 (zero padded): B operand of the wgrad GEMM"""

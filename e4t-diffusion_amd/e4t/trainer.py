@@ -175,44 +175,47 @@ class E4TTrainer:
         return self.vae.encode_sample(pixel_values.to(w.dtype), vae_eps).float()
 
     # ---- data-parallel gradient averaging, overlapped with the backward ---------------------------------------------
-    # The flat gradient is laid out [E4T head | mid/down weight offsets | up weight offsets].  In the backward the up-block
-    # offsets are final first (their bank's node fires when the full-pass backward leaves the up blocks), the head next
-    # (before the encoder-pass backward starts), the mid/down offsets last.  Each region's all-reduce is enqueued on RCCL's
-    # stream the moment it is final (async_op), in 256 MB buckets; the step only waits for them before AdamW.
+    # The flat gradient is laid out [E4T encoder | UNet down / mid (+ conv_in, time embedding) | UNet up (+ conv_norm_out,
+    # conv_out)] — in pre-training the UNet part holds only the weight offsets, in tuning every UNet parameter.  The order in
+    # which the regions become final in the backward:
+    #   U  when the full-pass backward leaves the up blocks: the UNet calls `on_up_backward_done` from a hook on the gradient
+    #      of the mid-block output, by which time the up bank's own backward node has run (it is created right before the up
+    #      blocks, so autograd — youngest ready node first — runs it before any mid-block node);
+    #   H  when the encoder's backward is complete (hook on the gradient of its pooled-UNet-feature input; a trainable ViT is
+    #      younger than that node and therefore done): before the whole encoder-pass UNet backward;
+    #   D  at the very end (the mid/down parameters are shared by both UNet passes).
+    # Each region's all-reduce is enqueued on RCCL's stream the moment it is final (async_op), in 256 MB buckets; the step only
+    # waits for the handles before the gradient clip / AdamW.
     def _setup_overlap(self, named, n_first):
         self._works, self._done = [], set()
         self.regions = None
-        if not self._comm or self.tuning:
+        up_bank, md_bank = self.unet.wo_banks
+        up_bank.on_backward_done = md_bank.on_backward_done = None          # a previous trainer's announcements, if any
+        self.unet.on_up_backward_done = None
+        self.encoder.on_backward_done = None
+        if not self._comm:
             return
         params = self.flat.params
-        idx_unet = next((i for i, (n, _) in enumerate(named) if n.startswith("unet.")), None)
-        names = [n for n, _ in named]
-        # `named` order == flat order only after the first_linears re-ordering: recompute from the flat list
-        pid = {id(p): n for n, p in named}
+        pid = {id(p): n for n, p in named}          # `named` order == flat order only after the first_linears re-ordering
         flat_names = [pid[id(p)] for p in params]
         first_unet = next(i for i, n in enumerate(flat_names) if n.startswith("unet."))
         first_up = next(i for i, n in enumerate(flat_names) if n.startswith("unet.up_blocks."))
-        assert all(n.startswith("unet.up_blocks.") for n in flat_names[first_up:]) and all(not n.startswith("unet.") for n in flat_names[:first_unet])
+        tail = ("unet.up_blocks.", "unet.conv_norm_out.", "unet.conv_out.")
+        assert all(n.startswith(tail) for n in flat_names[first_up:]) and all(not n.startswith("unet.") for n in flat_names[:first_unet])
+        assert not any(n.startswith(tail) for n in flat_names[first_unet:first_up])
         o = self.flat.offsets
         self.regions = dict(H=(0, o[first_unet]), D=(o[first_unet], o[first_up]), U=(o[first_up], self.flat.numel))
-        up_bank, md_bank = self.unet.wo_banks
-        up_bank.on_backward_done = lambda b: self._reduce_region("U")
-        md_bank.on_backward_done = lambda b: self._reduce_region("D")
-        enc = self.encoder
-        if not any(p.requires_grad for p in enc.clip_vision.parameters()):
-            # the last head gradients to be accumulated are those of unet_feature_embedder.0 (deepest head layer)
-            last = [enc.unet_feature_embedder[0].weight, enc.unet_feature_embedder[0].bias]
-            self._head_pending = 0
+        self._up_events = 0
 
-            def hook(_p):
-                self._head_pending -= 1
-                if self._head_pending == 0:
-                    self._reduce_region("H")
-            for p in last:
-                p.register_post_accumulate_grad_hook(hook)
-            self._head_last = len(last)
-        else:
-            self._head_last = 0
+        def up_event(*_):
+            # two announcements per step: the up bank's backward node and the mid-output gradient hook
+            self._up_events += 1
+            if self._up_events == 2:
+                self._reduce_region("U")
+        up_bank.on_backward_done = up_event
+        self.unet.on_up_backward_done = up_event
+        md_bank.on_backward_done = lambda b: self._reduce_region("D")
+        self.encoder.on_backward_done = lambda: self._reduce_region("H")
 
     def _reduce_region(self, key, force=False):
         """enqueue the all-reduce of one region; during the backward only while a synchronising step is armed, `force` for the
@@ -292,7 +295,7 @@ class E4TTrainer:
             timesteps = torch.randint(0, self.acp.shape[0], (B,), device=dev).long()
         loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
         self._armed = bool(sync)             # micro-batches that only accumulate start no collectives
-        self._head_pending = getattr(self, "_head_last", 0)
+        self._up_events = 0
         Fn.set_inplace_param_grads(True)     # weight / bias gradients accumulate straight into the flat buffer (functional.py)
         try:
             (loss if loss_scale == 1.0 else loss * loss_scale).backward()

@@ -30,6 +30,10 @@ int e4t_version(void);
 const char* e4t_last_error(void);
 /* device sanity: returns 0 and fills arch name (e.g. "gfx950"), CU count */
 int e4t_device_info(char* arch, int arch_len, int* cu_count);
+/* diagnostics: write one text line per kernel launch (kernel symbol | shape | algorithmic bytes | flops) to `path`
+ * (NULL or "" stops).  Also enabled by the environment variable E4T_LAUNCH_LOG=<path>.  Used by tools/roofline_report.py to
+ * join a rocprofv3 kernel trace / PMC run of the same process per SHAPE; the reference has no counterpart. */
+int e4t_set_launch_log(const char* path);
 
 /* ---------------------------------------------------------------- GEMM / conv (gemm.hip) ---- */
 /* epilogue flags */

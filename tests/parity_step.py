@@ -1,0 +1,347 @@
+"""The parity protocol of SURVEY.md §8(c), one harness for every model-level GPU parity test (TEST INFRASTRUCTURE).
+
+One training step (pretrain_e4t.py:595-654 / tuning_e4t.py:266-338) on seeded weights and inputs is run three ways:
+
+  oracle    oracle/e4t_oracle.py, CPU, fp32                                  -> the reference answer
+  native    the product path: e4t.* modules on the HIP kernels, bf16         -> what is being tested
+  autocast  a copy of the SAME oracle under stock ``torch.autocast(bf16)``   -> the calibration: how far a stock bf16
+            (on the GPU when there is one: rocBLAS / MIOpen)                    run of the same algorithm lands
+
+and every compared quantity q (13 encoder maps, VAE latents, losses, every trainable gradient) must satisfy SURVEY §8(c):
+
+    rel_l2(native q, oracle q)  <=  2 * rel_l2(autocast q, oracle q) + FLOOR          (losses: also <= 1e-2 relative)
+
+The autocast leg replaces the hand-picked 0.25 gradient bound of round 1: a gradient that is mostly rounding noise in a
+stock bf16 run may be that noisy here too, and nothing else may.  FLOOR (3e-3, ~one bf16 rounding of the quantity)
+only matters where the autocast run happens to be nearly exact.
+"""
+from __future__ import annotations
+
+import copy
+import time
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+FLOOR = 3e-3
+
+TINY_VIT = dict(image_size=28, patch_size=14, width=128, layers=2, heads=2, mlp_ratio=4.0)
+WIDE_VIT = dict(image_size=224, patch_size=14, width=1280, layers=2, heads=16, mlp_ratio=4.0)      # ViT-H-14 width / heads / 257 tokens, 2 layers
+TINY_TEXT = dict(vocab_size=100, hidden_size=64, num_layers=2, num_heads=2, intermediate_size=128, max_len=9, act="quick_gelu")
+TINY_BOC = (64, 128, 128, 128)
+SD_BOC = (320, 640, 1280, 1280)
+
+
+@dataclass
+class Case:
+    name: str
+    unet_cfg: dict
+    boc: tuple = TINY_BOC
+    vit_cfg: Optional[dict] = field(default_factory=lambda: dict(TINY_VIT))     # None -> ViT-H-14 (full size)
+    text_cfg: dict = field(default_factory=lambda: dict(TINY_TEXT))
+    B: int = 2
+    px: int = 64                            # image side
+    lat: int = 16                           # latent side
+    tuning: bool = False                    # tuning_e4t.py: every UNet parameter trains, gradient-norm clip
+    unfreeze_vit: bool = False              # --unfreeze_clip_vision (encoder.py:98-99)
+    prediction_type: str = "epsilon"
+    reg_lambda: float = 0.01
+    with_vae: bool = False                  # run the VAE encoder too (latents compared), else latents are drawn
+    vae_boc: tuple = (128, 256, 512, 512)
+    class_id: int = 11
+    seed: int = 0
+
+
+def cases():
+    import e4t_oracle as orc
+    tiny = orc.tiny_unet_config(ctx_dim=64)
+    wtext = lambda w, h: dict(TINY_TEXT, hidden_size=w, num_heads=h, intermediate_size=2 * w)
+    return {
+        # the round-1 smoke case (tiny SD-1 topology)
+        "tiny_sd1": Case("tiny_sd1", tiny),
+        # BASELINE configs[1] at B=1: full SD-1.4 UNet + ViT-H-14 encoder + CLIP-L text + AutoencoderKL encoder, 512 px
+        "full_sd14": Case("full_sd14", dict(orc.SD14_UNET_CONFIG), boc=SD_BOC, vit_cfg=None,
+                          text_cfg=dict(vocab_size=49409, hidden_size=768, num_layers=12, num_heads=12, intermediate_size=3072, max_len=77,
+                                        act="quick_gelu"), B=1, px=512, lat=64, with_vae=True, class_id=1125),
+        "full_sd21": Case("full_sd21", dict(orc.SD21_UNET_CONFIG), boc=SD_BOC, vit_cfg=None,
+                          text_cfg=dict(vocab_size=49409, hidden_size=1024, num_layers=23, num_heads=16, intermediate_size=4096, max_len=77,
+                                        act="gelu"), B=1, px=768, lat=96, with_vae=True, class_id=1125, prediction_type="v_prediction"),
+        # BASELINE configs[4]: the SD-2.x UNet config at its real widths (heads 5/10/20/20 = dh 64, ctx 1024, linear projections,
+        # v-prediction) on 24x24 latents (T = 576 / 144 / 36 / 9: ragged attention and GEMM tiles), wide 2-layer ViT
+        "sd2_real_width": Case("sd2_real_width", dict(orc.SD21_UNET_CONFIG, sample_size=24), boc=SD_BOC, vit_cfg=WIDE_VIT,
+                               text_cfg=wtext(1024, 16), B=2, px=192, lat=24, prediction_type="v_prediction"),
+        "tiny_sd2": Case("tiny_sd2", dict(tiny, attention_head_dim=(1, 2, 2, 2), use_linear_projection=True), prediction_type="v_prediction",
+                         lat=24, px=96),
+        # BASELINE configs[3]: tuning step, every UNet weight trains (3x3 conv wgrad through im2col + TN GEMM), real SD-1.4 widths
+        "tuning_real_width": Case("tuning_real_width", dict(orc.SD14_UNET_CONFIG, sample_size=16), boc=SD_BOC, vit_cfg=TINY_VIT,
+                                  text_cfg=wtext(768, 12), B=2, px=64, lat=16, tuning=True, reg_lambda=0.1),
+        "tuning_tiny": Case("tuning_tiny", tiny, tuning=True, reg_lambda=0.1, B=3),
+        # --unfreeze_clip_vision: backward through the ViT tower at ViT-H width
+        "unfrozen_vit": Case("unfrozen_vit", tiny, vit_cfg=WIDE_VIT, unfreeze_vit=True, px=96),
+        "unfrozen_vit_tiny": Case("unfrozen_vit_tiny", tiny, unfreeze_vit=True),
+    }
+
+
+# ---- key maps between the native (HF checkpoint) module trees and the oracle's flat ones ------------------------------------
+def text_to_oracle_keys(sd):
+    out = {}
+    for k, v in sd.items():
+        k = k.replace("text_model.", "").replace("embeddings.", "").replace("encoder.layers.", "layers.").replace("self_attn.", "").replace("mlp.", "")
+        if "position_ids" not in k:
+            out[k] = v
+    return out
+
+
+def vae_to_oracle_keys(sd):
+    out = {}
+    for k, v in sd.items():
+        k2 = k
+        if k.startswith("encoder."):
+            k2 = k[len("encoder."):]
+            k2 = k2.replace("down_blocks.", "down.").replace("downsamplers.0.", "downsampler.")
+            k2 = k2.replace("mid_block.resnets.0.", "mid_res1.").replace("mid_block.resnets.1.", "mid_res2.").replace("mid_block.attentions.0.", "mid_attn.")
+        out[k2] = v
+    return out
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ---- model pairs -------------------------------------------------------------------------------------------------------------
+def build_oracle(case: Case):
+    """The oracle models on the CPU in fp32 with torch's default initialisers (weight offsets at their default init, so
+    the offsets are not zero) — the seeded state every other leg loads."""
+    import e4t_oracle as orc
+    torch.manual_seed(case.seed)
+    t = case.text_cfg
+    unet = orc.UNet2DConditionModel(**case.unet_cfg)
+    vit = dict(orc.VIT_H_14) if case.vit_cfg is None else dict(case.vit_cfg)
+    enc = orc.E4TEncoder(word_embedding_dim=t["hidden_size"], block_out_channels=case.boc, vit_cfg=vit,
+                         n_odd_layers=None, freeze_clip_vision=not case.unfreeze_vit)
+    text = orc.CLIPTextModel(vocab=t["vocab_size"], width=t["hidden_size"], layers=t["num_layers"], heads=t["num_heads"],
+                             mlp=t["intermediate_size"], max_len=t["max_len"], act=t["act"]).requires_grad_(False)
+    vae = orc.VAEEncoder(block_out_channels=case.vae_boc).requires_grad_(False) if case.with_vae else None
+    for n, p in unet.named_parameters():
+        p.requires_grad_(case.tuning or "wo" in n)
+    return dict(unet=unet, enc=enc, text=text, vae=vae)
+
+
+def build_native(case: Case, o, dev):
+    """The product modules, constructed on `dev`, loaded from the oracle's state dicts by key."""
+    from e4t.encoder import E4TEncoder, VIT_ARCHS
+    from e4t.models.unet_2d_condition import UNet2DConditionModel
+    from e4t.text import CLIPTextModel
+    from e4t.vae import VAEEncoder
+    with torch.device(dev):
+        unet = UNet2DConditionModel(**case.unet_cfg)
+        if case.vit_cfg is None:
+            enc = E4TEncoder(word_embedding_dim=case.text_cfg["hidden_size"], block_out_channels=case.boc, arch="ViT-H-14",
+                             freeze_clip_vision=not case.unfreeze_vit)
+        else:
+            g = case.vit_cfg["image_size"] // case.vit_cfg["patch_size"]
+            enc = E4TEncoder(word_embedding_dim=case.text_cfg["hidden_size"], block_out_channels=case.boc, arch="custom", vit_cfg=dict(case.vit_cfg),
+                             n_odd_layers=(g * g) // 2 + 1, freeze_clip_vision=not case.unfreeze_vit)
+        text = CLIPTextModel(**case.text_cfg).requires_grad_(False)
+        vae = VAEEncoder(block_out_channels=case.vae_boc).requires_grad_(False) if case.with_vae else None
+    unet.load_state_dict(o["unet"].state_dict())
+    enc.load_state_dict(o["enc"].state_dict())
+    want = set(text.state_dict())
+    text.load_state_dict({k: v for k, v in _to_native_text(o["text"].state_dict(), want).items()})
+    if vae is not None:
+        back = {vk: k for k, vk in zip(vae.state_dict().keys(), vae_to_oracle_keys(vae.state_dict()).keys())}
+        vae.load_state_dict({back[k]: v for k, v in o["vae"].state_dict().items()})
+    return dict(unet=unet, enc=enc, text=text, vae=vae)
+
+
+def _to_native_text(osd, native_keys):
+    inv = {}
+    for k in native_keys:
+        inv[next(iter(text_to_oracle_keys({k: None})))] = k
+    return {inv[k]: v for k, v in osd.items()}
+
+
+def make_data(case: Case):
+    g = torch.Generator().manual_seed(1000 + case.seed)
+    B, S, V = case.B, case.text_cfg["max_len"], case.text_cfg["vocab_size"]
+    d = dict(pixels=torch.rand(B, 3, case.px, case.px, generator=g) * 2 - 1,
+             noise=torch.randn(B, 4, case.lat, case.lat, generator=g),
+             t=torch.randint(0, 1000, (B,), generator=g),
+             ids=torch.randint(1, V - 1, (B, S), generator=g),
+             pidx=torch.randint(1, S - 1, (B,), generator=g),
+             empty_ids=torch.zeros(1, S, dtype=torch.long))
+    if case.with_vae:
+        d["vae_eps"] = torch.randn(B, 4, case.lat, case.lat, generator=g)
+    else:
+        d["latents"] = torch.randn(B, 4, case.lat, case.lat, generator=g) * 0.18215
+    if case.tuning:          # tuning_e4t.py:266: ONE image expanded over the batch
+        d["pixels"] = d["pixels"][:1].expand(B, -1, -1, -1).contiguous()
+        if "latents" in d:
+            d["latents"] = d["latents"][:1].expand(B, -1, -1, -1).contiguous()
+        d["ids"], d["pidx"] = d["ids"][:1].expand(B, -1).contiguous(), d["pidx"][:1].expand(B).contiguous()
+    return d
+
+
+# ---- the three legs ------------------------------------------------------------------------------------------------------------
+def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collect=True):
+    """fp32 on the CPU = the reference answer; autocast=True on `dev` = the calibration leg (on copies of the models)."""
+    import e4t_oracle as orc
+    if autocast or dev.type != "cpu":
+        o = {k: (copy.deepcopy(v).to(dev) if v is not None else None) for k, v in o.items()}
+    mv = lambda x: x.to(dev)
+    unet, enc, text, vae = o["unet"], o["enc"], o["text"], o["vae"]
+    for m in (unet, enc):
+        for p in m.parameters():
+            p.grad = None
+    acp = mv(orc.ddpm_alphas_cumprod())
+    ctx_mgr = torch.autocast(dev.type, dtype=torch.bfloat16) if autocast else torch.autocast(dev.type, enabled=False)
+    out = {}
+    with ctx_mgr:
+        with torch.no_grad():
+            class_embed = text.get_input_embeddings()(torch.tensor([case.class_id], device=dev))[0]
+            ctx0 = text(input_ids=mv(d["empty_ids"]))
+            emb = text.get_input_embeddings()(mv(d["ids"]))
+            if case.with_vae:
+                latents = vae.encode_sample(mv(d["pixels"]), mv(d["vae_eps"])).float()
+                out["latents"] = latents
+            else:
+                latents = mv(d["latents"])
+        loss, ld, lr_, aux = orc.e4t_losses(unet, enc, lambda inputs_embeds: text(inputs_embeds=inputs_embeds), mv(d["pixels"]), latents,
+                                            mv(d["noise"]), mv(d["t"]), emb, d["pidx"].tolist(), ctx0, class_embed, acp,
+                                            reg_lambda=case.reg_lambda, prediction_type=case.prediction_type)
+    loss.backward()
+    if not collect:
+        return None
+    out["loss_diff"], out["loss_reg"] = ld.detach().float(), lr_.detach().float()
+    for i, m in enumerate(aux["enc"]["down_block_samples"]):
+        out[f"enc_map_{i:02d}"] = m.detach().float()
+    out["domain_embed"] = aux["domain_embed"].detach().float()
+    for n, p in unet.named_parameters():
+        if p.requires_grad:
+            out[f"grad/unet.{n}"] = p.grad.detach().float()
+    for n, p in enc.named_parameters():
+        if p.requires_grad:
+            out[f"grad/e4t_encoder.{n}"] = p.grad.detach().float()
+    return {k: v.cpu() for k, v in out.items()}
+
+
+def native_leg(case: Case, n, d, dev):
+    """The product path: E4TTrainer on the native modules (HIP kernels on a GPU)."""
+    from e4t import functional as Fn
+    from e4t.trainer import E4TTrainer
+    mv = lambda x: x.to(dev)
+    tr = E4TTrainer(n["unet"], n["enc"], n["text"], vae=n["vae"], lr=1e-4, reg_lambda=case.reg_lambda, prediction_type=case.prediction_type,
+                    class_token_id=case.class_id, empty_prompt_ids=mv(d["empty_ids"]), device=dev, tuning=case.tuning,
+                    max_grad_norm=1.0 if case.tuning else None)
+    out = {}
+    B = case.B
+    with torch.no_grad():
+        if case.with_vae:
+            latents = tr.encode_latents(mv(d["pixels"]), mv(d["vae_eps"]))
+            out["latents"] = latents.float()
+        else:
+            latents = mv(d["latents"])
+        noisy = tr.add_noise(latents, mv(d["noise"]), mv(d["t"]))
+        maps = n["unet"](noisy, mv(d["t"]), tr.ctx_for_e4t.expand(B, -1, -1), return_encoder_outputs=True)["down_block_samples"]
+        for i, m in enumerate(maps):
+            out[f"enc_map_{i:02d}"] = m.float()
+    got = {}
+    hook = n["enc"].register_forward_hook(lambda m, a, y: got.__setitem__("y", y.detach().float()))
+    loss, ld, lr_ = tr.losses(mv(d["pixels"]), latents, mv(d["noise"]), mv(d["t"]), mv(d["ids"]), mv(d["pidx"]))
+    hook.remove()
+    out["domain_embed"] = tr.class_embed[None, :] + tr.scale * got["y"]                       # pretrain_e4t.py:628
+    Fn.set_inplace_param_grads(True)            # as E4TTrainer.train_step does
+    try:
+        loss.backward()
+    finally:
+        Fn.set_inplace_param_grads(False)
+    out["loss_diff"], out["loss_reg"] = ld.detach().float(), lr_.detach().float()
+    for name, p in n["unet"].named_parameters():
+        if p.requires_grad:
+            out[f"grad/unet.{name}"] = p.grad.detach().float().clone()
+    for name, p in n["enc"].named_parameters():
+        if p.requires_grad:
+            out[f"grad/e4t_encoder.{name}"] = p.grad.detach().float().clone()
+    out = {k: v.cpu() for k, v in out.items()}
+    if case.tuning:
+        from e4t import ops
+        out["grad_norm"] = ops.backend().sumsq(tr.flat.grad).sqrt().detach().float().cpu()
+    tr.clip_grad_norm()
+    tr.optimizer_step()
+    tr.zero_grad()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    return out
+
+
+# ---- comparison ----------------------------------------------------------------------------------------------------------------
+def compare(case: Case, nat, ref, cal, verbose=True, strict=True):
+    """-> report dict; raises AssertionError listing every quantity that breaks  err <= 2 * calib + FLOOR.
+    Gradients are judged per tensor when it has >= 256 elements, else pooled with the other small tensors of its block (down_blocks.i / mid_block / up_blocks.i / encoder sub-module)."""
+    rows, small = [], {}
+    for k in ref:
+        if k not in nat:
+            continue
+        if k.startswith("grad/") and ref[k].numel() < 256:
+            small.setdefault(".".join(k.split(".")[:3 if ("_blocks." in k or ".resblocks." in k) else 2]), []).append(k)
+            continue
+        rows.append((k, rel(nat[k], ref[k]), rel(cal[k], ref[k])))
+    for gname, ks in small.items():
+        cat = lambda r: torch.cat([r[k].reshape(-1) for k in ks])
+        rows.append((gname + ".{small}", rel(cat(nat), cat(ref)), rel(cat(cal), cat(ref))))
+    if "grad_norm" in nat:
+        gn = torch.sqrt(sum(v.double().pow(2).sum() for k, v in ref.items() if k.startswith("grad/")))
+        gc = torch.sqrt(sum(v.double().pow(2).sum() for k, v in cal.items() if k.startswith("grad/")))
+        rows.append(("grad_norm", abs(float(nat["grad_norm"]) - float(gn)) / float(gn), abs(float(gc) - float(gn)) / float(gn)))
+    missing = [k for k in ref if k not in nat]
+    assert not missing, f"native leg did not produce {missing[:5]}"
+    bad = []
+    for k, e, c in rows:
+        bound = 2 * c + FLOOR
+        if k.startswith("loss"):
+            bound = min(max(bound, FLOOR), 1e-2)
+        if not (e <= bound):
+            bad.append((k, e, c))
+    kinds = dict(enc_maps=[r for r in rows if r[0].startswith("enc_map")], losses=[r for r in rows if r[0].startswith("loss")],
+                 grads=[r for r in rows if r[0].startswith("grad")], other=[r for r in rows if r[0] in ("latents", "domain_embed", "grad_norm")])
+    worst = lambda rs: max(rs, key=lambda r: r[1]) if rs else None
+    ratio = lambda rs: max(rs, key=lambda r: r[1] / (2 * r[2] + FLOOR)) if rs else None
+    rep = dict(case=case.name, n_quantities=len(rows), n_bad=len(bad))
+    for kind, rs in kinds.items():
+        if rs:
+            w, q = worst(rs), ratio(rs)
+            rep[kind] = dict(worst=dict(name=w[0], native=w[1], autocast=w[2]),
+                             tightest=dict(name=q[0], native=q[1], autocast=q[2], used=q[1] / (2 * q[2] + FLOOR)), count=len(rs))
+    if verbose:
+        for kind in ("other", "enc_maps", "losses", "grads"):
+            if kind in rep:
+                w, q = rep[kind]["worst"], rep[kind]["tightest"]
+                print(f"  parity[{case.name}] {kind:<9s} n={rep[kind]['count']:<4d} worst {w['name']}: native {w['native']:.3e} (autocast {w['autocast']:.3e});"
+                      f" tightest {q['name']}: {q['used']:.2f} of its bound")
+        for k, e, c in bad[:20]:
+            print(f"  parity[{case.name}] OVER  {k}: native {e:.3e} > 2 x autocast {c:.3e} + {FLOOR}")
+    rep["bad"] = [dict(name=k, native=e, autocast=c) for k, e, c in bad[:16]]
+    rep["rule"] = f"rel_l2(native, oracle) <= 2 * rel_l2(stock autocast bf16 of the oracle, oracle) + {FLOOR}; losses also <= 1e-2"
+    assert not (bad and strict), f"{case.name}: {len(bad)} quantities exceed 2 x stock-autocast error + {FLOOR}: " + ", ".join(f"{k} {e:.2e}/{c:.2e}" for k, e, c in bad[:8])
+    return rep
+
+
+def run(case_name, dev, calib_dev=None, verbose=True):
+    """Build the pair, run the three legs, compare.  Returns the report (also carries wall times)."""
+    case = cases()[case_name]
+    t0 = time.perf_counter()
+    o = build_oracle(case)
+    n = build_native(case, o, dev)
+    d = make_data(case)
+    t1 = time.perf_counter()
+    nat = native_leg(case, n, d, dev)
+    t2 = time.perf_counter()
+    ref = oracle_leg(case, o, d)
+    t3 = time.perf_counter()
+    cal = oracle_leg(case, o, d, dev=calib_dev or dev, autocast=True)
+    t4 = time.perf_counter()
+    rep = compare(case, nat, ref, cal, verbose=verbose)
+    rep["seconds"] = dict(build=t1 - t0, native=t2 - t1, oracle_fp32_cpu=t3 - t2, autocast=t4 - t3)
+    return rep

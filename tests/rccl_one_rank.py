@@ -1,0 +1,77 @@
+"""Launched by tests/test_rccl_gpu.py under torch.distributed.run with ONE rank on a real MI355X (no 8-GPU node is available to
+the build): the data-parallel path of the trainer on real RCCL — hook-triggered async all-reduces of the three gradient
+regions on RCCL's stream, the waits before the clip / AdamW — must leave exactly the parameters of the no-communication run
+(a 1-rank sum is the identity, so any difference is a stream-ordering bug: a region reduced before its last gradient kernel
+finished, or AdamW reading a region before its all-reduce completed)."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (os.path.join(ROOT, "e4t-diffusion_amd"), ROOT, HERE, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def run(dev, comm, tuning, steps=3):
+    from test_train_step_host_logic import TEXT_CFG, build
+    from e4t.text import CLIPTextModel
+    from e4t.trainer import E4TTrainer
+    os.environ["E4T_FORCE_COMM"] = "1" if comm else "0"
+    _, _, n_unet, n_enc, text_t = build(seed=0)
+    text = CLIPTextModel(**TEXT_CFG).requires_grad_(False)
+    text.load_state_dict(text_t.state_dict())
+    n_unet.to(dev), n_enc.to(dev), text.to(dev)
+    tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev),
+                    device=dev, tuning=tuning, max_grad_norm=1.0 if tuning else None)
+    assert tr._comm == comm and (tr.regions is not None) == comm
+    log = []
+    if comm:
+        orig = tr._reduce_region
+
+        def spy(key, force=False):
+            if key not in tr._done and (tr._armed or force):
+                log.append((key, bool(force)))
+            return orig(key, force)
+        tr._reduce_region = spy
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    pidx = torch.tensor([2, 4], device=dev)
+    losses = []
+    for s in range(steps):
+        px, lat = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1, torch.randn(B, 4, 16, 16, generator=g) * 0.18215
+        noise, t, ids = torch.randn(B, 4, 16, 16, generator=g), torch.randint(0, 1000, (B,), generator=g), torch.randint(1, 99, (B, 9), generator=g)
+        kw = dict(noise=noise.to(dev), timesteps=t.to(dev), latents=lat.to(dev))
+        if s == 1:      # a gradient-accumulation micro-batch: no collective, no optimiser step
+            out = tr.train_step(px.to(dev), ids.to(dev), pidx, sync=False, loss_scale=0.5, **kw)
+        else:
+            out = tr.train_step(px.to(dev), ids.to(dev), pidx, loss_scale=0.5 if s == 2 else 1.0, **kw)
+        losses.append(torch.stack([o.detach().float() for o in out]).cpu())
+    torch.cuda.synchronize()
+    return torch.stack(losses), tr.flat.data.detach().cpu().clone(), log
+
+
+def main():
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+    for tuning in (False, True):
+        l0, p0, _ = run(dev, comm=False, tuning=tuning)
+        l1, p1, log = run(dev, comm=True, tuning=tuning)
+        assert torch.equal(l0, l1), (tuning, l0, l1)
+        assert torch.equal(p0, p1), (tuning, float((p0 - p1).abs().max()))
+        # two synchronising steps, each: U, H announced by the backward hooks, D by the mid/down bank — none by the sweep
+        assert log == [("U", False), ("H", False), ("D", False)] * 2, log
+        print(f"rccl one-rank {'tuning' if tuning else 'pretrain'}: {p0.numel()} parameters bit-identical with / without the collective path; regions {log[:3]}")
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RCCL_ONE_RANK_OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -94,3 +94,53 @@ def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
     finally:
         ops.set_backend(old_b)
         ops.ACT = old_act
+
+
+def _order_worker(rank, world, port, out_dir, tuning):
+    """1-rank group with E4T_FORCE_COMM=1: record when each gradient region's all-reduce is enqueued."""
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", E4T_FORCE_COMM="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.set_num_threads(2)
+    from e4t.trainer import E4TTrainer
+    _, _, n_unet, n_enc, text = _build()
+    tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long),
+                    device=torch.device("cpu"), tuning=tuning, max_grad_norm=1.0 if tuning else None)
+    assert tr._comm and tr.regions is not None
+    log, marks = [], []
+    orig = tr._reduce_region
+
+    def spy(key, force=False):
+        if key not in tr._done and (tr._armed or force):
+            log.append((key, bool(force), len(marks)))
+        return orig(key, force)
+    tr._reduce_region = spy
+    # marker: the backward of the ENCODER pass starts when the gradient of the mid-block output of that pass arrives
+    real_forward = n_unet.forward
+
+    def fwd(*a, **k):
+        out = real_forward(*a, **k)
+        if k.get("return_encoder_outputs") and torch.is_grad_enabled():
+            out["down_block_samples"][-1].register_hook(lambda g: marks.append("encoder_pass_backward_started"))
+        return out
+    n_unet.forward = fwd
+    b = _batch(0)
+    tr.train_step(b["pixels"], b["ids"], b["pidx"], noise=b["noise"], timesteps=b["t"], latents=b["latents"])
+    torch.save(dict(log=log, regions=tr.regions, numel=tr.flat.numel), os.path.join(out_dir, "order.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tuning", [False, True], ids=["pretrain", "tuning"])
+def test_gradient_regions_are_reduced_as_soon_as_they_are_final(tmp_path, tuning):
+    """SURVEY §8e bucket schedule: U (up blocks) is enqueued when the full-pass backward leaves the up blocks, H (E4T encoder)
+    before the encoder-pass UNet backward starts, D (mid/down, shared by both passes) last — none of them by the
+    post-backward sweep, in pre-training and in tuning (where every UNet parameter is in U / D)."""
+    mp.spawn(_order_worker, args=(1, _free_port(), str(tmp_path), tuning), nprocs=1, join=True)
+    r = torch.load(tmp_path / "order.pt")
+    keys = [k for k, _, _ in r["log"]]
+    assert keys == ["U", "H", "D"], r["log"]
+    assert not any(forced for _, forced, _ in r["log"]), r["log"]
+    by = {k: m for k, _, m in r["log"]}
+    assert by["U"] == 0 and by["H"] == 0 and by["D"] == 1, r["log"]       # U and H before the encoder-pass backward, D after
+    (h0, h1), (d0, d1), (u0, u1) = r["regions"]["H"], r["regions"]["D"], r["regions"]["U"]
+    assert h0 == 0 and h1 == d0 and d1 == u0 and u1 == r["numel"] and u1 > u0 > d0 > 0

@@ -1,0 +1,23 @@
+"""-m gpu: BASELINE.json configs[1] at B=1 — the FULL SD-1.4 UNet + ViT-H-14 E4T encoder + CLIP-L text encoder + AutoencoderKL
+encoder at 512 px — one training step on the HIP kernels vs the CPU fp32 oracle, with the autocast-calibrated tolerance of
+SURVEY.md §8(c) (tests/parity_step.py).  This is the reference's own full-size smoke (pretrain_e4t.py:595-654,
+e4t/encoder.py:171-296) turned into a parity test: VAE latents, the 13 encoder maps, the domain embedding, both losses and the
+gradient of every one of the 96 x 9 weight-offset tensors and of every E4T-head parameter."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_sd14_step_matches_oracle(hip_env):
+    import parity_step
+    rep = parity_step.run("full_sd14", torch.device("cuda:0"))
+    assert rep["n_bad"] == 0
+    assert rep["grads"]["count"] >= 96 * 2 + 5          # every weight-offset instance's two big matrices + the head
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_full_sd14.json"), "w") as fh:
+            json.dump(rep, fh, indent=1)

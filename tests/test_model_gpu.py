@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 def test_smoke_step_matches_oracle(hip_env):
     import smoke_step as smoke
     errs = smoke.run(torch.device("cuda:0"), verbose=False)
-    assert errs["loss_diff"] < 2e-2
+    assert errs["losses"] < 2e-2
 
 
 def test_native_vae_matches_torch(hip_env):
