@@ -54,10 +54,8 @@ def cpu_baseline_and_parity(model, threads, dev):
     nat = ps.native_leg(case, n, d, dev)
     del n
     torch.cuda.empty_cache()
-    cal = ps.oracle_leg(case, o, d, dev=dev, autocast=True)
+    rep, _ = ps.evaluate(case, o, d, nat, dev, verbose=False, strict=False)      # its CPU fp32 oracle run = the warm-up step
     torch.cuda.empty_cache()
-    ref = ps.oracle_leg(case, o, d)                                   # CPU fp32: the reference answer = the warm-up step
-    rep = ps.compare(case, nat, ref, cal, verbose=False, strict=False)
     par = dict(case=case.name, rule=rep["rule"], n_quantities=rep["n_quantities"], n_bad=rep["n_bad"], bad=rep["bad"])
     for kind, key in (("losses", "loss_rel"), ("enc_maps", "enc_maps_rel"), ("grads", "grad_rel"), ("other", "latents_embed_rel")):
         if kind in rep:

@@ -11,6 +11,18 @@ and every compared quantity q (13 encoder maps, VAE latents, losses, every train
 
     rel_l2(native q, oracle q)  <=  2 * rel_l2(autocast q, oracle q) + FLOOR          (losses: also <= 1e-2 relative)
 
+Two statistical refinements, both measured on the GPU before they were written (tools/parity_diag*.py, tools/shadow_ops.py):
+  * The E4T encoder has two LeakyReLU kinks (encoder.py:101-105,163-166).  An input element whose magnitude is below the
+    forward error (|x| ~ 1e-2 of typical) takes a different branch in two bf16 realisations; ONE such flip moves every
+    encoder gradient by ~1/sqrt(B * hid) in rel-L2: 6 % at B*hid = 256, and at the full size (1 x 1280) the measured 5 flips of
+    the native run against 0 of the autocast run are 13.7 % against 0.4 %.  Which elements flip is a lottery, not a
+    property of either implementation, so each leg is compared with an oracle run whose ambiguous kink elements
+    (|x_oracle| <= KINK_TOL x median |x|, and only those) take THAT leg's branch — a valid sub-gradient of the same
+    function; everything else about the oracle run is unchanged.  The report counts the aligned elements.
+  * "the stock bf16 error" is a random variable (tensors fed by a handful of tokens, e.g. the 2x2 mid block of the tiny UNet,
+    differ 3x between rocBLAS and oneDNN autocast runs): where a second realisation is cheap (`Case.cpu_calib`) the
+    calibration is the larger of the GPU and the CPU autocast runs.
+
 The autocast leg replaces the hand-picked 0.25 gradient bound of round 1: a gradient that is mostly rounding noise in a
 stock bf16 run may be that noisy here too, and nothing else may.  FLOOR (3e-3, ~one bf16 rounding of the quantity)
 only matters where the autocast run happens to be nearly exact.
@@ -25,6 +37,7 @@ from typing import Optional
 import torch
 
 FLOOR = 3e-3
+KINK_TOL = 5e-2
 
 TINY_VIT = dict(image_size=28, patch_size=14, width=128, layers=2, heads=2, mlp_ratio=4.0)
 WIDE_VIT = dict(image_size=224, patch_size=14, width=1280, layers=2, heads=16, mlp_ratio=4.0)      # ViT-H-14 width / heads / 257 tokens, 2 layers
@@ -51,6 +64,9 @@ class Case:
     vae_boc: tuple = (128, 256, 512, 512)
     class_id: int = 11
     seed: int = 0
+    cpu_calib: bool = True                  # second stock-bf16 realisation (autocast on the CPU); off for the full-size cases
+
+    align_kinks: bool = True                # compare each leg with the oracle run that takes its branch at ambiguous LeakyReLU inputs
 
 
 def cases():
@@ -63,10 +79,10 @@ def cases():
         # BASELINE configs[1] at B=1: full SD-1.4 UNet + ViT-H-14 encoder + CLIP-L text + AutoencoderKL encoder, 512 px
         "full_sd14": Case("full_sd14", dict(orc.SD14_UNET_CONFIG), boc=SD_BOC, vit_cfg=None,
                           text_cfg=dict(vocab_size=49409, hidden_size=768, num_layers=12, num_heads=12, intermediate_size=3072, max_len=77,
-                                        act="quick_gelu"), B=1, px=512, lat=64, with_vae=True, class_id=1125),
+                                        act="quick_gelu"), B=1, px=512, lat=64, with_vae=True, class_id=1125, cpu_calib=False),
         "full_sd21": Case("full_sd21", dict(orc.SD21_UNET_CONFIG), boc=SD_BOC, vit_cfg=None,
                           text_cfg=dict(vocab_size=49409, hidden_size=1024, num_layers=23, num_heads=16, intermediate_size=4096, max_len=77,
-                                        act="gelu"), B=1, px=768, lat=96, with_vae=True, class_id=1125, prediction_type="v_prediction"),
+                                        act="gelu"), B=1, px=768, lat=96, with_vae=True, class_id=1125, prediction_type="v_prediction", cpu_calib=False),
         # BASELINE configs[4]: the SD-2.x UNet config at its real widths (heads 5/10/20/20 = dh 64, ctx 1024, linear projections,
         # v-prediction) on 24x24 latents (T = 576 / 144 / 36 / 9: ragged attention and GEMM tiles), wide 2-layer ViT
         "sd2_real_width": Case("sd2_real_width", dict(orc.SD21_UNET_CONFIG, sample_size=24), boc=SD_BOC, vit_cfg=WIDE_VIT,
@@ -74,7 +90,7 @@ def cases():
         "tiny_sd2": Case("tiny_sd2", dict(tiny, attention_head_dim=(1, 2, 2, 2), use_linear_projection=True), prediction_type="v_prediction",
                          lat=24, px=96),
         # BASELINE configs[3]: tuning step, every UNet weight trains (3x3 conv wgrad through im2col + TN GEMM), real SD-1.4 widths
-        "tuning_real_width": Case("tuning_real_width", dict(orc.SD14_UNET_CONFIG, sample_size=16), boc=SD_BOC, vit_cfg=TINY_VIT,
+        "tuning_real_width": Case("tuning_real_width", dict(orc.SD14_UNET_CONFIG, sample_size=16), boc=SD_BOC, vit_cfg=WIDE_VIT,
                                   text_cfg=wtext(768, 12), B=2, px=64, lat=16, tuning=True, reg_lambda=0.1),
         "tuning_tiny": Case("tuning_tiny", tiny, tuning=True, reg_lambda=0.1, B=3),
         # --unfreeze_clip_vision: backward through the ViT tower at ViT-H width
@@ -185,8 +201,35 @@ def make_data(case: Case):
 
 
 # ---- the three legs ------------------------------------------------------------------------------------------------------------
-def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collect=True):
-    """fp32 on the CPU = the reference answer; autocast=True on `dev` = the calibration leg (on copies of the models)."""
+class _Kinks:
+    """Records the inputs of the encoder's two LeakyReLUs (call order: unet_feature_embedder.1, act) and, given another
+    leg's recorded inputs, makes the ambiguous elements take that leg's branch."""
+
+    def __init__(self, enc, follow=None):
+        self.seen, self.follow, self.aligned = [], follow, 0
+        self.handles = [m.register_forward_hook(self._hook) for m in (enc.unet_feature_embedder[1], enc.act)]
+
+    def _hook(self, mod, args, out):
+        x = args[0]
+        i = len(self.seen)
+        self.seen.append(x.detach().float().cpu().clone())
+        if self.follow is None:
+            return None
+        other = self.follow[i].to(x.device).reshape(x.shape)
+        amb = (x.detach().abs() <= KINK_TOL * x.detach().abs().median()) & (torch.sign(other) != torch.sign(x.detach()))
+        self.aligned += int(amb.sum())
+        pos = torch.where(amb, other > 0, x.detach() > 0)
+        return torch.where(pos, x, mod.negative_slope * x)
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+
+
+def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collect=True, follow_kinks=None):
+    """fp32 on the CPU = the reference answer; autocast=True on `dev` = the calibration leg (on copies of the models).
+    follow_kinks: another leg's recorded LeakyReLU inputs (see _Kinks).  Returns the results dict; ["_kinks"] holds this
+    leg's own recorded inputs, ["_aligned"] the number of elements that followed."""
     import e4t_oracle as orc
     if autocast or dev.type != "cpu":
         o = {k: (copy.deepcopy(v).to(dev) if v is not None else None) for k, v in o.items()}
@@ -198,6 +241,7 @@ def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collec
     acp = mv(orc.ddpm_alphas_cumprod())
     ctx_mgr = torch.autocast(dev.type, dtype=torch.bfloat16) if autocast else torch.autocast(dev.type, enabled=False)
     out = {}
+    kinks = _Kinks(enc, follow_kinks)
     with ctx_mgr:
         with torch.no_grad():
             class_embed = text.get_input_embeddings()(torch.tensor([case.class_id], device=dev))[0]
@@ -212,6 +256,7 @@ def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collec
                                             mv(d["noise"]), mv(d["t"]), emb, d["pidx"].tolist(), ctx0, class_embed, acp,
                                             reg_lambda=case.reg_lambda, prediction_type=case.prediction_type)
     loss.backward()
+    kinks.close()
     if not collect:
         return None
     out["loss_diff"], out["loss_reg"] = ld.detach().float(), lr_.detach().float()
@@ -224,7 +269,9 @@ def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collec
     for n, p in enc.named_parameters():
         if p.requires_grad:
             out[f"grad/e4t_encoder.{n}"] = p.grad.detach().float()
-    return {k: v.cpu() for k, v in out.items()}
+    out = {k: v.cpu() for k, v in out.items()}
+    out["_kinks"], out["_aligned"] = kinks.seen, kinks.aligned
+    return out
 
 
 def native_leg(case: Case, n, d, dev):
@@ -247,10 +294,16 @@ def native_leg(case: Case, n, d, dev):
         maps = n["unet"](noisy, mv(d["t"]), tr.ctx_for_e4t.expand(B, -1, -1), return_encoder_outputs=True)["down_block_samples"]
         for i, m in enumerate(maps):
             out[f"enc_map_{i:02d}"] = m.float()
-    got = {}
+    got, kinks = {}, []
     hook = n["enc"].register_forward_hook(lambda m, a, y: got.__setitem__("y", y.detach().float()))
-    loss, ld, lr_ = tr.losses(mv(d["pixels"]), latents, mv(d["noise"]), mv(d["t"]), mv(d["ids"]), mv(d["pidx"]))
+    real_lrelu = Fn.leaky_relu              # the encoder's only two calls (encoder.py forward): embedder LeakyReLU, then `act`
+    Fn.leaky_relu = lambda x: (kinks.append(x.detach().float().cpu().clone()), real_lrelu(x))[1]
+    try:
+        loss, ld, lr_ = tr.losses(mv(d["pixels"]), latents, mv(d["noise"]), mv(d["t"]), mv(d["ids"]), mv(d["pidx"]))
+    finally:
+        Fn.leaky_relu = real_lrelu
     hook.remove()
+    assert len(kinks) == 2, len(kinks)
     out["domain_embed"] = tr.class_embed[None, :] + tr.scale * got["y"]                       # pretrain_e4t.py:628
     Fn.set_inplace_param_grads(True)            # as E4TTrainer.train_step does
     try:
@@ -268,6 +321,7 @@ def native_leg(case: Case, n, d, dev):
     if case.tuning:
         from e4t import ops
         out["grad_norm"] = ops.backend().sumsq(tr.flat.grad).sqrt().detach().float().cpu()
+    out["_kinks"] = kinks
     tr.clip_grad_norm()
     tr.optimizer_step()
     tr.zero_grad()
@@ -277,25 +331,29 @@ def native_leg(case: Case, n, d, dev):
 
 
 # ---- comparison ----------------------------------------------------------------------------------------------------------------
-def compare(case: Case, nat, ref, cal, verbose=True, strict=True):
-    """-> report dict; raises AssertionError listing every quantity that breaks  err <= 2 * calib + FLOOR.
-    Gradients are judged per tensor when it has >= 256 elements, else pooled with the other small tensors of its block (down_blocks.i / mid_block / up_blocks.i / encoder sub-module)."""
+def compare(case: Case, nat, ref, cals, verbose=True, strict=True):
+    """nat: native results; ref: the oracle results `nat` is judged against; cals: [(stock-bf16 results, the oracle results
+    they are judged against), ...] — the calibration of a quantity is its largest error over `cals`.
+    -> report dict; raises AssertionError listing every quantity that breaks  err <= 2 * calib + FLOOR.
+    Gradients are judged per tensor when it has >= 256 elements, else pooled with the other small tensors of the same
+    model (the 1-element `v` of every weight-offset head, short bias vectors of the tiny configs)."""
     rows, small = [], {}
-    for k in ref:
+    calib = lambda f: max(f(c, r) for c, r in cals)
+    keys = [k for k in ref if not k.startswith("_")]
+    for k in keys:
         if k not in nat:
             continue
         if k.startswith("grad/") and ref[k].numel() < 256:
-            small.setdefault(".".join(k.split(".")[:3 if ("_blocks." in k or ".resblocks." in k) else 2]), []).append(k)
+            small.setdefault(k.split(".")[0], []).append(k)        # "grad/unet" / "grad/e4t_encoder"
             continue
-        rows.append((k, rel(nat[k], ref[k]), rel(cal[k], ref[k])))
+        rows.append((k, rel(nat[k], ref[k]), calib(lambda c, r: rel(c[k], r[k]))))
     for gname, ks in small.items():
         cat = lambda r: torch.cat([r[k].reshape(-1) for k in ks])
-        rows.append((gname + ".{small}", rel(cat(nat), cat(ref)), rel(cat(cal), cat(ref))))
+        rows.append((gname + ".{small}", rel(cat(nat), cat(ref)), calib(lambda c, r: rel(cat(c), cat(r)))))
     if "grad_norm" in nat:
-        gn = torch.sqrt(sum(v.double().pow(2).sum() for k, v in ref.items() if k.startswith("grad/")))
-        gc = torch.sqrt(sum(v.double().pow(2).sum() for k, v in cal.items() if k.startswith("grad/")))
-        rows.append(("grad_norm", abs(float(nat["grad_norm"]) - float(gn)) / float(gn), abs(float(gc) - float(gn)) / float(gn)))
-    missing = [k for k in ref if k not in nat]
+        gnorm = lambda r: float(torch.sqrt(sum(v.double().pow(2).sum() for k, v in r.items() if k.startswith("grad/"))))
+        rows.append(("grad_norm", abs(float(nat["grad_norm"]) - gnorm(ref)) / gnorm(ref), calib(lambda c, r: abs(gnorm(c) - gnorm(r)) / gnorm(r))))
+    missing = [k for k in keys if k not in nat]
     assert not missing, f"native leg did not produce {missing[:5]}"
     bad = []
     for k, e, c in rows:
@@ -305,10 +363,11 @@ def compare(case: Case, nat, ref, cal, verbose=True, strict=True):
         if not (e <= bound):
             bad.append((k, e, c))
     kinds = dict(enc_maps=[r for r in rows if r[0].startswith("enc_map")], losses=[r for r in rows if r[0].startswith("loss")],
-                 grads=[r for r in rows if r[0].startswith("grad")], other=[r for r in rows if r[0] in ("latents", "domain_embed", "grad_norm")])
+                 grads=[r for r in rows if r[0].startswith("grad/")], other=[r for r in rows if r[0] in ("latents", "domain_embed", "grad_norm")])
     worst = lambda rs: max(rs, key=lambda r: r[1]) if rs else None
     ratio = lambda rs: max(rs, key=lambda r: r[1] / (2 * r[2] + FLOOR)) if rs else None
-    rep = dict(case=case.name, n_quantities=len(rows), n_bad=len(bad))
+    rep = dict(case=case.name, n_quantities=len(rows), n_bad=len(bad), calibration_legs=len(cals),
+               kink_elements_aligned=dict(native=ref.get("_aligned", 0), autocast=[r.get("_aligned", 0) for _, r in cals]))
     for kind, rs in kinds.items():
         if rs:
             w, q = worst(rs), ratio(rs)
@@ -320,6 +379,8 @@ def compare(case: Case, nat, ref, cal, verbose=True, strict=True):
                 w, q = rep[kind]["worst"], rep[kind]["tightest"]
                 print(f"  parity[{case.name}] {kind:<9s} n={rep[kind]['count']:<4d} worst {w['name']}: native {w['native']:.3e} (autocast {w['autocast']:.3e});"
                       f" tightest {q['name']}: {q['used']:.2f} of its bound")
+        if case.align_kinks:
+            print(f"  parity[{case.name}] LeakyReLU kink elements aligned: {rep['kink_elements_aligned']}")
         for k, e, c in bad[:20]:
             print(f"  parity[{case.name}] OVER  {k}: native {e:.3e} > 2 x autocast {c:.3e} + {FLOOR}")
     rep["bad"] = [dict(name=k, native=e, autocast=c) for k, e, c in bad[:16]]
@@ -328,8 +389,27 @@ def compare(case: Case, nat, ref, cal, verbose=True, strict=True):
     return rep
 
 
-def run(case_name, dev, calib_dev=None, verbose=True):
-    """Build the pair, run the three legs, compare.  Returns the report (also carries wall times)."""
+def evaluate(case: Case, o, d, nat, dev, verbose=True, strict=True, timings=None):
+    """Run the oracle (CPU fp32) and the stock-autocast calibration leg(s) for `nat` and compare.  -> (report, oracle results)"""
+    t = time.perf_counter()
+    ref = oracle_leg(case, o, d)                                               # the reference answer
+    t_ref = time.perf_counter() - t
+    legs = [oracle_leg(case, o, d, dev=dev, autocast=True)]                    # stock bf16 on the GPU (rocBLAS / MIOpen)
+    if case.cpu_calib and dev.type != "cpu":
+        legs.append(oracle_leg(case, o, d, dev=torch.device("cpu"), autocast=True))      # ... and on the CPU (oneDNN)
+    if case.align_kinks:
+        ref_nat = oracle_leg(case, o, d, follow_kinks=nat["_kinks"])
+        cals = [(c, oracle_leg(case, o, d, follow_kinks=c["_kinks"])) for c in legs]
+    else:
+        ref_nat, cals = ref, [(c, ref) for c in legs]
+    if timings is not None:
+        timings["oracle_fp32_cpu"] = t_ref
+        timings["calibration_and_aligned_runs"] = time.perf_counter() - t - t_ref
+    return compare(case, nat, ref_nat, cals, verbose=verbose, strict=strict), ref
+
+
+def run(case_name, dev, verbose=True):
+    """Build the pair, run the legs, compare.  Returns the report (also carries wall times)."""
     case = cases()[case_name]
     t0 = time.perf_counter()
     o = build_oracle(case)
@@ -338,10 +418,7 @@ def run(case_name, dev, calib_dev=None, verbose=True):
     t1 = time.perf_counter()
     nat = native_leg(case, n, d, dev)
     t2 = time.perf_counter()
-    ref = oracle_leg(case, o, d)
-    t3 = time.perf_counter()
-    cal = oracle_leg(case, o, d, dev=calib_dev or dev, autocast=True)
-    t4 = time.perf_counter()
-    rep = compare(case, nat, ref, cal, verbose=verbose)
-    rep["seconds"] = dict(build=t1 - t0, native=t2 - t1, oracle_fp32_cpu=t3 - t2, autocast=t4 - t3)
+    sec = dict(build=t1 - t0, native=t2 - t1)
+    rep, _ = evaluate(case, o, d, nat, dev, verbose=verbose, timings=sec)
+    rep["seconds"] = sec
     return rep
