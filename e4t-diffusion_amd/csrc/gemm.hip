@@ -387,6 +387,18 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int GM) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// The K-loop barrier of the DMA kernels.  After it, some wave starts the LDS-DMA of a new tile INTO THE STAGE EVERY WAVE READ IN
+// THE ITERATION BEFORE, so every wave's fragment reads of that stage must have COMPLETED, not merely been issued, when it
+// arrives.  s_barrier alone does not order that: the compiler sinks the last k-step's MFMA — and the lgkmcnt wait in front of
+// it — below the barrier (gfx950 needs no counter drain at s_barrier), leaving ds_reads in flight across it.  Measured: with
+// three 4-wave workgroups per CU (64 x 64 tile, 3 stages) 0-2 of 1280 output tiles per launch came out wrong, not
+// reproducibly — a DMA that hit in L2 landed before a ds_read queued behind the other workgroups' LDS traffic had executed.
+// Draining lgkmcnt first closes the window for every stage count.
+__device__ __forceinline__ void loop_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 template <int BM, int BN, int WGM, int WGN, int MODE, int NSTAGE>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   constexpr int NA = BM / 8 / NW, NB = (BN / 8 + NW - 1) / NW;   // 1-KiB DMA pieces (8 rows) per wave per K-tile (B: last wave may own fewer)
   constexpr int LOOK = NSTAGE - 1;                    // K-tiles in flight
   constexpr int TILE = (BM + BN) * BK;          // elements per LDS buffer
-  static_assert(NA >= 1 && NB >= 1 && (NW == 4 || NW == 8) && (NSTAGE == 2 || NSTAGE == 3), "bad tile configuration");
+  static_assert(NA >= 1 && NB >= 1 && (NW == 4 || NW == 8) && (NSTAGE >= 2 && NSTAGE <= 4), "bad tile configuration");
   static_assert(NSTAGE == 2 || (BN / 8) % NW == 0, "counted vmcnt needs the same piece count in every wave");
 
   __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * TILE];
@@ -571,10 +583,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   auto body = [&](auto CURc, int kt) {
     constexpr int CUR = decltype(CURc)::value;
     constexpr int NXT = (CUR + LOOK) % NSTAGE;
-    // this wave's pieces of tile kt have landed once at most the pieces of the (LOOK-1) newer tiles are outstanding
-    if (LOOK == 2 && kt + 1 < kt_end) wait_vmcnt<NA + NB>();
+    // this wave's pieces of tile kt have landed once at most the pieces of the newer tiles in flight (LOOK-1 of them, fewer
+    // at the end of the K range) are outstanding: a counted wait, the loads of the deeper stages keep flying
+    if (LOOK >= 3 && kt + 2 < kt_end) wait_vmcnt<2 * (NA + NB)>();
+    else if (LOOK >= 2 && kt + 1 < kt_end) wait_vmcnt<NA + NB>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                      // ... everyone's have; and everyone finished reading slot NXT
+    loop_barrier();                                    // ... everyone's have; and everyone finished reading slot NXT
     const bf16_t* st = smem + CUR * TILE;
     bf16x8 af[2][FM], bfr[2][FN];
 #pragma unroll
@@ -603,10 +617,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
     for (; kt + NSTAGE <= kt_end; kt += NSTAGE) {
       body(std::integral_constant<int, 0>{}, kt);
       body(std::integral_constant<int, 1>{}, kt + 1);
-      if (NSTAGE == 3) body(std::integral_constant<int, 2 % NSTAGE>{}, kt + 2);
+      if (NSTAGE >= 3) body(std::integral_constant<int, 2 % NSTAGE>{}, kt + 2);
+      if (NSTAGE >= 4) body(std::integral_constant<int, 3 % NSTAGE>{}, kt + 3);
     }
     if (kt < kt_end) { body(std::integral_constant<int, 0>{}, kt); ++kt; }
     if (kt < kt_end) { body(std::integral_constant<int, 1>{}, kt); ++kt; }
+    if (NSTAGE >= 4 && kt < kt_end) { body(std::integral_constant<int, 2 % NSTAGE>{}, kt); ++kt; }
   }
   __syncthreads();   // all fragment reads done before the epilogue reuses the LDS
   write_tile<WM, WN, FM, FN>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
@@ -1223,7 +1239,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
   auto body = [&](auto CURc, int kt) {
     constexpr int CUR = decltype(CURc)::value;
     wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    loop_barrier();
     const bf16_t* st = smem + CUR * TILE;
     bf16x8 af[2], bfr[2][FN];
     af[0] = tr_frag(st + a_off, st + a_off + 512);
@@ -1275,6 +1291,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p, int nz) 
 int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int splitk_req, int batch, hipStream_t st) {
   const int nkt = cdiv(p.K, BK);
   // --- tile selection: fill >= ~1.5 waves of the 256 CUs with 128x128 tiles, else drop to 64x64 ---
+  int stages = 2;                         // LDS stages of the 64 / 128 / 160 DMA kernels; a hint of 3128 / 4160 / ... forces 3 or 4
+  if (tile_hint >= 3000 && tile_hint < 5000) { stages = tile_hint / 1000; tile_hint %= 1000; }
   int tile = tile_hint;
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
@@ -1369,9 +1387,13 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     const char* sym = !(use_dma && buf_ok) ? "gemm_kernel" : tile == 512 ? (conv ? "gemm_pp_kernel<1>" : "gemm_pp_kernel<0>")
                       : tile == 640 ? (conv ? "gemm_pt_kernel<1>" : "gemm_pt_kernel<0>")
                       : tile == 256 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3>")
-                      : tile == 160 ? (conv ? "gemm_dma_kernel<128, 160, 4, 1, 1, 2>" : "gemm_dma_kernel<128, 160, 4, 1, 0, 2>")
-                      : tile == 128 ? (conv ? "gemm_dma_kernel<128, 128, 4, 2, 1, 2>" : "gemm_dma_kernel<128, 128, 4, 2, 0, 2>")
-                      : (conv ? "gemm_dma_kernel<64, 64, 2, 2, 1, 2>" : "gemm_dma_kernel<64, 64, 2, 2, 0, 2>");
+                      : nullptr;
+    char symbuf[64];
+    if (!sym) {
+      snprintf(symbuf, sizeof(symbuf), "gemm_dma_kernel<%d, %d, %d, %d, %d, %d>", tile == 64 ? 64 : 128, tile == 160 ? 160 : tile, tile == 64 ? 2 : 4,
+               tile == 160 ? 1 : 2, conv ? 1 : 0, stages);
+      sym = symbuf;
+    }
     if (conv) E4T_LOG_LAUNCH("%s|conv mode%d %dx%d->%dx%d Cin%d Cout%d M%d splitk%d|%.0f|%.0f", sym, p.mode, p.Hin, p.Win, p.Hout, p.Wout, p.Cin, p.N,
                              p.M, splitk, by, 2.0 * p.M * p.N * (double)p.K);
     else E4T_LOG_LAUNCH("%s|gemm M%d N%d K%d batch%d splitk%d flags%d|%.0f|%.0f", sym, p.M, p.N, p.K, batch, splitk, p.flags, by,
@@ -1392,18 +1414,25 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 0, 3>), grid, block, 0, st, p);
-    } else if (tile == 160) {
-      if (conv) hipLaunchKernelGGL((gemm_dma_kernel<128, 160, 4, 1, 1, 2>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((gemm_dma_kernel<128, 160, 4, 1, 0, 2>), grid, block, 0, st, p);
-    } else if (tile == 128) {
-      // 8 waves (wave tile 32x64): ~4 waves/SIMD at 2 workgroups/CU hide the DMA/LDS latency that the 4-wave
-      // version of the same tile exposed (measured +5..18 % on every E4T shape, 8192^3: 956 -> 980 TF)
-      block = dim3(512);
-      if (conv) hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 4, 2, 1, 2>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 4, 2, 0, 2>), grid, block, 0, st, p);
     } else {
-      if (conv) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 1, 2>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 0, 2>), grid, block, 0, st, p);
+      // 64 / 128 / 160 tiles: 2 LDS stages and 2 workgroups per CU by default; 3 or 4 stages (one workgroup per CU, 2-3 K-tiles
+      // in flight) when the grid cannot give a CU two workgroups anyway — see the stage choice above
+#define E4T_LAUNCH_DMA(BM_, BN_, WGM_, WGN_, NT_)                                                                         \
+  do {                                                                                                                   \
+    block = dim3(NT_);                                                                                                   \
+    if (stages == 4) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 4>), grid, block, 0, st, p); \
+                       else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 4>), grid, block, 0, st, p); }    \
+    else if (stages == 3) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 3>), grid, block, 0, st, p); \
+                            else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 3>), grid, block, 0, st, p); } \
+    else { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 2>), grid, block, 0, st, p);            \
+           else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 2>), grid, block, 0, st, p); }               \
+  } while (0)
+      // 128x128: 8 waves (wave tile 32x64): ~4 waves/SIMD at 2 workgroups/CU hide the DMA/LDS latency that the 4-wave
+      // version of the same tile exposed (measured +5..18 % on every E4T shape, 8192^3: 956 -> 980 TF)
+      if (tile == 160) E4T_LAUNCH_DMA(128, 160, 4, 1, 256);
+      else if (tile == 128) E4T_LAUNCH_DMA(128, 128, 4, 2, 512);
+      else E4T_LAUNCH_DMA(64, 64, 2, 2, 256);
+#undef E4T_LAUNCH_DMA
     }
   } else if (tile == 128) {
     if (conv) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 1>), grid, block, 0, st, p);

@@ -406,7 +406,40 @@ def check_image_prep(hip, emu, dev):
     return res
 
 
+def check_gemm_races(hip, emu, dev):
+    """The DMA GEMM kernels hand an LDS stage back to the loader right after the K-loop barrier.  Until round 2 that barrier
+    did not wait for the fragment reads of the stage to complete (gemm.hip, loop_barrier): with several workgroups per CU a
+    tile in a thousand came out wrong, not reproducibly.  The kernels are deterministic, so ANY difference between
+    repeated launches — and between the 2 / 3 / 4-stage variants, which accumulate in the same order — is a race.
+    Grids of several waves, 2-5 workgroups per CU, operands larger than one XCD's L2."""
+    out = []
+    g = gen(400, dev)
+    for M, N, K in [(4096, 1280, 320), (8192, 1280, 512), (16384, 640, 640)]:
+        a, w = rnd(g, M, K, dev=dev), rnd(g, N, K, dev=dev)
+        want = emu.gemm(a, w)
+        ref = hip.gemm(a, w, tile=128)
+        out.append((f"race-check reference {M}x{N}x{K}", rel(ref, want), TOL1))
+        for code in (64, 3064, 4064, 128, 3128, 4128, 160, 3160, 4160):
+            if code % 1000 == 160 and N % 160:
+                continue
+            differing = 0
+            for _ in range(12):
+                differing += int((hip.gemm(a, w, tile=code) != ref).sum() > 0)
+            out.append((f"gemm {M}x{N}x{K} tile code {code}: launches (of 12) differing from the reference", float(differing), 0.0))
+    x, w = rnd(g, 16 * 32 * 32, 640, dev=dev), rnd(g, 640, 9 * 640, dev=dev)
+    ref = hip.conv3x3(x, w, 16, 32, 32, 32, 32, CONV_S1, tile=128)
+    for code in (128, 3128, 160, 4160, 64, 3064):
+        differing = sum(int((hip.conv3x3(x, w, 16, 32, 32, 32, 32, CONV_S1, tile=code) != ref).sum() > 0) for _ in range(6))
+        out.append((f"conv 32x32 640->640 tile code {code}: launches (of 6) differing", float(differing), 0.0))
+    dy, xx = rnd(g, 16384, 640, dev=dev), rnd(g, 16384, 1280, dev=dev)
+    ref = hip.gemm_tn(dy, xx)
+    differing = sum(int((hip.gemm_tn(dy, xx) != ref).sum() > 0) for _ in range(12))
+    out.append(("gemm_tn 640x1280 K=16384: launches (of 12) differing", float(differing), 0.0))
+    return out
+
+
 def all_checks(hip, emu, dev, ops_mod):
+    yield "gemm_races", lambda: check_gemm_races(hip, emu, dev)
     yield "probe", lambda: check_probe(hip, emu, dev)
     yield "gemm", lambda: check_gemm(hip, emu, dev)
     yield "conv", lambda: check_conv(hip, emu, dev)

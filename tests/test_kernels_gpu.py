@@ -5,7 +5,7 @@ import kernel_checks as kc
 
 pytestmark = pytest.mark.gpu
 
-FAMILIES = ["probe", "gemm", "conv", "attention", "norms", "streaming", "wo", "image_prep"]
+FAMILIES = ["probe", "gemm", "gemm_races", "conv", "attention", "norms", "streaming", "wo", "image_prep"]
 
 
 @pytest.mark.parametrize("family", FAMILIES)
