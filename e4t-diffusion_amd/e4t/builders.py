@@ -17,6 +17,10 @@ CLIP_TEXT_L = dict(vocab_size=49408, hidden_size=768, num_layers=12, num_heads=1
 CLIP_TEXT_H = dict(vocab_size=49408, hidden_size=1024, num_layers=23, num_heads=16, intermediate_size=4096, max_len=77, act="gelu")
 TEXT_CONFIGS = {"sd14": CLIP_TEXT_L, "sd21": CLIP_TEXT_H}
 RESOLUTION = {"sd14": 512, "sd21": 768}
+# a 4-level toy of the same topology: the scripts' set-up code is exercised with it on machines without a GPU (tests/test_cli_setup.py)
+UNET_CONFIGS["tiny-test"] = dict(SD_UNET_BASE, sample_size=16, block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, attention_head_dim=2)
+TEXT_CONFIGS["tiny-test"] = dict(vocab_size=100, hidden_size=64, num_layers=2, num_heads=2, intermediate_size=128, max_len=9, act="quick_gelu")
+RESOLUTION["tiny-test"] = 64
 
 
 def build_models(dev, model="sd14", seed=0, vocab_size=None, freeze_clip_vision=True):
@@ -32,8 +36,9 @@ def build_models(dev, model="sd14", seed=0, vocab_size=None, freeze_clip_vision=
         tcfg["vocab_size"] = vocab_size
     with torch.device(dev):
         unet = UNet2DConditionModel(**ucfg)
-        enc = E4TEncoder(word_embedding_dim=tcfg["hidden_size"], block_out_channels=ucfg["block_out_channels"], arch="ViT-H-14",
-                         freeze_clip_vision=freeze_clip_vision)
+        tiny = model == "tiny-test"
+        enc = E4TEncoder(word_embedding_dim=tcfg["hidden_size"], block_out_channels=ucfg["block_out_channels"],
+                         arch="ViT-tiny-test" if tiny else "ViT-H-14", freeze_clip_vision=freeze_clip_vision, **(dict(n_odd_layers=3) if tiny else {}))
         text = CLIPTextModel(**tcfg).requires_grad_(False)      # fp32 master weights; bf16 compute copies are made once
-        vae = VAEEncoder().requires_grad_(False)
+        vae = VAEEncoder(**(dict(block_out_channels=(64, 64)) if tiny else {})).requires_grad_(False)
     return unet, enc, text, vae

@@ -1,9 +1,8 @@
-"""Stock-PyTorch twins of the frozen components around the UNet: the CLIP text encoder, the
-AutoencoderKL encoder (#15) and decoder.  They define the module trees / parameter names of the HF checkpoints
-(CLIPTextModel, AutoencoderKL.encoder / .decoder / quant convs) so real weights load by key, and they are the fp32 parity
-references of the kernel-driven subclasses in ``text.py`` and ``vae.py`` (tests/test_model_gpu.py, test_vae_host_logic.py,
-test_text_host_logic.py).  The training step and the sampling pipeline run the subclasses, not these forward()s; the one
-exception is a *trainable* text encoder (never the case in the reference's scripts), which ``text.py`` hands to this class.
+"""Module TREES (parameter containers, no arithmetic) of the components around the UNet: the CLIP text encoder (SURVEY.md §2
+#8), the AutoencoderKL encoder (#15) and decoder.  They fix the parameter names / shapes of the HF / diffusers checkpoints
+(CLIPTextModel, AutoencoderKL.encoder / .decoder / quant convs) so that real weights load by key; the kernel-driven classes
+in ``text.py`` and ``vae.py`` derive from them and add the forward passes.  Nothing here computes: the stock-torch
+forward passes of the same trees, used as fp32 parity references, live with the tests (tests/torch_twins.py).
 
 CLIPTextModel accepts ``inputs_embeds`` like the reference's patched class (e4t/models/modeling_clip.py:9-82) — the
 installed transformers 5.x no longer has the internals that file monkey-patches, so an equivalent is needed anyway.
@@ -11,7 +10,6 @@ installed transformers 5.x no longer has the internals that file monkey-patches,
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 CLIP_TEXT_L = dict(vocab_size=49409, hidden_size=768, num_layers=12, num_heads=12, intermediate_size=3072, max_len=77, act="quick_gelu")
@@ -24,22 +22,11 @@ class _SelfAttn(nn.Module):
         self.heads = heads
         self.q_proj, self.k_proj, self.v_proj, self.out_proj = (nn.Linear(w, w) for _ in range(4))
 
-    def forward(self, x):
-        b, s, w = x.shape
-        sp = lambda t: t.view(b, s, self.heads, w // self.heads).transpose(1, 2)
-        o = F.scaled_dot_product_attention(sp(self.q_proj(x)), sp(self.k_proj(x)), sp(self.v_proj(x)), is_causal=True)
-        return self.out_proj(o.transpose(1, 2).reshape(b, s, w))
-
 
 class _Mlp(nn.Module):
     def __init__(self, w, inter, act):
         super().__init__()
         self.fc1, self.fc2, self.act = nn.Linear(w, inter), nn.Linear(inter, w), act
-
-    def forward(self, x):
-        h = self.fc1(x)
-        h = h * torch.sigmoid(1.702 * h) if self.act == "quick_gelu" else F.gelu(h)
-        return self.fc2(h)
 
 
 class _Layer(nn.Module):
@@ -49,10 +36,6 @@ class _Layer(nn.Module):
         self.layer_norm1 = nn.LayerNorm(w)
         self.mlp = _Mlp(w, inter, act)
         self.layer_norm2 = nn.LayerNorm(w)
-
-    def forward(self, x):
-        x = x + self.self_attn(self.layer_norm1(x))
-        return x + self.mlp(self.layer_norm2(x))
 
 
 class _Embeddings(nn.Module):
@@ -111,14 +94,7 @@ class CLIPTextModel(nn.Module):
         return new
 
     def forward(self, input_ids=None, inputs_embeds=None):
-        tm = self.text_model
-        if inputs_embeds is None:
-            inputs_embeds = tm.embeddings.token_embedding(input_ids)
-        s = inputs_embeds.shape[1]
-        x = inputs_embeds + tm.embeddings.position_embedding.weight[:s]
-        for l in tm.encoder.layers:
-            x = l(x)
-        return (tm.final_layer_norm(x),)
+        raise NotImplementedError("parameter tree only: use e4t.text.CLIPTextModel (HIP kernels)")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -131,19 +107,11 @@ class _VRes(nn.Module):
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
 
-    def forward(self, x):
-        h = self.conv1(F.silu(self.norm1(x)))
-        h = self.conv2(F.silu(self.norm2(h)))
-        return (x if self.conv_shortcut is None else self.conv_shortcut(x)) + h
-
 
 class _VDown(nn.Module):
     def __init__(self, c):
         super().__init__()
         self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
-
-    def forward(self, x):
-        return self.conv(F.pad(x, (0, 1, 0, 1)))
 
 
 class _VDownBlock(nn.Module):
@@ -152,11 +120,6 @@ class _VDownBlock(nn.Module):
         self.resnets = nn.ModuleList([_VRes(cin, cout), _VRes(cout, cout)])
         self.downsamplers = nn.ModuleList([_VDown(cout)]) if down else None
 
-    def forward(self, x):
-        for r in self.resnets:
-            x = r(x)
-        return self.downsamplers[0](x) if self.downsamplers is not None else x
-
 
 class _VAttn(nn.Module):
     def __init__(self, c):
@@ -164,21 +127,12 @@ class _VAttn(nn.Module):
         self.group_norm = nn.GroupNorm(32, c, eps=1e-6)
         self.query, self.key, self.value, self.proj_attn = (nn.Linear(c, c) for _ in range(4))
 
-    def forward(self, x):
-        b, c, h, w = x.shape
-        t = self.group_norm(x).view(b, c, h * w).transpose(1, 2)
-        o = F.scaled_dot_product_attention(self.query(t)[:, None], self.key(t)[:, None], self.value(t)[:, None])[:, 0]
-        return self.proj_attn(o).transpose(1, 2).reshape(b, c, h, w) + x
-
 
 class _VMid(nn.Module):
     def __init__(self, c):
         super().__init__()
         self.resnets = nn.ModuleList([_VRes(c, c), _VRes(c, c)])
         self.attentions = nn.ModuleList([_VAttn(c)])
-
-    def forward(self, x):
-        return self.resnets[1](self.attentions[0](self.resnets[0](x)))
 
 
 class _VEncoder(nn.Module):
@@ -194,26 +148,15 @@ class _VEncoder(nn.Module):
         self.conv_norm_out = nn.GroupNorm(32, c, eps=1e-6)
         self.conv_out = nn.Conv2d(c, 2 * latent, 3, padding=1)
 
-    def forward(self, x):
-        x = self.conv_in(x)
-        for b in self.down_blocks:
-            x = b(x)
-        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
-
 
 class VAEEncoder(nn.Module):
-    """AutoencoderKL.encode(x).latent_dist.sample() * scaling_factor  (pretrain_e4t.py:598-599)."""
+    """Parameter tree of AutoencoderKL.encode(x).latent_dist.sample() * scaling_factor  (pretrain_e4t.py:598-599)."""
 
     def __init__(self, block_out_channels=(128, 256, 512, 512), latent_channels=4, scaling_factor=0.18215):
         super().__init__()
         self.scaling_factor = scaling_factor
         self.encoder = _VEncoder(tuple(block_out_channels), latent_channels)
         self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
-
-    @torch.no_grad()
-    def encode_sample(self, x, eps):
-        mean, logvar = self.quant_conv(self.encoder(x)).float().chunk(2, dim=1)
-        return (mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * eps) * self.scaling_factor
 
 
 # ------------------------------------------------------------------------------------------------
@@ -222,20 +165,12 @@ class _VUp(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
-    def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
-
 
 class _VUpBlock(nn.Module):
     def __init__(self, cin, cout, n, up):
         super().__init__()
         self.resnets = nn.ModuleList([_VRes(cin if j == 0 else cout, cout) for j in range(n)])
         self.upsamplers = nn.ModuleList([_VUp(cout)]) if up else None
-
-    def forward(self, x):
-        for r in self.resnets:
-            x = r(x)
-        return self.upsamplers[0](x) if self.upsamplers is not None else x
 
 
 class _VDecoder(nn.Module):
@@ -252,15 +187,9 @@ class _VDecoder(nn.Module):
         self.conv_norm_out = nn.GroupNorm(32, c, eps=1e-6)
         self.conv_out = nn.Conv2d(c, out_channels, 3, padding=1)
 
-    def forward(self, z):
-        x = self.mid_block(self.conv_in(z))
-        for b in self.up_blocks:
-            x = b(x)
-        return self.conv_out(F.silu(self.conv_norm_out(x)))
-
 
 class VAEDecoder(nn.Module):
-    """AutoencoderKL.decode(latents / scaling_factor).sample and the pipeline's decode_latents
+    """Parameter tree of AutoencoderKL.decode(latents / scaling_factor).sample and the pipeline's decode_latents
     (pipeline_stable_diffusion_e4t.py:226,237); key names of the diffusers checkpoint (post_quant_conv, decoder.*)."""
 
     def __init__(self, block_out_channels=(128, 256, 512, 512), latent_channels=4, out_channels=3, layers_per_block=2,
@@ -270,13 +199,3 @@ class VAEDecoder(nn.Module):
         self.block_out_channels = tuple(block_out_channels)
         self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
         self.decoder = _VDecoder(tuple(block_out_channels), latent_channels, out_channels, layers_per_block)
-
-    @torch.no_grad()
-    def decode(self, latents):
-        w = self.post_quant_conv.weight
-        return self.decoder(self.post_quant_conv((latents / self.scaling_factor).to(w.dtype)))
-
-    @torch.no_grad()
-    def decode_latents(self, latents):
-        """-> float32 [B, H, W, 3] in [0, 1]"""
-        return (self.decode(latents).float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous()

@@ -2,11 +2,12 @@
 e4t/models/modeling_clip.py:9-82 patches transformers' CLIPTextModel so the E4T domain embedding can be written into the
 token embeddings; pretrain_e4t.py:616,630-634 run it between the two UNet passes, forward + gradient w.r.t. the embeddings).
 
-Same module tree / parameter names as the stock-torch twin in ``frozen.py`` (= the HF checkpoint keys), so weights load by
-key into either.  The weights are frozen in both reference scripts; the native path therefore builds a fused q|k|v weight
-per layer once and propagates only dX: LayerNorm (residual gradient folded in) -> one (tokens x 3w) GEMM -> causal fused
-attention -> out-proj GEMM with the residual in its epilogue -> LayerNorm -> fc1 -> quick_gelu / gelu -> fc2 (+ residual).
-A trainable text encoder falls back to the torch twin (never used by the reference)."""
+Module tree / parameter names from ``checkpoint_trees.py`` (= the HF checkpoint keys), so real weights load by key.  Frozen weights (both reference scripts by default): a fused q|k|v weight per layer is built once and only dX
+is propagated: LayerNorm (residual gradient folded in) -> one (tokens x 3w) GEMM -> causal fused attention -> out-proj GEMM with
+the residual in its epilogue -> LayerNorm -> fc1 -> quick_gelu / gelu -> fc2 (+ residual).  Trainable weights
+(tuning_e4t.py --train_text_encoder, :145-146): the same kernels; the fused q|k|v weight is re-assembled every forward
+as a differentiable torch.cat of the three parameters, so the TN weight-gradient GEMM's result is split back onto them by
+autograd, and the LayerNorm / bias gradients come from the kernels' parameter-gradient outputs.  There is no other path."""
 from __future__ import annotations
 
 import torch
@@ -14,34 +15,41 @@ from torch import nn
 
 from . import functional as Fn
 from . import ops
-from .frozen import CLIPTextModel as _TorchCLIPTextModel
+from .checkpoint_trees import CLIPTextModel as _CLIPTextTree
 
 
-class CLIPTextModel(_TorchCLIPTextModel):
+class CLIPTextModel(_CLIPTextTree):
     def __init__(self, **cfg):
         super().__init__(**cfg)
         self._fused = None
 
-    def _prepare(self):
-        """Per layer: fused q|k|v weight + bias (frozen copies) and the PreparedLinear handles of every projection."""
+    def _prepare(self, trainable):
+        """Per layer: fused q|k|v weight + bias and the PreparedLinear handles of every projection.  Frozen: detached copies made
+        once (re-made when a checkpoint load or resize replaced / rewrote the parameters).  Trainable: a differentiable cat,
+        every forward (the bf16 compute copy has to be re-cast after each optimiser step anyway)."""
         layers = self.text_model.encoder.layers
-        key = tuple(l.self_attn.q_proj.weight.data_ptr() for l in layers)
-        if self._fused is not None and self._fused[0] == key:
-            return self._fused[1]
+        if not trainable:
+            key = tuple((l.self_attn.q_proj.weight.data_ptr(), l.self_attn.q_proj.weight._version, l.self_attn.v_proj.weight._version) for l in layers)
+            if self._fused is not None and self._fused[0] == key:
+                return self._fused[1]
         out = []
-        for l in layers:
+        for i, l in enumerate(layers):
             a = l.self_attn
-            w = nn.Parameter(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0).detach(), requires_grad=False)
-            b = nn.Parameter(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], dim=0).detach(), requires_grad=False)
-            out.append(dict(wqkv=w, bqkv=b, pqkv=Fn.PreparedLinear(w), pout=Fn.PreparedLinear(a.out_proj.weight),
-                            pfc1=Fn.PreparedLinear(l.mlp.fc1.weight), pfc2=Fn.PreparedLinear(l.mlp.fc2.weight)))
-        self._fused = (key, out)
+            w = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], dim=0)
+            b = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], dim=0)
+            if not trainable:
+                w, b = nn.Parameter(w.detach(), requires_grad=False), nn.Parameter(b.detach(), requires_grad=False)
+            keep = self._fused[1][i] if (trainable and self._fused is not None and len(self._fused[1]) == len(layers)) else None
+            out.append(dict(wqkv=w, bqkv=b, pqkv=Fn.PreparedLinear(w),
+                            pout=keep["pout"] if keep else Fn.PreparedLinear(a.out_proj.weight),
+                            pfc1=keep["pfc1"] if keep else Fn.PreparedLinear(l.mlp.fc1.weight),
+                            pfc2=keep["pfc2"] if keep else Fn.PreparedLinear(l.mlp.fc2.weight)))
+        self._fused = (None if trainable else key, out)
         return out
 
     def forward(self, input_ids=None, inputs_embeds=None):
         tm = self.text_model
-        if any(p.requires_grad for p in tm.encoder.parameters()):
-            return super().forward(input_ids=input_ids, inputs_embeds=inputs_embeds)
+        trainable = torch.is_grad_enabled() and any(p.requires_grad for p in tm.encoder.parameters())
         if inputs_embeds is None:
             inputs_embeds = tm.embeddings.token_embedding(input_ids)
         B, S, W = inputs_embeds.shape
@@ -50,7 +58,7 @@ class CLIPTextModel(_TorchCLIPTextModel):
         DH = W // H
         act = Fn.quick_gelu if cfg["act"] == "quick_gelu" else Fn.gelu
         x = (inputs_embeds + tm.embeddings.position_embedding.weight[:S]).to(ops.ACT).reshape(B * S, W).contiguous()
-        for l, f in zip(tm.encoder.layers, self._prepare()):
+        for l, f in zip(tm.encoder.layers, self._prepare(trainable)):
             n, xs = Fn.layer_norm_skip(x, l.layer_norm1.weight, l.layer_norm1.bias, l.layer_norm1.eps)
             qkv = Fn.linear(n, f["wqkv"], f["bqkv"], f["pqkv"])
             a = Fn.attention(qkv, None, B, H, S, S, DH, DH ** -0.5, causal=True)

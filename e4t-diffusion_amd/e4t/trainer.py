@@ -34,13 +34,16 @@ def ddpm_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012, device=None)
     return torch.cumprod(1.0 - betas, dim=0)
 
 
-def select_trainable(unet, encoder, tuning=False):
+def select_trainable(unet, encoder, tuning=False, text_encoder=None):
     """pre-training (pretrain_e4t.py:274-278): encoder params with requires_grad + UNet params whose name contains "wo";
     every other UNet parameter is frozen (the reference never reads their grads).
-    domain tuning (tuning_e4t.py:139-147): the whole UNet + the encoder's trainable parameters."""
+    domain tuning (tuning_e4t.py:139-147): the whole UNet + the encoder's trainable parameters (+ the text encoder's when
+    --train_text_encoder left them trainable).  Order = flat-buffer order: [E4T encoder | text encoder | UNet]."""
     for n, p in unet.named_parameters():
         p.requires_grad_(tuning or "wo" in n)
     named = [(f"e4t_encoder.{n}", p) for n, p in encoder.named_parameters() if p.requires_grad]
+    if text_encoder is not None:
+        named += [(f"text_encoder.{n}", p) for n, p in text_encoder.named_parameters() if p.requires_grad]
     named += [(f"unet.{n}", p) for n, p in unet.named_parameters() if tuning or "wo" in n]
     return named
 
@@ -89,7 +92,8 @@ class E4TTrainer:
         self.max_grad_norm = max_grad_norm
         self.tuning = tuning
         self._armed = False
-        named = select_trainable(unet, e4t_encoder, tuning=tuning)
+        named = select_trainable(unet, e4t_encoder, tuning=tuning, text_encoder=text_encoder)
+        self.text_trainable = any(n.startswith("text_encoder.") for n, _ in named)
         # order: the stacked first_linears weights, then their biases (contiguous stacks), then the rest
         fl_w = [p for n, p in named if ".first_linears." in n and n.endswith(".weight")]
         fl_b = [p for n, p in named if ".first_linears." in n and n.endswith(".bias")]
@@ -108,13 +112,18 @@ class E4TTrainer:
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
         ops.bump_weights_epoch()
-        # constants of the loop (pretrain_e4t.py:561-583)
-        with torch.no_grad():
-            emb = text_encoder.get_input_embeddings()
-            self.class_embed = emb(torch.tensor([class_token_id], device=self.device))[0].float()
-            ids = empty_prompt_ids if empty_prompt_ids is not None else torch.zeros((1, 77), dtype=torch.long, device=self.device)
-            self.ctx_for_e4t = text_encoder(input_ids=ids.to(self.device))[0].detach()
+        # constants of the loop (pretrain_e4t.py:561-583); with a trainable text encoder they are re-evaluated every step, detached,
+        # as tuning_e4t.py:276-284 does
+        self.class_token_id = class_token_id
+        self.empty_prompt_ids = (empty_prompt_ids if empty_prompt_ids is not None else torch.zeros((1, 77), dtype=torch.long)).to(self.device)
+        self._refresh_text_constants()
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self._comm and self.device.type == "cuda") else None
+
+    def _refresh_text_constants(self):
+        with torch.no_grad():
+            emb = self.text_encoder.get_input_embeddings()
+            self.class_embed = emb(torch.tensor([self.class_token_id], device=self.device))[0].float()
+            self.ctx_for_e4t = self.text_encoder(input_ids=self.empty_prompt_ids)[0].detach()
 
     # ------------------------------------------------------------------------------------------------
     def add_noise(self, x0, noise, t):
@@ -126,7 +135,9 @@ class E4TTrainer:
         """Forward half of the step (pretrain_e4t.py:616-647).  Returns (loss, loss_diff, loss_reg)."""
         B = latents.shape[0]
         te = self.text_encoder
-        with torch.no_grad():
+        if self.text_trainable:
+            self._refresh_text_constants()
+        with torch.set_grad_enabled(self.text_trainable and torch.is_grad_enabled()):     # the embedding table trains with the text encoder
             inputs_embeds = te.get_input_embeddings()(input_ids)
         noisy = self.add_noise(latents, noise, timesteps)
         # both UNet passes see the same (noisy, timesteps): the context-independent prefix is computed once (SURVEY §8a (3))

@@ -1,7 +1,7 @@
 """AutoencoderKL.encode on the HIP kernels ("next" row N1 of SURVEY.md §8f: 558 GMAC/image, inside every
 pre-training step at pretrain_e4t.py:597-599).
 
-Same parameters and key names as ``frozen.VAEEncoder`` (= the diffusers AutoencoderKL encoder checkpoint
+Same parameters and key names as ``checkpoint_trees.VAEEncoder`` (= the diffusers AutoencoderKL encoder checkpoint
 layout); forward-only and frozen, so no autograd: the kernels are called directly.
   conv_in (3 -> 128): a 27-wide im2col written by one kernel + one GEMM (K = 32) instead of padding RGB to 64 ch;
   ResBlocks: GroupNorm+SiLU kernels + implicit-GEMM 3x3 convs with the shortcut add in the epilogue;
@@ -13,11 +13,11 @@ from __future__ import annotations
 import torch
 
 from . import _C, ops
-from .frozen import VAEDecoder as _TorchVAEDecoder
-from .frozen import VAEEncoder as _TorchVAEEncoder
+from .checkpoint_trees import VAEDecoder as _VAEDecoderTree
+from .checkpoint_trees import VAEEncoder as _VAEEncoderTree
 
 
-class VAEEncoder(_TorchVAEEncoder):
+class VAEEncoder(_VAEEncoderTree):
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self._cache = None
@@ -129,9 +129,9 @@ def _attention_1head(be, h, B, T, gn, qkv, proj):
     return be.gemm(o, proj[0], bias=proj[1], residual=h, colstats=True)
 
 
-class VAEDecoder(_TorchVAEDecoder):
+class VAEDecoder(_VAEDecoderTree):
     """AutoencoderKL.decode on the HIP kernels (inference row N4: pipeline_stable_diffusion_e4t.py:226,237 ->
-    StableDiffusionPipeline.decode_latents).  Same parameters / key names as ``frozen.VAEDecoder``.
+    StableDiffusionPipeline.decode_latents).  Same parameters / key names as ``checkpoint_trees.VAEDecoder``.
       post_quant_conv (1x1, 4 -> 4) with 1/scaling_factor folded in: one GEMM whose output is already the 64-channel
         zero-padded NHWC operand of conv_in;
       Upsample2D: nearest x2 is a gather mode of the 3x3 conv (E4T_CONV_UP2) — the 4x larger map is never written;

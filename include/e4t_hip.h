@@ -60,7 +60,8 @@ typedef struct {
   int lda, lda2, ldb, ldc, ldr;
   int rows_per_batch;
   int flags;
-  int tile;            /* 0 = auto, 64 or 128 */
+  int tile;            /* 0 = auto; 64, 128, 160 (= 128x160), 256 (= 256x128), 512 (= 256x256 ping-pong), 640 (= 512x128);
+                          + 3000 / 4000 forces 3 / 4 LDS stages on the 64 / 128 / 160 tiles (e.g. 3128) */
   int splitk;          /* 0 = auto, >= 1 forced */
   int batch;           /* >= 1; operand base pointers advance by the strides below (elements) */
   long long strideA, strideB, strideC, strideBias;

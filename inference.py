@@ -50,14 +50,15 @@ def parse_args():
 
 def main():
     args = parse_args()
-    from bench import build_models
+    from e4t.builders import build_models
+    from e4t.cli_common import checked_load
     from e4t.pipeline_stable_diffusion_e4t import StableDiffusionE4TPipeline
     from e4t.schedulers import SCHEDULER_MAPPING
     from e4t.utils import AttributeDict, WhitespaceTokenizer, load_weight_offsets
     from e4t.vae import VAEDecoder
     dev = torch.device("cuda:0")
     print(f"device: {dev}")
-    unet, enc, text, _ = build_models(dev, args.unet_variant, seed=args.seed or 0)
+    unet, enc, text, _ = build_models(dev, args.unet_variant, seed=args.seed or 0)       # 49408-row token table; the pipeline adds the placeholder row
     with torch.device(dev):
         vae = VAEDecoder().requires_grad_(False)
     cfg = AttributeDict(placeholder_token="*s", domain_class_token="art", domain_embed_scale=0.1)
@@ -70,12 +71,17 @@ def main():
         cfg = AttributeDict(placeholder_token=e4t.placeholder_token, domain_class_token=e4t.domain_class_token,
                             domain_embed_scale=float(e4t.domain_embed_scale))
         base = e4t.pretrained_model_name_or_path
-        for name, mod in (("unet", unet), ("vae", vae), ("text_encoder", text)):
-            f = os.path.join(base or "", f"{name}.pt")
-            if os.path.exists(f):
-                mod.load_state_dict(torch.load(f, map_location="cpu"), strict=False)
+        if not base or not os.path.isdir(base):
+            raise SystemExit(f"{d}/config.json names the base model {base!r}: a local directory with unet.pt / vae.pt / text_encoder.pt / tokenizer/ is needed")
+        # every load is strict: a misnamed key must not leave random weights behind (e4t/utils.py:119-124)
+        checked_load(unet, os.path.join(base, "unet.pt"), lambda k: "wo" in k)
+        checked_load(text, os.path.join(base, "text_encoder.pt"))
+        sd = {k: v for k, v in torch.load(os.path.join(base, "vae.pt"), map_location="cpu").items() if k.startswith(("decoder.", "post_quant_conv."))}
+        missing, unexpected = vae.load_state_dict(sd, strict=False)
+        if missing or unexpected:
+            raise RuntimeError(f"{base}/vae.pt: missing {missing[:5]} unexpected {list(unexpected)[:5]}")
         if os.path.exists(os.path.join(d, "unet.pt")):
-            unet.load_state_dict(torch.load(os.path.join(d, "unet.pt"), map_location="cpu"))
+            checked_load(unet, os.path.join(d, "unet.pt"))
         else:
             load_weight_offsets(unet, os.path.join(d, "weight_offsets.pt"))
         from transformers import CLIPTokenizer
@@ -88,9 +94,9 @@ def main():
                                       safety_checker=None, feature_extractor=None, e4t_config=cfg, requires_safety_checker=False)
     if not args.random_init:
         d = args.pretrained_model_name_or_path
-        enc.load_state_dict(torch.load(os.path.join(d, "encoder.pt"), map_location="cpu"))
+        checked_load(enc, os.path.join(d, "encoder.pt"))
         if os.path.exists(os.path.join(d, "text_encoder.pt")):                                                  # inference.py:92-101
-            text.load_state_dict(torch.load(os.path.join(d, "text_encoder.pt"), map_location="cpu"))
+            checked_load(text, os.path.join(d, "text_encoder.pt"))        # written by --train_text_encoder: already holds the placeholder row
     unet.requires_grad_(False)
     enc.requires_grad_(False)
     if args.enable_xformers_memory_efficient_attention:

@@ -20,6 +20,16 @@ sys.path[:0] = [os.path.join(HERE, "shims"), "/root/reference", os.path.join(ROO
 import torch  # noqa: E402
 
 torch.set_grad_enabled(True)
+def torch_twin():
+    """tests/torch_twins.py (the stock-torch CLIP text encoder over this repository's checkpoint tree), loaded by path: in this
+    process `e4t` is the REFERENCE's package"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("torch_twins_by_path", os.path.join(ROOT, "tests", "torch_twins.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def pack(named):
     """{name: tensor} -> (one flat fp32 vector, [(name, shape)]): thousands of tiny tensors pickle to megabytes otherwise"""
     named = dict(named)
@@ -155,7 +165,7 @@ def pipeline_fixture(unet_blob):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         return mod
-    CLIPTextModel, WhitespaceTokenizer = native("frozen").CLIPTextModel, native("utils").WhitespaceTokenizer
+    CLIPTextModel, WhitespaceTokenizer = torch_twin().CLIPTextModel, native("utils").WhitespaceTokenizer
     from standin import PROMPT, TEXT_CFG, StandInEncoder
     for cls in (UNet2DConditionModel, StableDiffusionE4TPipeline):
         assert sys.modules[cls.__module__].__file__.startswith("/root/reference/"), cls
@@ -211,7 +221,7 @@ def pipeline_wide_fixture():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         return mod
-    CLIPTextModel, WhitespaceTokenizer = native("frozen").CLIPTextModel, native("utils").WhitespaceTokenizer
+    CLIPTextModel, WhitespaceTokenizer = torch_twin().CLIPTextModel, native("utils").WhitespaceTokenizer
 
     class Sched(orc.DDIMScheduler):
         def set_timesteps(self, n, device=None):
@@ -268,7 +278,7 @@ def step_fixture(unet_blob):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         return mod
-    CLIPTextModel, WhitespaceTokenizer = native("frozen").CLIPTextModel, native("utils").WhitespaceTokenizer
+    CLIPTextModel, WhitespaceTokenizer = torch_twin().CLIPTextModel, native("utils").WhitespaceTokenizer
     lines = open("/root/reference/pretrain_e4t.py").read().splitlines()
     prelude = textwrap.dedent("\n".join(lines[560:584]))          # file lines 561-584
     body = textwrap.dedent("\n".join(lines[596:654]))             # file lines 597-654
@@ -359,7 +369,7 @@ def tuning_step_fixture(unet_blob):
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         return mod
-    CLIPTextModel, WhitespaceTokenizer = native("frozen").CLIPTextModel, native("utils").WhitespaceTokenizer
+    CLIPTextModel, WhitespaceTokenizer = torch_twin().CLIPTextModel, native("utils").WhitespaceTokenizer
     lines = open("/root/reference/tuning_e4t.py").read().splitlines()
     i0 = next(i for i, l in enumerate(lines) if l.strip() == "pixel_values = image.expand(args.train_batch_size, -1, -1, -1)")
     iw = next(i for i, l in enumerate(lines) if l.strip() == "with accelerator.accumulate(unet):")

@@ -79,3 +79,31 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from e4t.vae import VAEEncoder
     with pytest.raises(_C.E4TError):
         VAEEncoder(block_out_channels=(64, 64)).moments(torch.zeros(1, 3, 16, 16))
+
+
+def test_integration_md_gemm_desc_example_has_the_c_layout(tmp_path):
+    """INTEGRATION.md shows maintainers a ctypes mirror of e4t_gemm_desc.  A struct that is short of the trailing `colstats`
+    pointer makes the library read 8 bytes past the caller's buffer (round-1 review): extract the documented class and hold it
+    against the C compiler's sizeof / offsetof, field by field."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class GemmDesc\(C\.Structure\):.*?\n(    _fields_ = \[.*?\])\s*(?:#[^\n]*)?\nlib\.", md, flags=re.S)
+    assert m, "INTEGRATION.md no longer contains the GemmDesc example"
+    ns = {"C": C}
+    exec("class GemmDesc(C.Structure):\n" + m.group(1), ns)
+    doc = ns["GemmDesc"]
+    assert [f for f, _ in doc._fields_] == [f for f, _ in _C.GemmDesc._fields_]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "e4t_hip.h")}"', "int main(void) {",
+             '  printf("sizeof %zu\\n", sizeof(e4t_gemm_desc));']
+    lines += [f'  printf("{f} %zu\\n", offsetof(e4t_gemm_desc, {f}));' for f, _ in doc._fields_]
+    lines += ["  return 0;", "}"]
+    (tmp_path / "l.c").write_text("\n".join(lines))
+    subprocess.run(["gcc", "-std=c99", str(tmp_path / "l.c"), "-o", str(tmp_path / "l")], check=True)
+    got = dict(l.split() for l in subprocess.run([str(tmp_path / "l")], check=True, capture_output=True, text=True).stdout.strip().split("\n"))
+    assert int(got["sizeof"]) == C.sizeof(doc), (got["sizeof"], C.sizeof(doc))
+    for f, _ in doc._fields_:
+        assert int(got[f]) == getattr(doc, f).offset, f

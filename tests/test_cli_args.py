@@ -38,7 +38,9 @@ def test_tuning_flags(monkeypatch):
                              "--gradient_accumulation_steps", "2", "--lr_scheduler", "constant_with_warmup", "--lr_warmup_steps", "3", "--unfreeze_clip_vision",
                              "--scale_lr", "--checkpointing_steps", "10", "--max_grad_norm", "1.0"], monkeypatch)
     assert a.learning_rate == 1.6e-5 and a.seed == 42 and a.train_batch_size == 16 and a.max_grad_norm == 1.0      # the reference's defaults
-    for bad in (["--use_8bit_adam"], ["--train_text_encoder"]):
+    assert parse("tuning_e4t", ["--train_text_encoder"], monkeypatch).train_text_encoder          # native since round 2 (e4t/text.py)
+    assert parse("tuning_e4t", [], monkeypatch).prompt_template is None                           # None -> the pre-trained run's template (:252-253)
+    for bad in (["--use_8bit_adam"], ["--gradient_accumulation_steps", "0"]):
         with pytest.raises(SystemExit):
             parse("tuning_e4t", bad, monkeypatch)
 

@@ -98,7 +98,7 @@ def test_sampling_loop_matches_reference_pipeline(guidance):
     import sys
     sys.path.insert(0, GOLD)
     from standin import PROMPT, TEXT_CFG, StandInEncoder
-    from e4t.frozen import CLIPTextModel
+    from torch_twins import CLIPTextModel
     from e4t.utils import WhitespaceTokenizer
     ub = torch.load(os.path.join(GOLD, "reference_unet.pt"))["sd1"]
     pb = torch.load(os.path.join(GOLD, "reference_pipeline.pt"))
@@ -236,7 +236,7 @@ def test_training_step_matches_reference_lines():
     import torch.nn.functional as F
     sys.path.insert(0, GOLD)
     from standin import TEXT_CFG, StandInEncoder
-    from e4t.frozen import CLIPTextModel
+    from torch_twins import CLIPTextModel
     from e4t.utils import WhitespaceTokenizer
     ub = torch.load(os.path.join(GOLD, "reference_unet.pt"))["sd1"]
     sb = torch.load(os.path.join(GOLD, "reference_step.pt"))
@@ -299,7 +299,7 @@ def test_tuning_step_matches_reference_lines():
     import torch.nn.functional as F
     sys.path.insert(0, GOLD)
     from standin import TEXT_CFG, StandInEncoder
-    from e4t.frozen import CLIPTextModel
+    from torch_twins import CLIPTextModel
     from e4t.utils import WhitespaceTokenizer
     ub = torch.load(os.path.join(GOLD, "reference_unet.pt"))["sd1"]
     sb = torch.load(os.path.join(GOLD, "reference_tuning_step.pt"))

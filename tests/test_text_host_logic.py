@@ -1,5 +1,5 @@
 """CPU: the native CLIP text encoder (e4t/text.py: fused q|k|v GEMM, causal fused attention, residual epilogues) against its
-stock-torch twin (e4t/frozen.py = the HF CLIPTextModel semantics the reference uses through modeling_clip.py) — forward and the
+stock-torch twin (tests/torch_twins.py = the HF CLIPTextModel semantics the reference uses through modeling_clip.py) — forward and the
 gradient w.r.t. inputs_embeds, both activations, through the fp32 op emulation."""
 import pytest
 import torch
@@ -9,7 +9,7 @@ from test_unet_host_logic import emu_fp32  # noqa: F401
 
 @pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
 def test_text_encoder_matches_torch_twin(emu_fp32, act):
-    from e4t.frozen import CLIPTextModel as TorchText
+    from torch_twins import CLIPTextModel as TorchText
     from e4t.text import CLIPTextModel as NativeText
     cfg = dict(vocab_size=120, hidden_size=64, num_layers=3, num_heads=2, intermediate_size=160, max_len=77, act=act)
     torch.manual_seed(0)
@@ -34,13 +34,32 @@ def test_text_encoder_matches_torch_twin(emu_fp32, act):
     torch.testing.assert_close(nat(inputs_embeds=e3)[0][:, :40], y1.detach()[:, :40], rtol=1e-5, atol=1e-6)
 
 
-def test_trainable_text_encoder_falls_back_to_torch(emu_fp32):
+def test_trainable_text_encoder_gradients_match_torch_twin(emu_fp32):
+    """tuning_e4t.py --train_text_encoder: every parameter gradient of the native text encoder (fused q|k|v assembled by a
+    differentiable cat, TN weight-gradient GEMMs, LayerNorm / bias gradients from the kernels) vs autograd on the torch twin."""
+    from torch_twins import CLIPTextModel as TorchText
     from e4t.text import CLIPTextModel as NativeText
-    cfg = dict(vocab_size=50, hidden_size=32, num_layers=1, num_heads=2, intermediate_size=64, max_len=9, act="quick_gelu")
-    m = NativeText(**cfg)          # parameters require grad -> torch path, weight gradients exist
-    ids = torch.randint(0, 50, (2, 9))
-    m(input_ids=ids)[0].sum().backward()
-    assert m.text_model.encoder.layers[0].mlp.fc1.weight.grad is not None
+    cfg = dict(vocab_size=50, hidden_size=64, num_layers=2, num_heads=2, intermediate_size=128, max_len=9, act="quick_gelu")
+    torch.manual_seed(0)
+    ref, nat = TorchText(**cfg), NativeText(**cfg)
+    nat.load_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, 50, (3, 9), generator=g)
+    w = torch.randn(3, 9, 64, generator=g)
+    (ref(input_ids=ids)[0] * w).sum().backward()
+    (nat(input_ids=ids)[0] * w).sum().backward()
+    want = dict(ref.named_parameters())
+    n = 0
+    for name, p in nat.named_parameters():
+        assert p.grad is not None, name
+        torch.testing.assert_close(p.grad, want[name].grad, rtol=2e-3, atol=2e-5, msg=lambda m, name=name: f"{name}: {m}")
+        n += 1
+    assert n == len(want) == 2 + 2 * 16 + 2
+    # a second forward after an in-place weight update sees the new weights (the fused copy is rebuilt every forward)
+    with torch.no_grad():
+        for m in (ref, nat):
+            m.text_model.encoder.layers[0].self_attn.q_proj.weight.mul_(1.5)
+    torch.testing.assert_close(nat(input_ids=ids)[0], ref(input_ids=ids)[0], rtol=2e-4, atol=2e-5)
 
 
 def test_text_encoder_matches_installed_transformers_clip():
@@ -50,7 +69,7 @@ def test_text_encoder_matches_installed_transformers_clip():
     the inputs_embeds entry point equals the input_ids one."""
     transformers = pytest.importorskip("transformers")
     import e4t_oracle as orc
-    from e4t.frozen import CLIPTextModel as Twin
+    from torch_twins import CLIPTextModel as Twin
     for act, heads in (("quick_gelu", 2), ("gelu", 4)):
         cfg = transformers.CLIPTextConfig(vocab_size=100, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=heads,
                                           max_position_embeddings=9, hidden_act=act, bos_token_id=1, eos_token_id=2)

@@ -14,7 +14,7 @@ TEXT_CFG = dict(vocab_size=100, hidden_size=64, num_layers=2, num_heads=2, inter
 
 def build(seed=0):
     from e4t.encoder import E4TEncoder
-    from e4t.frozen import CLIPTextModel
+    from torch_twins import CLIPTextModel
     from e4t.models.unet_2d_condition import UNet2DConditionModel
     torch.manual_seed(seed)
     cfg = orc.tiny_unet_config(ctx_dim=64)

@@ -1,8 +1,9 @@
-"""CPU: the kernel-driven VAE encoder (e4t/vae.py) vs its stock-torch twin (e4t/frozen.py) and vs the oracle's VAE,
+"""CPU: the kernel-driven VAE encoder (e4t/vae.py) vs its stock-torch twin (tests/torch_twins.py) and vs the oracle's VAE,
 same parameters, through the fp32 op emulation."""
 import torch
 
 import e4t_oracle as orc
+import torch_twins
 from test_unet_host_logic import emu_fp32  # noqa: F401
 
 
@@ -28,7 +29,7 @@ def test_native_vae_matches_torch_and_oracle(emu_fp32):
     x = torch.rand(2, 3, 32, 32) * 2 - 1
     eps = torch.randn(2, 4, 8, 8)
     z_nat = nat.encode_sample(x, eps)
-    z_torch = super(VAEEncoder, nat).encode_sample(x, eps)
+    z_torch = torch_twins.vae_encode_sample(nat, x, eps)
     z_ref = ref.encode_sample(x, eps)
     torch.testing.assert_close(z_torch, z_ref, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(z_nat, z_ref, rtol=2e-4, atol=2e-5)
@@ -43,7 +44,7 @@ def test_native_vae_decoder_matches_torch_and_oracle(emu_fp32):
     ref.load_state_dict(nat.state_dict())                    # same key names as the diffusers checkpoint
     z = torch.randn(2, 4, 8, 8) * 0.18215
     want = ref.decode_latents(z)
-    torch.testing.assert_close(super(VAEDecoder, nat).decode_latents(z), want, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(torch_twins.vae_decode_latents(nat, z), want, rtol=1e-4, atol=1e-5)
     got = nat.decode_latents(z)
     assert got.shape == (2, 32, 32, 3) and got.dtype == torch.float32
     torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-5)

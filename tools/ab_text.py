@@ -2,7 +2,9 @@ import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(R, "e4t-diffusion_amd")]
 import torch
-from e4t.frozen import CLIPTextModel as TorchText, CLIP_TEXT_L
+sys.path.insert(0, os.path.join(R, 'tests'))
+from torch_twins import CLIPTextModel as TorchText
+from e4t.checkpoint_trees import CLIP_TEXT_L
 from e4t.text import CLIPTextModel as NativeText
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
