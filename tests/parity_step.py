@@ -373,6 +373,8 @@ def compare(case: Case, nat, ref, cals, verbose=True, strict=True):
             w, q = worst(rs), ratio(rs)
             rep[kind] = dict(worst=dict(name=w[0], native=w[1], autocast=w[2]),
                              tightest=dict(name=q[0], native=q[1], autocast=q[2], used=q[1] / (2 * q[2] + FLOOR)), count=len(rs))
+            if kind == "grads":
+                rep[kind]["by_part"] = {part: sum(1 for r in rs if part in r[0]) for part in ("grad/unet.", "grad/e4t_encoder.", ".clip_vision.", ".wo_")}
     if verbose:
         for kind in ("other", "enc_maps", "losses", "grads"):
             if kind in rep:

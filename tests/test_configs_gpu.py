@@ -43,4 +43,4 @@ def test_sd2_config_step_matches_oracle(hip_env, name):
 @pytest.mark.parametrize("name", ["unfrozen_vit_tiny", "unfrozen_vit"])
 def test_unfrozen_vit_step_matches_oracle(hip_env, name):
     rep = _run(name)
-    assert "clip_vision" in json.dumps(rep) or rep["grads"]["count"] > 220
+    assert rep["grads"]["by_part"][".clip_vision."] >= 12          # the ViT tower's gradients were compared, not only the head's
