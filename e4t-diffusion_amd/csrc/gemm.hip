@@ -102,18 +102,35 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][
     // rounded value in fp32 and rounded again, which is exactly what a bf16 linear followed by a bf16 add does.
     constexpr int ELD = WN + 8;
     bf16_t* stage = smem + wave * (WM * ELD);
+    // Everything the epilogue reads from global memory is fetched by UNCONDITIONAL loads issued back to back (indices clamped
+    // into range, values masked afterwards).  The first version guarded each load (`col < N ? bias[col] : 0`, the row-bias
+    // inside the 16-element loop, the residual chunk inside the store loop): the compiler answered every guarded load with its
+    // own s_waitcnt vmcnt(0) — FN serialized L2 round trips for the bias, 16 x FM x FN for the ResBlock time-embedding row-bias
+    // (85 in the 128 x 160 conv tile), one per 16-byte residual chunk (10) — in the epilogue of EVERY workgroup (ISA, round 2).
+    float bv[FN], rbv[FM][FN];
+    const bool rb_blocked = p.rowbias && (p.rows_per_batch % 32 == 0);        // a 32-row fragment lies inside one batch entry
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = min(nw + j * 32 + frow, p.N - 1);
+      bv[j] = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = min(mw + i * 32, p.M - 1);
+        rbv[i][j] = rb_blocked ? p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col] : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int cl = j * 32 + frow;
         const int col = nw + cl;
-        const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+        const float add = bv[j] + rbv[i][j];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-          float v = acc[i][j][r] * p.alpha + bv;
-          if (p.rowbias) {
+          float v = acc[i][j][r] * p.alpha + add;
+          if (p.rowbias && !rb_blocked) {      // odd geometry (rows_per_batch not a multiple of 32): per-row lookup
             const int row = mw + rl;
             if (row < p.M && col < p.N) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
           }
@@ -123,10 +140,21 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][
       }
     __syncthreads();                     // (a wave only reads back its own region; the barrier orders the LDS traffic)
     constexpr int CPR = WN / 8;          // 16-byte chunks per row
+    constexpr int NIT = (WM * CPR + 63) / 64;
     bf16_t* Cb = (bf16_t*)p.C;
     const bf16_t* Rb = (const bf16_t*)p.residual;
+    uint4 rres[NIT];
+    if (Rb) {
 #pragma unroll
-    for (int it = 0; it < (WM * CPR + 63) / 64; ++it) {
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = min(it * 64 + lane, WM * CPR - 1);
+        const int rl = idx / CPR, cch = idx - rl * CPR;
+        const int row = min(mw + rl, p.M - 1), col = min(nw + cch * 8, p.N - 8);
+        rres[it] = *(const uint4*)(Rb + (size_t)row * p.ldr + col);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
       const int idx = it * 64 + lane;
       const int rl = idx / CPR, cch = idx - rl * CPR;
       const int row = mw + rl, col = nw + cch * 8;
@@ -135,7 +163,7 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][
         if (Rb) {
           float a[8], b[8];
           unpack8(v, a);
-          unpack8(*(const uint4*)(Rb + (size_t)row * p.ldr + col), b);
+          unpack8(rres[it], b);
 #pragma unroll
           for (int k = 0; k < 8; ++k) a[k] += b[k];
           v = pack8(a);
@@ -1288,6 +1316,57 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs p, int nz) 
   }
 }
 
+// The same reduction for the common case — bf16 C, N and every leading dimension a multiple of 8, no accumulate — with 8
+// columns per thread: the partial slabs are read as 2 x float4 per split with ALL splits of a trip in flight (the scalar
+// version above walks them one 4-byte load at a time and answers the guarded bias / row-bias / residual loads of
+// epilogue_store with one memory round trip each), bias / row bias / residual as 32- / 16-byte vectors, C as one 16-byte store.
+// Same arithmetic, same summation order (z ascending), single rounding.
+__global__ __launch_bounds__(256) void splitk_reduce8_kernel(GemmArgs p, int nz) {
+  const int n8 = p.N >> 3;
+  const size_t total = (size_t)p.M * p.N, total8 = (size_t)p.M * n8;
+  const int bz = blockIdx.y;
+  if (!p.reduce_batch) {
+    if (p.bias) p.bias += bz * p.strideBias;
+    p.C = (bf16_t*)p.C + bz * p.strideC;
+  }
+  const float* ws = p.ws + (size_t)bz * nz * total;
+  const bf16_t* Rb = (const bf16_t*)p.residual;
+  for (size_t i8 = (size_t)blockIdx.x * 256 + threadIdx.x; i8 < total8; i8 += (size_t)gridDim.x * 256) {
+    const int row = (int)(i8 / n8), c8 = (int)(i8 - (size_t)row * n8) * 8;
+    const size_t idx = (size_t)row * p.N + c8;
+    float bi[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) { const float4 a = *(const float4*)(p.bias + c8), b = *(const float4*)(p.bias + c8 + 4); bi[0] = a.x; bi[1] = a.y; bi[2] = a.z; bi[3] = a.w; bi[4] = b.x; bi[5] = b.y; bi[6] = b.z; bi[7] = b.w; }
+    if (p.rowbias) {
+      const float* q = p.rowbias + (size_t)(row / p.rows_per_batch) * p.ldrb + c8;
+      const float4 a = *(const float4*)q, b = *(const float4*)(q + 4);
+      rb[0] = a.x; rb[1] = a.y; rb[2] = a.z; rb[3] = a.w; rb[4] = b.x; rb[5] = b.y; rb[6] = b.z; rb[7] = b.w;
+    }
+    if (Rb) unpack8(*(const uint4*)(Rb + (size_t)row * p.ldr + c8), rs);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int z0 = 0; z0 < nz; z0 += 4) {
+      float4 lo[4], hi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* q = ws + (size_t)min(z0 + u, nz - 1) * total + idx;
+        lo[u] = *(const float4*)q; hi[u] = *(const float4*)(q + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float w = z0 + u < nz ? 1.f : 0.f;
+        v[0] += lo[u].x * w; v[1] += lo[u].y * w; v[2] += lo[u].z * w; v[3] += lo[u].w * w;
+        v[4] += hi[u].x * w; v[5] += hi[u].y * w; v[6] += hi[u].z * w; v[7] += hi[u].w * w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float x = v[k] * p.alpha + bi[k] + rb[k];
+      if (p.flags & E4T_ACT_GELU) x = gelu_f(x);
+      v[k] = x + rs[k];
+    }
+    *(uint4*)((bf16_t*)p.C + (size_t)row * p.ldc + c8) = pack8(v);
+  }
+}
+
 int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int splitk_req, int batch, hipStream_t st) {
   const int nkt = cdiv(p.K, BK);
   // --- tile selection: fill >= ~1.5 waves of the 256 CUs with 128x128 tiles, else drop to 64x64 ---
@@ -1375,6 +1454,11 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                (p.strideC % 8 == 0) && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
   if (p.colstats && (p.ws || !p.fast_epi || p.M % 32 != 0 || batch != 1)) p.colstats = nullptr;   // only the bf16 single-pass epilogue produces them
   const int stats_written = p.colstats != nullptr;
+  // split-K / batch reduction: the 8-columns-per-thread kernel when C is bf16 and everything it touches is 16-byte aligned
+  const bool vec8 = p.ws && !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
+                    p.strideC % 8 == 0 && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0)) &&
+                    (!p.bias || (((uintptr_t)p.bias & 15) == 0 && p.strideBias % 4 == 0)) &&
+                    (!p.rowbias || (((uintptr_t)p.rowbias & 15) == 0 && p.ldrb % 4 == 0)) && ((uintptr_t)p.ws & 15) == 0;
   dim3 grid(gx, gy, splitk * batch), block(256);
   static const bool use_dma = getenv("E4T_GEMM_REGSTAGE") == nullptr;   // A/B switch: register-staged reference kernel
   if (e4t_launch_log_enabled()) {
@@ -1398,8 +1482,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                              p.M, splitk, by, 2.0 * p.M * p.N * (double)p.K);
     else E4T_LOG_LAUNCH("%s|gemm M%d N%d K%d batch%d splitk%d flags%d|%.0f|%.0f", sym, p.M, p.N, p.K, batch, splitk, p.flags, by,
                         2.0 * p.M * p.N * (double)p.K * batch);
-    if (p.ws) E4T_LOG_LAUNCH("splitk_reduce_kernel|M%d N%d nz%d|%.0f|0", p.M, p.N, p.reduce_batch ? splitk * batch : splitk,
-                             4.0 * (double)p.M * p.N * splitk * batch + osz * (double)p.M * p.N);
+    if (p.ws) E4T_LOG_LAUNCH("%s|M%d N%d nz%d|%.0f|0", vec8 ? "splitk_reduce8_kernel" : "splitk_reduce_kernel",
+                             p.M, p.N, p.reduce_batch ? splitk * batch : splitk, 4.0 * (double)p.M * p.N * splitk * batch + osz * (double)p.M * p.N);
   }
   if (use_dma && buf_ok) {
     if (tile == 512) {
@@ -1447,7 +1531,13 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     const int nz = p.reduce_batch ? splitk * batch : splitk;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, p.reduce_batch ? 1 : batch), dim3(256), 0, st, p, nz);
+    if (vec8) {
+      int b8 = (int)((total / 8 + 255) / 256);
+      if (b8 > 2048) b8 = 2048;
+      hipLaunchKernelGGL(splitk_reduce8_kernel, dim3(b8, p.reduce_batch ? 1 : batch), dim3(256), 0, st, p, nz);
+    } else {
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, p.reduce_batch ? 1 : batch), dim3(256), 0, st, p, nz);
+    }
     E4T_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return (use_dma && buf_ok) ? stats_written : 0;

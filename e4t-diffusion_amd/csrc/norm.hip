@@ -12,6 +12,7 @@
 // 554-556), nn.LayerNorm in BasicTransformerBlock (e4t/models/attention.py:259,268,273) and in the
 // open_clip ViT (e4t/encoder.py:154).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/e4t_hip.h"
 
 namespace {
@@ -20,6 +21,9 @@ namespace {
 //   QW <= 256: the block's 256 threads form PG = 256/QW pixel groups x QW chunk lanes (every thread busy);
 //   QW  > 256: one pixel group, each thread owns chunks tid and tid+256 (C <= 4096).
 constexpr int GN_MAXS = 2;
+// pixels a thread has in flight per loop trip: all GN_U x (1-3) 16-byte loads of a trip are issued before the first is consumed.
+// One load per trip left ~16 KiB in flight per CU = 2 TB/s on the mid-size maps (Little's law at ~2 us); 4 reach the HBM rate.
+constexpr int GN_U = 4;          // (one-slot kernels; the two-slot ones, C > 2048, carry twice the state and use GN_U / 2)
 
 struct GNSrc {
   const bf16_t* x1; const bf16_t* x2; int C1, C2;
@@ -76,7 +80,66 @@ __device__ __forceinline__ void gn_block_reduce(const GNMap& m, int C, int G, fl
   }
 }
 
+// ---- straight-line inner loops ---------------------------------------------------------------------------------------------
+// Every GroupNorm kernel walks its chunk GN_U pixels per trip.  The loads of a trip must sit in ONE basic block: the first
+// version guarded each load (inactive thread / pixel past the chunk end) and the compiler answered every guarded load with
+// its own s_waitcnt vmcnt(0) — one memory round trip per 16 bytes per thread, 2 TB/s on the 64x64-level maps whatever the
+// occupancy; the per-channel gamma / beta / mean / rstd fetches of the prologue were 16-32 such round trips in a row before
+// the first pixel was touched (ISA inspection, round 2).  Now: the slot count NS is a template parameter, inactive threads
+// alias chunk 0 and out-of-range pixels alias the chunk's last pixel (loads unconditional, only stores / accumulations are
+// masked), the two-source select is a pointer select, and the per-channel constants come from 32-byte vector loads plus an
+// LDS copy of the per-group statistics.
+__device__ __forceinline__ uint4 gn_load8u(const GNSrc& s, size_t pix, int c) {
+  const bf16_t* p = c < s.C1 ? s.x1 + pix * s.C1 + c : s.x2 + pix * s.C2 + (c - s.C1);
+  return *(const uint4*)p;
+}
+__device__ __forceinline__ void ld8f(const float* p, float* o) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <int NS>
+struct GNSlots {
+  int c[NS];       // first channel of the slot's 8-channel chunk (chunk 0 for an inactive slot)
+  bool act[NS];
+  __device__ GNSlots(const GNMap& m) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { act[i] = m.ch[i] >= 0; c[i] = act[i] ? m.ch[i] * 8 : 0; }
+  }
+};
+// the (b, g) statistics of this batch entry in LDS: mr[g*2] = mean, mr[g*2+1] = rstd   (G <= 256)
+__device__ __forceinline__ void gn_stage_stats(float* mr, const float* mean_rstd_b, int G) {
+  for (int i = threadIdx.x; i < G * 2; i += 256) mr[i] = mean_rstd_b[i];
+  __syncthreads();
+}
+
 // partial[b][chunk][g][2] = (sum, sumsq) of x over this chunk's pixels and group g's channels
+template <int NS>
+__device__ __forceinline__ void gn_stats_body(const GNSrc& s, const GNMap& m, int b, int HW, int p0, int p1, float (*sm)[8], float (*sq)[8]) {
+  constexpr int U = NS == 1 ? GN_U : GN_U / 2;
+  const GNSlots<NS> sl(m);
+  for (int p = p0 + m.pg; p < p1; p += U * m.PG) {
+    uint4 vx[U][NS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pp = min(p + u * m.PG, p1 - 1);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) vx[u][i] = gn_load8u(s, (size_t)b * HW + pp, sl.c[i]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = p + u * m.PG < p1;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        float f[8];
+        unpack8(vx[u][i], f);
+        const float w = (in && sl.act[i]) ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float v = f[j] * w; sm[i][j] += v; sq[i][j] += v * v; }
+      }
+    }
+  }
+}
+template <int NS>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GNSrc s, int HW, int G, int pix_per_chunk, float* partial) {
   extern __shared__ float lds[];
   const int C = s.C1 + s.C2;
@@ -89,17 +152,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNSrc s, int HW, int G, i
   for (int i = 0; i < GN_MAXS; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) sm[i][j] = sq[i][j] = 0.f;
-  for (int p = p0 + m.pg; p < p1; p += m.PG) {
-    const size_t pix = (size_t)b * HW + p;
-#pragma unroll
-    for (int i = 0; i < GN_MAXS; ++i)
-      if (m.ch[i] >= 0) {
-        float f[8];
-        unpack8(gn_load8(s, pix, m.ch[i] * 8), f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { sm[i][j] += f[j]; sq[i][j] += f[j] * f[j]; }
-      }
-  }
+  if (p0 < p1) gn_stats_body<NS>(s, m, b, HW, p0, p1, sm, sq);
   gn_block_reduce(m, C, G, sm, sq, lds, nullptr, partial + ((size_t)b * gridDim.x + chunk) * G * 2, nullptr);
 }
 
@@ -151,14 +204,58 @@ __device__ __forceinline__ void gn_block_sum_partials(const float* partial_b /* 
 // y = act(gamma * (x - mean) * rstd + beta), written as one contiguous (B*HW, C) bf16 matrix
 // FUSED: mean / rstd are finalised from the stats kernel's chunk partials in the prologue (and written to mean_rstd_out by
 // chunk 0 of every batch entry for the backward) instead of by a separate finalize launch.
-template <bool FUSED>
+template <int NS>
+__device__ __forceinline__ void gn_apply_body(const GNSrc& s, const GNMap& m, int b, int HW, int C, int cpg, int p0, int p1, const float* mr,
+                                              const float* gamma, const float* beta, bf16_t* y, int silu) {
+  constexpr int U = NS == 1 ? GN_U : GN_U / 2;
+  const GNSlots<NS> sl(m);
+  float sc[NS][8], sh[NS][8];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    float ga[8], be[8];
+    ld8f(gamma + sl.c[i], ga);
+    ld8f(beta + sl.c[i], be);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (sl.c[i] + j) / cpg;
+      sc[i][j] = mr[g * 2 + 1] * ga[j];
+      sh[i][j] = be[j] - mr[g * 2] * sc[i][j];
+    }
+  }
+  for (int p = p0 + m.pg; p < p1; p += U * m.PG) {
+    uint4 vx[U][NS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pp = min(p + u * m.PG, p1 - 1);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) vx[u][i] = gn_load8u(s, (size_t)b * HW + pp, sl.c[i]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = p + u * m.PG < p1;
+      const size_t pix = (size_t)b * HW + p + u * m.PG;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        float f[8];
+        unpack8(vx[u][i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float z = f[j] * sc[i][j] + sh[i][j];
+          f[j] = silu ? silu_f(z) : z;
+        }
+        if (in && sl.act[i]) *(uint4*)(y + pix * C + sl.c[i]) = pack8(f);
+      }
+    }
+  }
+}
+template <bool FUSED, int NS>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNSrc s, const float* mean_rstd, const float* gamma, const float* beta,
                                                        bf16_t* y, int HW, int G, int pix_per_chunk, int silu,
                                                        const float* partial, int npart, float inv_n, float eps, float* mean_rstd_out) {
   const int C = s.C1 + s.C2, cpg = C / G;
   const GNMap m(C);
   const int b = blockIdx.y;
-  __shared__ float mr_lds[FUSED ? 512 : 2];
+  __shared__ float mr_lds[512];
   if (FUSED) {
     gn_block_sum_partials(partial + (size_t)b * npart * G * 2, npart, G, [&](int g, double sm, double sq) {
       const double mean = sm * inv_n;
@@ -168,87 +265,153 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNSrc s, const float* mea
       mr_lds[g * 2] = mf; mr_lds[g * 2 + 1] = rf;
       if (blockIdx.x == 0) { mean_rstd_out[((size_t)b * G + g) * 2] = mf; mean_rstd_out[((size_t)b * G + g) * 2 + 1] = rf; }
     });
+  } else {
+    gn_stage_stats(mr_lds, mean_rstd + (size_t)b * G * 2, G);
   }
   const int p0 = blockIdx.x * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
-  float sc[GN_MAXS][8], sh[GN_MAXS][8];
-#pragma unroll
-  for (int i = 0; i < GN_MAXS; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sc[i][j] = 0.f; sh[i][j] = 0.f;
-      if (m.ch[i] >= 0) {
-        const int c = m.ch[i] * 8 + j, g = c / cpg;
-        const float mean = FUSED ? mr_lds[g * 2] : mean_rstd[((size_t)b * G + g) * 2];
-        const float rstd = FUSED ? mr_lds[g * 2 + 1] : mean_rstd[((size_t)b * G + g) * 2 + 1];
-        sc[i][j] = rstd * gamma[c];
-        sh[i][j] = beta[c] - mean * sc[i][j];
-      }
-    }
-  for (int p = p0 + m.pg; p < p1; p += m.PG) {
-    const size_t pix = (size_t)b * HW + p;
-#pragma unroll
-    for (int i = 0; i < GN_MAXS; ++i)
-      if (m.ch[i] >= 0) {
-        float f[8];
-        unpack8(gn_load8(s, pix, m.ch[i] * 8), f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float z = f[j] * sc[i][j] + sh[i][j];
-          f[j] = silu ? silu_f(z) : z;
-        }
-        *(uint4*)(y + pix * C + m.ch[i] * 8) = pack8(f);
-      }
-  }
+  if (p0 >= p1) return;
+  gn_apply_body<NS>(s, m, b, HW, C, cpg, p0, p1, mr_lds, gamma, beta, y, silu);
 }
 
 // Backward pass 1.  With z = gamma*xhat + beta, dz = dy * act'(z):
 //   partial[b][chunk][g] = ( sum_c gamma_c * sum_p dz , sum_c gamma_c * sum_p dz*xhat )
 //   chan_partial[b][chunk][c] = ( sum_p dz , sum_p dz*xhat )      (optional: gives dbeta, dgamma)
+template <int NS>
+__device__ __forceinline__ void gn_bwd_stats_body(const GNSrc& s, const GNMap& m, int b, int HW, int C, int cpg, int p0, int p1, const float* mr,
+                                                  const bf16_t* dy, const float* gamma, const float* beta, int silu, float (*s1)[8], float (*s2)[8]) {
+  constexpr int U = NS == 1 ? GN_U : GN_U / 2;
+  const GNSlots<NS> sl(m);
+  float mu[NS][8], rs[NS][8], ga[NS][8], be[NS][8];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    ld8f(gamma + sl.c[i], ga[i]);
+    ld8f(beta + sl.c[i], be[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (sl.c[i] + j) / cpg;
+      mu[i][j] = mr[g * 2]; rs[i][j] = mr[g * 2 + 1];
+    }
+  }
+  for (int p = p0 + m.pg; p < p1; p += U * m.PG) {
+    uint4 vx[U][NS], vd[U][NS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t pix = (size_t)b * HW + min(p + u * m.PG, p1 - 1);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        vx[u][i] = gn_load8u(s, pix, sl.c[i]);
+        vd[u][i] = *(const uint4*)(dy + pix * C + sl.c[i]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = p + u * m.PG < p1;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        float f[8], d[8];
+        unpack8(vx[u][i], f);
+        unpack8(vd[u][i], d);
+        const float w = (in && sl.act[i]) ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (f[j] - mu[i][j]) * rs[i][j];
+          float dz = d[j] * w;
+          if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
+          s1[i][j] += dz; s2[i][j] += dz * xh;
+        }
+      }
+    }
+  }
+}
+template <int NS>
 __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(GNSrc s, const bf16_t* dy, const float* mean_rstd, const float* gamma,
                                                            const float* beta, int HW, int G, int pix_per_chunk, int silu,
                                                            float* partial, float* chan_partial) {
   extern __shared__ float lds[];
+  __shared__ float mr_lds[512];
   const int C = s.C1 + s.C2, cpg = C / G;
   const GNMap m(C);
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int p0 = chunk * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
-  float s1[GN_MAXS][8], s2[GN_MAXS][8], mu[GN_MAXS][8], rs[GN_MAXS][8], ga[GN_MAXS][8], be[GN_MAXS][8];
+  gn_stage_stats(mr_lds, mean_rstd + (size_t)b * G * 2, G);
+  float s1[GN_MAXS][8], s2[GN_MAXS][8];
 #pragma unroll
   for (int i = 0; i < GN_MAXS; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      s1[i][j] = s2[i][j] = 0.f; mu[i][j] = rs[i][j] = ga[i][j] = be[i][j] = 0.f;
-      if (m.ch[i] >= 0) {
-        const int c = m.ch[i] * 8 + j, g = c / cpg;
-        mu[i][j] = mean_rstd[((size_t)b * G + g) * 2]; rs[i][j] = mean_rstd[((size_t)b * G + g) * 2 + 1];
-        ga[i][j] = gamma[c]; be[i][j] = beta[c];
-      }
-    }
-  for (int p = p0 + m.pg; p < p1; p += m.PG) {
-    const size_t pix = (size_t)b * HW + p;
-#pragma unroll
-    for (int i = 0; i < GN_MAXS; ++i)
-      if (m.ch[i] >= 0) {
-        float f[8], d[8];
-        unpack8(gn_load8(s, pix, m.ch[i] * 8), f);
-        unpack8(*(const uint4*)(dy + pix * C + m.ch[i] * 8), d);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xh = (f[j] - mu[i][j]) * rs[i][j];
-          float dz = d[j];
-          if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
-          s1[i][j] += dz; s2[i][j] += dz * xh;
-        }
-      }
-  }
+    for (int j = 0; j < 8; ++j) s1[i][j] = s2[i][j] = 0.f;
+  if (p0 < p1) gn_bwd_stats_body<NS>(s, m, b, HW, C, cpg, p0, p1, mr_lds, dy, gamma, beta, silu, s1, s2);
   gn_block_reduce(m, C, G, s1, s2, lds, gamma, partial + ((size_t)b * gridDim.x + chunk) * G * 2,
                   chan_partial ? chan_partial + ((size_t)b * gridDim.x + chunk) * C * 2 : nullptr);
 }
 
 // Backward pass 2: dx = rstd * (dz*gamma - (S1 + xhat*S2)/n) (+ add), split into dx1 | dx2 along C
 // gsum == nullptr: (S1, S2) are reduced from bwd_stats' chunk partials in the prologue (no finalize launch)
+template <int NS>
+__device__ __forceinline__ void gn_bwd_apply_body(const GNSrc& s, const GNMap& m, int b, int HW, int C, int cpg, int p0, int p1, const float* mr,
+                                                  const float* gs, float inv_n, const bf16_t* dy, const float* gamma, const float* beta,
+                                                  const bf16_t* add1, const bf16_t* add2, bf16_t* dx1, bf16_t* dx2, int silu) {
+  constexpr int U = NS == 1 ? GN_U : GN_U / 2;
+  const GNSlots<NS> sl(m);
+  float mu[NS][8], rs[NS][8], ga[NS][8], be[NS][8], g1[NS][8], g2[NS][8];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    ld8f(gamma + sl.c[i], ga[i]);
+    ld8f(beta + sl.c[i], be[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = (sl.c[i] + j) / cpg;
+      mu[i][j] = mr[g * 2]; rs[i][j] = mr[g * 2 + 1];
+      g1[i][j] = gs[g * 2] * inv_n; g2[i][j] = gs[g * 2 + 1] * inv_n;
+    }
+  }
+  // the gradient arriving through the block's shortcut: a zero page stands in when a source has none, so that the load stays unconditional
+  const bool has1 = add1 != nullptr, has2 = add2 != nullptr;
+  for (int p = p0 + m.pg; p < p1; p += U * m.PG) {
+    uint4 vx[U][NS], vd[U][NS], va[U][NS];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t pix = (size_t)b * HW + min(p + u * m.PG, p1 - 1);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int c = sl.c[i];
+        vx[u][i] = gn_load8u(s, pix, c);
+        vd[u][i] = *(const uint4*)(dy + pix * C + c);
+        const bool first = c < s.C1;
+        const bf16_t* ap = first ? (has1 ? add1 + pix * s.C1 + c : dy + pix * C + c) : (has2 ? add2 + pix * s.C2 + (c - s.C1) : dy + pix * C + c);
+        va[u][i] = *(const uint4*)ap;            // (a duplicate of the dy load, ignored below, when that source has no shortcut gradient)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool in = p + u * m.PG < p1;
+      const size_t pix = (size_t)b * HW + p + u * m.PG;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int c = sl.c[i];
+        const bool first = c < s.C1;
+        const float wa = (first ? has1 : has2) ? 1.f : 0.f;
+        float f[8], d[8], a[8];
+        unpack8(vx[u][i], f);
+        unpack8(vd[u][i], d);
+        unpack8(va[u][i], a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (f[j] - mu[i][j]) * rs[i][j];
+          float dz = d[j];
+          if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
+          f[j] = rs[i][j] * (dz * ga[i][j] - g1[i][j] - xh * g2[i][j]) + a[j] * wa;
+        }
+        if (in && sl.act[i]) {
+          if (first) *(uint4*)(dx1 + pix * s.C1 + c) = pack8(f);
+          else *(uint4*)(dx2 + pix * s.C2 + (c - s.C1)) = pack8(f);
+        }
+      }
+    }
+  }
+}
+template <int NS>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t* dy, const float* mean_rstd, const float* gsum,
                                                            const float* gamma, const float* beta, const bf16_t* add1,
                                                            const bf16_t* add2, bf16_t* dx1, bf16_t* dx2, int HW, int G,
@@ -257,46 +420,17 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t
   const GNMap m(C);
   const int b = blockIdx.y;
   __shared__ float gs_lds[512];
+  __shared__ float mr_lds[512];
   if (!gsum) gn_block_sum_partials(partial + (size_t)b * gridDim.x * G * 2, gridDim.x, G,
                                    [&](int g, double sm, double sq) { gs_lds[g * 2] = (float)sm; gs_lds[g * 2 + 1] = (float)sq; });
+  else {
+    for (int i = threadIdx.x; i < G * 2; i += 256) gs_lds[i] = gsum[(size_t)b * G * 2 + i];
+  }
+  gn_stage_stats(mr_lds, mean_rstd + (size_t)b * G * 2, G);
   const int p0 = blockIdx.x * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
-  float mu[GN_MAXS][8], rs[GN_MAXS][8], ga[GN_MAXS][8], be[GN_MAXS][8], g1[GN_MAXS][8], g2[GN_MAXS][8];
-#pragma unroll
-  for (int i = 0; i < GN_MAXS; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      mu[i][j] = rs[i][j] = ga[i][j] = be[i][j] = g1[i][j] = g2[i][j] = 0.f;
-      if (m.ch[i] >= 0) {
-        const int c = m.ch[i] * 8 + j, g = c / cpg;
-        mu[i][j] = mean_rstd[((size_t)b * G + g) * 2]; rs[i][j] = mean_rstd[((size_t)b * G + g) * 2 + 1];
-        ga[i][j] = gamma[c]; be[i][j] = beta[c];
-        g1[i][j] = (gsum ? gsum[((size_t)b * G + g) * 2] : gs_lds[g * 2]) * inv_n;
-        g2[i][j] = (gsum ? gsum[((size_t)b * G + g) * 2 + 1] : gs_lds[g * 2 + 1]) * inv_n;
-      }
-    }
-  for (int p = p0 + m.pg; p < p1; p += m.PG) {
-    const size_t pix = (size_t)b * HW + p;
-#pragma unroll
-    for (int i = 0; i < GN_MAXS; ++i)
-      if (m.ch[i] >= 0) {
-        const int c = m.ch[i] * 8;
-        float f[8], d[8], a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        unpack8(gn_load8(s, pix, c), f);
-        unpack8(*(const uint4*)(dy + pix * C + c), d);
-        if (c < s.C1) { if (add1) unpack8(*(const uint4*)(add1 + pix * s.C1 + c), a); }
-        else if (add2) unpack8(*(const uint4*)(add2 + pix * s.C2 + (c - s.C1)), a);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xh = (f[j] - mu[i][j]) * rs[i][j];
-          float dz = d[j];
-          if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
-          f[j] = rs[i][j] * (dz * ga[i][j] - g1[i][j] - xh * g2[i][j]) + a[j];
-        }
-        if (c < s.C1) *(uint4*)(dx1 + pix * s.C1 + c) = pack8(f);
-        else *(uint4*)(dx2 + pix * s.C2 + (c - s.C1)) = pack8(f);
-      }
-  }
+  if (p0 >= p1) return;
+  gn_bwd_apply_body<NS>(s, m, b, HW, C, cpg, p0, p1, mr_lds, gs_lds, inv_n, dy, gamma, beta, add1, add2, dx1, dx2, silu);
 }
 
 size_t gn_lds_bytes(int C) {
@@ -310,80 +444,104 @@ size_t gn_lds_bytes(int C) {
 // ------------------------------------------------------------------------------------------------
 constexpr int LN_MAXC = 3;
 
+// Every load of a row (x, gamma, beta / x, dy, gamma, add) is issued up front from one basic block: chunk indices past the row end are
+// clamped to the last chunk (loads unconditional, contributions and stores masked) — the guarded loads of the first version each
+// cost a full memory round trip (3 + 3 in a row for D = 1280: 17 us for the ViT's 4112-row LayerNorms at 1.2 TB/s).
+template <int NC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
                                                      float* mean_rstd, int M, int D, float eps) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const int nc = D >> 3;
-  float v[LN_MAXC][8];
+  uint4 raw[NC];
+  float ga[NC][8], be[NC][8];
+  int cc[NC];
+  bool act[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + i * 64;
+    act[i] = c < nc;
+    cc[i] = act[i] ? c : nc - 1;
+    raw[i] = *(const uint4*)(x + (size_t)row * D + cc[i] * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) { ld8f(gamma + cc[i] * 8, ga[i]); ld8f(beta + cc[i] * 8, be[i]); }
+  float v[NC][8];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int c = lane + i * 64;
-    if (c < nc) {
-      unpack8(*(const uint4*)(x + (size_t)row * D + c * 8), v[i]);
+  for (int i = 0; i < NC; ++i) {
+    unpack8(raw[i], v[i]);
+    if (act[i])
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[i][j];
-    }
   }
   const float mean = wave_sum(s) / D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int c = lane + i * 64;
-    if (c < nc)
+  for (int i = 0; i < NC; ++i)
+    if (act[i])
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
-  }
   const float rstd = rsqrtf(wave_sum(q) / D + eps);
   if (lane == 0 && mean_rstd) { mean_rstd[(size_t)row * 2] = mean; mean_rstd[(size_t)row * 2 + 1] = rstd; }
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int c = lane + i * 64;
-    if (c < nc) {
-      float o[8];
+  for (int i = 0; i < NC; ++i) {
+    float o[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gamma[c * 8 + j] + beta[c * 8 + j];
-      *(uint4*)(y + (size_t)row * D + c * 8) = pack8(o);
-    }
+    for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * ga[i][j] + be[i][j];
+    if (act[i]) *(uint4*)(y + (size_t)row * D + cc[i] * 8) = pack8(o);
   }
 }
 
 // dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
+template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* mean_rstd,
                                                      const bf16_t* add, bf16_t* dx, int M, int D) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const int nc = D >> 3;
-  const float mean = mean_rstd[(size_t)row * 2], rstd = mean_rstd[(size_t)row * 2 + 1];
-  float xh[LN_MAXC][8], dg[LN_MAXC][8];
+  uint4 rx[NC], rd[NC], ra[NC];
+  float ga[NC][8];
+  int cc[NC];
+  bool act[NC];
+  const bf16_t* asrc = add ? add : dy;                       // no residual gradient: alias dy (ignored below), the load stays unconditional
+  const float wa = add ? 1.f : 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + i * 64;
+    act[i] = c < nc;
+    cc[i] = act[i] ? c : nc - 1;
+    const size_t o = (size_t)row * D + cc[i] * 8;
+    rx[i] = *(const uint4*)(x + o);
+    rd[i] = *(const uint4*)(dy + o);
+    ra[i] = *(const uint4*)(asrc + o);
+  }
+  const float2 mr = *(const float2*)(mean_rstd + (size_t)row * 2);
+  const float mean = mr.x, rstd = mr.y;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) ld8f(gamma + cc[i] * 8, ga[i]);
+  float xh[NC][8], dg[NC][8];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int c = lane + i * 64;
-    if (c < nc) {
-      float xv[8], dv[8];
-      unpack8(*(const uint4*)(x + (size_t)row * D + c * 8), xv);
-      unpack8(*(const uint4*)(dy + (size_t)row * D + c * 8), dv);
+  for (int i = 0; i < NC; ++i) {
+    float xv[8], dv[8];
+    unpack8(rx[i], xv);
+    unpack8(rd[i], dv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        xh[i][j] = (xv[j] - mean) * rstd;
-        dg[i][j] = dv[j] * gamma[c * 8 + j];
-        s1 += dg[i][j]; s2 += dg[i][j] * xh[i][j];
-      }
+    for (int j = 0; j < 8; ++j) {
+      xh[i][j] = (xv[j] - mean) * rstd;
+      dg[i][j] = dv[j] * ga[i][j];
+      if (act[i]) { s1 += dg[i][j]; s2 += dg[i][j] * xh[i][j]; }
     }
   }
   s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
 #pragma unroll
-  for (int i = 0; i < LN_MAXC; ++i) {
-    const int c = lane + i * 64;
-    if (c < nc) {
-      float o[8], a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (add) unpack8(*(const uint4*)(add + (size_t)row * D + c * 8), a);
+  for (int i = 0; i < NC; ++i) {
+    float o[8], a[8];
+    unpack8(ra[i], a);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = rstd * (dg[i][j] - s1 - xh[i][j] * s2) + a[j];
-      *(uint4*)(dx + (size_t)row * D + c * 8) = pack8(o);
-    }
+    for (int j = 0; j < 8; ++j) o[j] = rstd * (dg[i][j] - s1 - xh[i][j] * s2) + a[j] * wa;
+    if (act[i]) *(uint4*)(dx + (size_t)row * D + cc[i] * 8) = pack8(o);
   }
 }
 
@@ -446,7 +604,8 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* part,
 int colreduce_splits(int M) { int n = cdiv(M, 1024); return n > 128 ? 128 : (n < 1 ? 1 : n); }
 
 int gn_chunks(int Bn, int HW) {
-  int ch = 1024 / (Bn > 0 ? Bn : 1);
+  static const int target = getenv("E4T_GN_BLOCKS") ? atoi(getenv("E4T_GN_BLOCKS")) : 1024;      // workgroups per launch (tuning knob)
+  int ch = target / (Bn > 0 ? Bn : 1);
   if (ch < 1) ch = 1;
   const int maxch = HW / 8 > 0 ? HW / 8 : 1;
   if (ch > maxch) ch = maxch;
@@ -455,6 +614,9 @@ int gn_chunks(int Bn, int HW) {
 }
 
 }  // namespace
+
+// one 16-byte chunk per thread up to C = 2048, two above (GNMap): the kernels are instantiated per slot count
+#define GN_TWO_SLOTS ((C1 + C2) / 8 > 256)
 
 extern "C" int e4t_groupnorm_num_chunks(int Bn, int HW) { return gn_chunks(Bn, HW); }
 
@@ -482,7 +644,8 @@ extern "C" int e4t_groupnorm_stats(const void* x1, int C1, const void* x2, int C
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
   hipStream_t st = (hipStream_t)stream;
   E4T_LOG_LAUNCH("gn_stats_kernel|B%d HW%d C%d G%d|%.0f|0", Bn, HW, C, G, 2.0 * Bn * (double)HW * C);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
+  if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_stats_kernel<2>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
+  else hipLaunchKernelGGL((gn_stats_kernel<1>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
   E4T_CHECK_LAUNCH("gn_stats_kernel");
   const int BG = Bn * G;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(BG, 4)), dim3(256), 0, st, (const float*)workspace, ch, G, BG,
@@ -498,7 +661,9 @@ extern "C" int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C
   const int ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch);
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
   E4T_LOG_LAUNCH("gn_apply_kernel<false>|B%d HW%d C%d G%d|%.0f|0", Bn, HW, C1 + C2, G, 4.0 * Bn * (double)HW * (C1 + C2));
-  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(ch, Bn), dim3(256), 0, (hipStream_t)stream, s, mean_rstd, gamma, beta, (bf16_t*)y, HW, G, ppc,
+  if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_apply_kernel<false, 2>), dim3(ch, Bn), dim3(256), 0, (hipStream_t)stream, s, mean_rstd, gamma, beta, (bf16_t*)y, HW, G, ppc,
+                     silu, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr);
+  else hipLaunchKernelGGL((gn_apply_kernel<false, 1>), dim3(ch, Bn), dim3(256), 0, (hipStream_t)stream, s, mean_rstd, gamma, beta, (bf16_t*)y, HW, G, ppc,
                      silu, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr);
   E4T_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
@@ -551,7 +716,9 @@ extern "C" int e4t_groupnorm_fwd_cs(const void* x1, int C1, const float* cs1, co
                      (float*)workspace);
   E4T_CHECK_LAUNCH("gn_stats_cols_kernel");
   E4T_LOG_LAUNCH("gn_apply_kernel<true>|B%d HW%d C%d G%d silu%d|%.0f|0", Bn, HW, C, G, silu, 4.0 * Bn * (double)HW * C);
-  hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
+  if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_apply_kernel<true, 2>), dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
+                     (const float*)workspace, npart, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
+  else hipLaunchKernelGGL((gn_apply_kernel<true, 1>), dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
                      (const float*)workspace, npart, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
   E4T_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
@@ -567,10 +734,13 @@ extern "C" int e4t_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2,
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
   hipStream_t st = (hipStream_t)stream;
   E4T_LOG_LAUNCH("gn_stats_kernel|B%d HW%d C%d G%d|%.0f|0", Bn, HW, C, G, 2.0 * Bn * (double)HW * C);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
+  if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_stats_kernel<2>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
+  else hipLaunchKernelGGL((gn_stats_kernel<1>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
   E4T_CHECK_LAUNCH("gn_stats_kernel");
   E4T_LOG_LAUNCH("gn_apply_kernel<true>|B%d HW%d C%d G%d silu%d|%.0f|0", Bn, HW, C, G, silu, 4.0 * Bn * (double)HW * C);
-  hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
+  if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_apply_kernel<true, 2>), dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
+                     (const float*)workspace, ch, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
+  else hipLaunchKernelGGL((gn_apply_kernel<true, 1>), dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
                      (const float*)workspace, ch, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
   E4T_CHECK_LAUNCH("gn_apply_kernel");
   return 0;
@@ -592,11 +762,16 @@ extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2,
   E4T_LOG_LAUNCH("gn_bwd_stats_kernel|B%d HW%d C%d G%d|%.0f|0", Bn, HW, C, G, 4.0 * Bn * (double)HW * C);
   E4T_LOG_LAUNCH("gn_bwd_apply_kernel|B%d HW%d C%d G%d add%d|%.0f|0", Bn, HW, C, G, (add1 != nullptr) + (add2 != nullptr),
                  2.0 * Bn * (double)HW * (3.0 * C + (add1 ? C1 : 0) + (add2 ? C2 : 0)));
-  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, (const bf16_t*)dy, mean_rstd,
+  if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_bwd_stats_kernel<2>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, (const bf16_t*)dy, mean_rstd,
+                     gamma, beta, HW, G, ppc, silu, partial, dgamma_dbeta_partial);
+  else hipLaunchKernelGGL((gn_bwd_stats_kernel<1>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, (const bf16_t*)dy, mean_rstd,
                      gamma, beta, HW, G, ppc, silu, partial, dgamma_dbeta_partial);
   E4T_CHECK_LAUNCH("gn_bwd_stats_kernel");
   (void)gsum;     // (S1, S2) are reduced from the partials inside gn_bwd_apply_kernel: no finalize launch
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ch, Bn), dim3(256), 0, st, s, (const bf16_t*)dy, mean_rstd, (const float*)nullptr, gamma, beta,
+  if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_bwd_apply_kernel<2>), dim3(ch, Bn), dim3(256), 0, st, s, (const bf16_t*)dy, mean_rstd, (const float*)nullptr, gamma, beta,
+                     (const bf16_t*)add1, (const bf16_t*)add2, (bf16_t*)dx1, (bf16_t*)dx2, HW, G, ppc, silu, 1.f / ((float)(C / G) * (float)HW),
+                     (const float*)partial);
+  else hipLaunchKernelGGL((gn_bwd_apply_kernel<1>), dim3(ch, Bn), dim3(256), 0, st, s, (const bf16_t*)dy, mean_rstd, (const float*)nullptr, gamma, beta,
                      (const bf16_t*)add1, (const bf16_t*)add2, (bf16_t*)dx1, (bf16_t*)dx2, HW, G, ppc, silu, 1.f / ((float)(C / G) * (float)HW),
                      (const float*)partial);
   E4T_CHECK_LAUNCH("gn_bwd_apply_kernel");
@@ -608,7 +783,10 @@ extern "C" int e4t_layernorm_fwd(const void* x, const float* gamma, const float*
   E4T_REQUIRE(x && gamma && beta && y && M > 0, "layernorm_fwd: null argument");
   E4T_REQUIRE(D % 8 == 0 && D <= LN_MAXC * 64 * 8, "layernorm: D=%d must be a multiple of 8 and <= 1536", D);
   E4T_LOG_LAUNCH("ln_fwd_kernel|M%d D%d|%.0f|0", M, D, 4.0 * (double)M * D);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, M, D, eps);
+  const int ncl = cdiv(D / 8, 64);      // 16-byte chunks per lane: the kernels are instantiated per count (no dead loads)
+#define E4T_LN_FWD(NC_) hipLaunchKernelGGL((ln_fwd_kernel<NC_>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, M, D, eps)
+  if (ncl == 1) E4T_LN_FWD(1); else if (ncl == 2) E4T_LN_FWD(2); else E4T_LN_FWD(3);
+#undef E4T_LN_FWD
   E4T_CHECK_LAUNCH("ln_fwd_kernel");
   return 0;
 }
@@ -618,7 +796,10 @@ extern "C" int e4t_layernorm_bwd(const void* x, const void* dy, const float* gam
   E4T_REQUIRE(x && dy && gamma && mean_rstd && dx && M > 0, "layernorm_bwd: null argument");
   E4T_REQUIRE(D % 8 == 0 && D <= LN_MAXC * 64 * 8, "layernorm: D=%d must be a multiple of 8 and <= 1536", D);
   E4T_LOG_LAUNCH("ln_bwd_kernel|M%d D%d add%d|%.0f|0", M, D, add != nullptr, 2.0 * (double)M * D * (add ? 4 : 3));
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (const bf16_t*)add, (bf16_t*)dx, M, D);
+  const int ncl = cdiv(D / 8, 64);
+#define E4T_LN_BWD(NC_) hipLaunchKernelGGL((ln_bwd_kernel<NC_>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (const bf16_t*)add, (bf16_t*)dx, M, D)
+  if (ncl == 1) E4T_LN_BWD(1); else if (ncl == 2) E4T_LN_BWD(2); else E4T_LN_BWD(3);
+#undef E4T_LN_BWD
   E4T_CHECK_LAUNCH("ln_bwd_kernel");
   return 0;
 }

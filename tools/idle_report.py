@@ -1,0 +1,43 @@
+"""From a rocprofv3 kernel trace of bench.py: how much of the timed region is the GPU idle (no kernel of any stream running), per
+phase of the step — tells whether the step is kernel-bound or launch-bound.  usage: idle_report.py TRACE_DIR_OR_CSV [n_last_steps]"""
+import csv, glob, os, re, sys
+path = sys.argv[1]
+if os.path.isdir(path):
+    path = max(glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getsize)
+rows = []
+with open(path, newline="") as fh:
+    for r in csv.DictReader(fh):
+        name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0].replace("void ", "")
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Stream_Id", r.get("Queue_Id", "0"))))
+rows.sort()
+# steps are delimited by adamw_kernel launches
+ad = [i for i, r in enumerate(rows) if r[2].startswith("adamw_kernel")]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+ad = ad[-(n + 1):]
+t0, t1 = rows[ad[0]][1], rows[ad[-1]][1]
+sel = [r for r in rows if r[0] >= t0 and r[1] <= t1]
+busy, cur_s, cur_e = 0, None, None
+gaps = []
+for s, e, name, q in sel:
+    if cur_e is None:
+        cur_s, cur_e = s, e
+    elif s <= cur_e:
+        cur_e = max(cur_e, e)
+    else:
+        busy += cur_e - cur_s
+        gaps.append((s - cur_e, name))
+        cur_s, cur_e = s, e
+busy += cur_e - cur_s
+wall = t1 - t0
+print(f"{n} steps: wall {wall / n / 1e6:.2f} ms/step, some kernel running {busy / n / 1e6:.2f} ms/step, idle {(wall - busy) / n / 1e6:.2f} ms/step ({100 * (wall - busy) / wall:.1f} %), "
+      f"kernels/step {len(sel) / n:.0f}, sum of kernel durations {sum(e - s for s, e, _, _ in sel) / n / 1e6:.2f} ms/step")
+import collections
+by = collections.Counter()
+cnt = collections.Counter()
+for g, name in gaps:
+    by[name] += g; cnt[name] += 1
+print("idle time in front of (kernel that ended the gap), top 25, per step:")
+for name, g in by.most_common(25):
+    print(f"  {g / n / 1e3:8.1f} us  {cnt[name] / n:6.1f} gaps  avg {g / cnt[name] / 1e3:6.1f} us  {name[:70]}")
+big = sorted(gaps, reverse=True)[:10]
+print("largest single gaps (us):", [(round(g / 1e3, 1), nm[:40]) for g, nm in big])
