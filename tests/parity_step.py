@@ -86,12 +86,12 @@ def cases():
         # BASELINE configs[4]: the SD-2.x UNet config at its real widths (heads 5/10/20/20 = dh 64, ctx 1024, linear projections,
         # v-prediction) on 24x24 latents (T = 576 / 144 / 36 / 9: ragged attention and GEMM tiles), wide 2-layer ViT
         "sd2_real_width": Case("sd2_real_width", dict(orc.SD21_UNET_CONFIG, sample_size=24), boc=SD_BOC, vit_cfg=WIDE_VIT,
-                               text_cfg=wtext(1024, 16), B=2, px=192, lat=24, prediction_type="v_prediction"),
+                               text_cfg=wtext(1024, 16), B=2, px=192, lat=24, prediction_type="v_prediction", cpu_calib=False),
         "tiny_sd2": Case("tiny_sd2", dict(tiny, attention_head_dim=(1, 2, 2, 2), use_linear_projection=True), prediction_type="v_prediction",
                          lat=24, px=96),
         # BASELINE configs[3]: tuning step, every UNet weight trains (3x3 conv wgrad through im2col + TN GEMM), real SD-1.4 widths
         "tuning_real_width": Case("tuning_real_width", dict(orc.SD14_UNET_CONFIG, sample_size=16), boc=SD_BOC, vit_cfg=WIDE_VIT,
-                                  text_cfg=wtext(768, 12), B=2, px=64, lat=16, tuning=True, reg_lambda=0.1),
+                                  text_cfg=wtext(768, 12), B=2, px=64, lat=16, tuning=True, reg_lambda=0.1, cpu_calib=False),
         "tuning_tiny": Case("tuning_tiny", tiny, tuning=True, reg_lambda=0.1, B=3),
         # --unfreeze_clip_vision: backward through the ViT tower at ViT-H width
         "unfrozen_vit": Case("unfrozen_vit", tiny, vit_cfg=WIDE_VIT, unfreeze_vit=True, px=96),
