@@ -90,8 +90,18 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int r
 }
 
 // Write one wave's WM x WN accumulator tile (origin mw, nw) with the fused epilogue.
-template <int WM, int WN, int FM, int FN>
-__device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][FN], bf16_t* smem, int wave, int lane, int mw, int nw) {
+#ifdef DMA_TRACE
+#define WT_STAMP(k) do { if (dt_ptr) dt_ptr[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WT_STAMP(k) do { } while (0)
+#endif
+// GENERAL: the epilogue variant with the exact-GELU activation and the per-row row-bias lookup (rows_per_batch not a multiple of
+// 32).  It is a separate INSTANTIATION, not a branch: inlined next to the plain path its erff expansion over 16 x FM x FN
+// elements set the register allocation of the whole kernel (288 instead of 208 registers in the 128 x 160 tile = one
+// workgroup per CU instead of two).  The launcher picks the variant (launch_gemm).
+template <int WM, int WN, int FM, int FN, bool GENERAL = false>
+__device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][FN], bf16_t* smem, int wave, int lane, int mw, int nw,
+                                           unsigned long long* dt_ptr = nullptr) {
   const int frow = lane & 31, fhi = lane >> 5;
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
   const bool partial = p.ws != nullptr;
@@ -119,57 +129,91 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][
         rbv[i][j] = rb_blocked ? p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col] : 0.f;
       }
     }
+    WT_STAMP(13);
+    // The uniform special cases (GELU epilogue, per-row row-bias lookup) are decided ONCE, outside the 16 x FM x FN element loop: as
+    // per-element `if`s they were two scalar branches per element — the staging of a 32 x 160 wave tile took 8300 of the
+    // workgroup's 32000 cycles on the K = 320 projections (cycle stamps, tools/dma_trace.sh), 1400 without them.
+    const bool rb_slow = p.rowbias && !rb_blocked;
+    if constexpr (!GENERAL) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int cl = j * 32 + frow;
-        const int col = nw + cl;
-        const float add = bv[j] + rbv[i][j];
+        for (int j = 0; j < FN; ++j) {
+          const int cl = j * 32 + frow;
+          const float add = bv[j] + rbv[i][j];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-          float v = acc[i][j][r] * p.alpha + add;
-          if (p.rowbias && !rb_blocked) {      // odd geometry (rows_per_batch not a multiple of 32): per-row lookup
-            const int row = mw + rl;
-            if (row < p.M && col < p.N) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
+          for (int r = 0; r < 16; ++r) {
+            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+            stage[rl * ELD + cl] = f2bf(acc[i][j][r] * p.alpha + add);
           }
-          if (p.flags & E4T_ACT_GELU) v = gelu_f(v);
-          stage[rl * ELD + cl] = f2bf(v);
+          // one fragment at a time: without the fence the scheduler pulls the accumulator reads of ALL fragments (80 AGPR -> VGPR
+          // copies in the 128 x 160 tile) in front of the first write, and the kernel loses one of its two waves per SIMD
+          __builtin_amdgcn_sched_barrier(0);
         }
-      }
+    } else {
+      const bool gelu = (p.flags & E4T_ACT_GELU) != 0;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int cl = j * 32 + frow;
+          const int col = nw + cl;
+          const float add = bv[j] + rbv[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+            float v = acc[i][j][r] * p.alpha + add;
+            if (rb_slow) {      // odd geometry (rows_per_batch not a multiple of 32): per-row lookup
+              const int row = mw + rl;
+              if (row < p.M && col < p.N) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
+            }
+            if (gelu) v = gelu_f(v);
+            stage[rl * ELD + cl] = f2bf(v);
+          }
+        }
+    }
+    WT_STAMP(14);
     __syncthreads();                     // (a wave only reads back its own region; the barrier orders the LDS traffic)
+    WT_STAMP(15);
     constexpr int CPR = WN / 8;          // 16-byte chunks per row
     constexpr int NIT = (WM * CPR + 63) / 64;
     bf16_t* Cb = (bf16_t*)p.C;
     const bf16_t* Rb = (const bf16_t*)p.residual;
-    uint4 rres[NIT];
-    if (Rb) {
+    // residual chunks are fetched RB at a time ahead of their use (all loads of a batch back to back); RB = 4 keeps the 128 x 160
+    // kernel at 2 waves per SIMD (10 chunks in flight at once cost 40 VGPRs and one of the two resident workgroups per CU)
+    constexpr int RB = NIT < 4 ? NIT : 4;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = min(it * 64 + lane, WM * CPR - 1);
-        const int rl = idx / CPR, cch = idx - rl * CPR;
-        const int row = min(mw + rl, p.M - 1), col = min(nw + cch * 8, p.N - 8);
-        rres[it] = *(const uint4*)(Rb + (size_t)row * p.ldr + col);
-      }
-    }
+    for (int it0 = 0; it0 < NIT; it0 += RB) {
+      uint4 rres[RB];
+      if (Rb) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = it * 64 + lane;
-      const int rl = idx / CPR, cch = idx - rl * CPR;
-      const int row = mw + rl, col = nw + cch * 8;
-      if (idx < WM * CPR && row < p.M && col < p.N) {
-        uint4 v = *(const uint4*)(stage + rl * ELD + cch * 8);
-        if (Rb) {
-          float a[8], b[8];
-          unpack8(v, a);
-          unpack8(rres[it], b);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) a[k] += b[k];
-          v = pack8(a);
-          if (p.colstats) *(uint4*)(stage + rl * ELD + cch * 8) = v;      // the statistics are those of the FINAL values
+        for (int u = 0; u < RB; ++u) {
+          const int idx = min((it0 + u) * 64 + lane, WM * CPR - 1);
+          const int rl = idx / CPR, cch = idx - rl * CPR;
+          const int row = min(mw + rl, p.M - 1), col = min(nw + cch * 8, p.N - 8);
+          rres[u] = *(const uint4*)(Rb + (size_t)row * p.ldr + col);
         }
-        *(uint4*)(Cb + (size_t)row * p.ldc + col) = v;
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int it = it0 + u;
+        if (it >= NIT) break;
+        const int idx = it * 64 + lane;
+        const int rl = idx / CPR, cch = idx - rl * CPR;
+        const int row = mw + rl, col = nw + cch * 8;
+        if (idx < WM * CPR && row < p.M && col < p.N) {
+          uint4 v = *(const uint4*)(stage + rl * ELD + cch * 8);
+          if (Rb) {
+            float a[8], b[8];
+            unpack8(v, a);
+            unpack8(rres[u], b);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += b[k];
+            v = pack8(a);
+            if (p.colstats) *(uint4*)(stage + rl * ELD + cch * 8) = v;      // the statistics are those of the FINAL values
+          }
+          *(uint4*)(Cb + (size_t)row * p.ldc + col) = v;
+        }
       }
     }
     if (p.colstats) {
@@ -366,7 +410,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  write_tile<WM, WN, FM, FN>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
+  write_tile<WM, WN, FM, FN, true>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,8 +471,20 @@ __device__ __forceinline__ void loop_barrier() {
   __builtin_amdgcn_s_barrier();
 }
 
-template <int BM, int BN, int WGM, int WGN, int MODE, int NSTAGE>
+#ifdef DMA_TRACE    // debug builds only (tools/dma_trace.sh): cycle stamps of wave 0 of every 8th workgroup
+__device__ unsigned long long g_dma_trace[128 * 16];
+#define DT(slot) do { if (dt_on) g_dma_trace[dt_wg * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DT(slot) do { } while (0)
+#endif
+template <int BM, int BN, int WGM, int WGN, int MODE, int NSTAGE, bool GENERAL = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
+#ifdef DMA_TRACE
+  const int dt_lin = blockIdx.y * gridDim.x + blockIdx.x;
+  const int dt_wg = dt_lin >> 3;
+  const bool dt_on = (threadIdx.x == 0) && (dt_lin & 7) == 0 && dt_wg < 128 && blockIdx.z == 0;
+  DT(0);
+#endif
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int NW = WGM * WGN;                       // waves per workgroup (4 or 8)
@@ -607,6 +663,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
 #pragma unroll
   for (int s = 0; s < LOOK; ++s)
     if (kt_begin + s < kt_end) issue_tile(kt_begin + s, smem + s * TILE);
+  DT(1);
 
   auto body = [&](auto CURc, int kt) {
     constexpr int CUR = decltype(CURc)::value;
@@ -617,6 +674,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
     else if (LOOK >= 2 && kt + 1 < kt_end) wait_vmcnt<NA + NB>();
     else wait_vmcnt<0>();
     loop_barrier();                                    // ... everyone's have; and everyone finished reading slot NXT
+#ifdef DMA_TRACE
+    if (kt - kt_begin < 8) DT(2 + (kt - kt_begin));
+#endif
     const bf16_t* st = smem + CUR * TILE;
     bf16x8 af[2][FM], bfr[2][FN];
 #pragma unroll
@@ -652,9 +712,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
     if (kt < kt_end) { body(std::integral_constant<int, 1>{}, kt); ++kt; }
     if (NSTAGE >= 4 && kt < kt_end) { body(std::integral_constant<int, 2 % NSTAGE>{}, kt); ++kt; }
   }
+  DT(10);
   __syncthreads();   // all fragment reads done before the epilogue reuses the LDS
-  write_tile<WM, WN, FM, FN>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
+  DT(11);
+#ifdef DMA_TRACE
+  write_tile<WM, WN, FM, FN, GENERAL>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN, dt_on ? g_dma_trace + dt_wg * 16 : nullptr);
+#else
+  write_tile<WM, WN, FM, FN, GENERAL>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
+#endif
+  DT(12);
 }
+#ifdef DMA_TRACE
+}  // namespace
+extern "C" int e4t_debug_dma_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dma_trace), sizeof(g_dma_trace));
+}
+namespace {
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // 256 x 256 x 64 "ping-pong" variant for the big, K-deep shapes (VAE / 1280-channel convs, FF GEMMs).
@@ -1397,6 +1471,9 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     if (auto_pt && allow256 && tile == 128 && p.N % 128 == 0 && p.N % 256 != 0 && p.K % BK == 0 && nkt >= 16 && !p.A2 &&
         (long long)cdiv(p.M, 512) * (p.N / 128) * batch >= 512) tile = 640;
   }
+  // epilogues with the exact GELU or a per-row row-bias lookup run the GENERAL instantiation, built for the 2-stage 64 / 128 / 160 tiles
+  const bool general_epi = (p.flags & E4T_ACT_GELU) || (p.rowbias && p.rows_per_batch % 32 != 0);
+  if (general_epi) { stages = 2; if (tile == 256 || tile == 512 || tile == 640) tile = 128; }
   if (tile == 256 && !allow256) tile = 128;
   if (tile == 160 && !allow256) tile = 128;
   if (tile == 640 && (!allow256 || p.A2)) tile = 128;
@@ -1508,6 +1585,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                        else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 4>), grid, block, 0, st, p); }    \
     else if (stages == 3) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 3>), grid, block, 0, st, p); \
                             else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 3>), grid, block, 0, st, p); } \
+    else if (general_epi) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 2, true>), grid, block, 0, st, p); \
+                            else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 2, true>), grid, block, 0, st, p); } \
     else { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 2>), grid, block, 0, st, p);            \
            else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 2>), grid, block, 0, st, p); }               \
   } while (0)

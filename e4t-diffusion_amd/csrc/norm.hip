@@ -204,7 +204,7 @@ __device__ __forceinline__ void gn_block_sum_partials(const float* partial_b /* 
 // y = act(gamma * (x - mean) * rstd + beta), written as one contiguous (B*HW, C) bf16 matrix
 // FUSED: mean / rstd are finalised from the stats kernel's chunk partials in the prologue (and written to mean_rstd_out by
 // chunk 0 of every batch entry for the backward) instead of by a separate finalize launch.
-template <int NS>
+template <int NS, bool SILU>
 __device__ __forceinline__ void gn_apply_body(const GNSrc& s, const GNMap& m, int b, int HW, int C, int cpg, int p0, int p1, const float* mr,
                                               const float* gamma, const float* beta, bf16_t* y, int silu) {
   constexpr int U = NS == 1 ? GN_U : GN_U / 2;
@@ -241,7 +241,7 @@ __device__ __forceinline__ void gn_apply_body(const GNSrc& s, const GNMap& m, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float z = f[j] * sc[i][j] + sh[i][j];
-          f[j] = silu ? silu_f(z) : z;
+          f[j] = SILU ? silu_f(z) : z;
         }
         if (in && sl.act[i]) *(uint4*)(y + pix * C + sl.c[i]) = pack8(f);
       }
@@ -271,13 +271,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNSrc s, const float* mea
   const int p0 = blockIdx.x * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
   if (p0 >= p1) return;
-  gn_apply_body<NS>(s, m, b, HW, C, cpg, p0, p1, mr_lds, gamma, beta, y, silu);
+  if (silu) gn_apply_body<NS, true>(s, m, b, HW, C, cpg, p0, p1, mr_lds, gamma, beta, y, silu);
+  else gn_apply_body<NS, false>(s, m, b, HW, C, cpg, p0, p1, mr_lds, gamma, beta, y, silu);
 }
 
 // Backward pass 1.  With z = gamma*xhat + beta, dz = dy * act'(z):
 //   partial[b][chunk][g] = ( sum_c gamma_c * sum_p dz , sum_c gamma_c * sum_p dz*xhat )
 //   chan_partial[b][chunk][c] = ( sum_p dz , sum_p dz*xhat )      (optional: gives dbeta, dgamma)
-template <int NS>
+template <int NS, bool SILU>
 __device__ __forceinline__ void gn_bwd_stats_body(const GNSrc& s, const GNMap& m, int b, int HW, int C, int cpg, int p0, int p1, const float* mr,
                                                   const bf16_t* dy, const float* gamma, const float* beta, int silu, float (*s1)[8], float (*s2)[8]) {
   constexpr int U = NS == 1 ? GN_U : GN_U / 2;
@@ -317,7 +318,7 @@ __device__ __forceinline__ void gn_bwd_stats_body(const GNSrc& s, const GNMap& m
         for (int j = 0; j < 8; ++j) {
           const float xh = (f[j] - mu[i][j]) * rs[i][j];
           float dz = d[j] * w;
-          if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
+          if (SILU) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
           s1[i][j] += dz; s2[i][j] += dz * xh;
         }
       }
@@ -341,14 +342,17 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(GNSrc s, const bf16_t
   for (int i = 0; i < GN_MAXS; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[i][j] = s2[i][j] = 0.f;
-  if (p0 < p1) gn_bwd_stats_body<NS>(s, m, b, HW, C, cpg, p0, p1, mr_lds, dy, gamma, beta, silu, s1, s2);
+  if (p0 < p1) {
+    if (silu) gn_bwd_stats_body<NS, true>(s, m, b, HW, C, cpg, p0, p1, mr_lds, dy, gamma, beta, silu, s1, s2);
+    else gn_bwd_stats_body<NS, false>(s, m, b, HW, C, cpg, p0, p1, mr_lds, dy, gamma, beta, silu, s1, s2);
+  }
   gn_block_reduce(m, C, G, s1, s2, lds, gamma, partial + ((size_t)b * gridDim.x + chunk) * G * 2,
                   chan_partial ? chan_partial + ((size_t)b * gridDim.x + chunk) * C * 2 : nullptr);
 }
 
 // Backward pass 2: dx = rstd * (dz*gamma - (S1 + xhat*S2)/n) (+ add), split into dx1 | dx2 along C
 // gsum == nullptr: (S1, S2) are reduced from bwd_stats' chunk partials in the prologue (no finalize launch)
-template <int NS>
+template <int NS, bool SILU>
 __device__ __forceinline__ void gn_bwd_apply_body(const GNSrc& s, const GNMap& m, int b, int HW, int C, int cpg, int p0, int p1, const float* mr,
                                                   const float* gs, float inv_n, const bf16_t* dy, const float* gamma, const float* beta,
                                                   const bf16_t* add1, const bf16_t* add2, bf16_t* dx1, bf16_t* dx2, int silu) {
@@ -400,7 +404,7 @@ __device__ __forceinline__ void gn_bwd_apply_body(const GNSrc& s, const GNMap& m
         for (int j = 0; j < 8; ++j) {
           const float xh = (f[j] - mu[i][j]) * rs[i][j];
           float dz = d[j];
-          if (silu) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
+          if (SILU) dz *= dsilu_f(ga[i][j] * xh + be[i][j]);
           f[j] = rs[i][j] * (dz * ga[i][j] - g1[i][j] - xh * g2[i][j]) + a[j] * wa;
         }
         if (in && sl.act[i]) {
@@ -430,7 +434,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t
   const int p0 = blockIdx.x * pix_per_chunk;
   int p1 = p0 + pix_per_chunk; if (p1 > HW) p1 = HW;
   if (p0 >= p1) return;
-  gn_bwd_apply_body<NS>(s, m, b, HW, C, cpg, p0, p1, mr_lds, gs_lds, inv_n, dy, gamma, beta, add1, add2, dx1, dx2, silu);
+  if (silu) gn_bwd_apply_body<NS, true>(s, m, b, HW, C, cpg, p0, p1, mr_lds, gs_lds, inv_n, dy, gamma, beta, add1, add2, dx1, dx2, silu);
+  else gn_bwd_apply_body<NS, false>(s, m, b, HW, C, cpg, p0, p1, mr_lds, gs_lds, inv_n, dy, gamma, beta, add1, add2, dx1, dx2, silu);
 }
 
 size_t gn_lds_bytes(int C) {
