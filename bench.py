@@ -153,9 +153,9 @@ def main():
             a = agg.setdefault(key, [0.0, 0.0, 0.0, 0])
             a[0] += fl; a[1] += nb; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
         hip.prof = None
-        names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, 2>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, 2>",
-                 "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, 2>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2>",
-                 "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, 2>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, 2>",
+        names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, 2, false, 64>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, 2, false, 64>",
+                 "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, 2, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2, false, 64>",
+                 "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, 2, false, 64>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, 2, false, 64>",
                  "conv512": "gemm_pp_kernel<1>", "gemm512": "gemm_pp_kernel<0>", "gemm_tn": "gemm_tn_kernel",
                  "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true>", "gn_fwd_2pass": "gn_stats_kernel + gn_apply_kernel<true>",
                  "gn_bwd": "gn_bwd_stats_kernel + gn_bwd_apply_kernel", "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel",

@@ -477,7 +477,11 @@ __device__ unsigned long long g_dma_trace[128 * 16];
 #else
 #define DT(slot) do { } while (0)
 #endif
-template <int BM, int BN, int WGM, int WGN, int MODE, int NSTAGE, bool GENERAL = false>
+// KT: K-tile width.  64 (128-byte rows, 8 rows per 1-KiB DMA piece) or 32 (64-byte rows, 16 rows per piece): the same LDS budget
+// then holds twice the stages — 4 x 16 KiB instead of 2 x 32 KiB for the 128 x 128 tile, still two workgroups per CU — i.e. 3 K-tiles
+// (48 KiB) instead of 1 (32 KiB) in flight per workgroup.  The cycle-stamp trace (tools/dma_trace.sh) shows the K loop of every
+// shape waiting ~1700-2500 cycles per 64-wide tile for a DMA issued one iteration earlier against ~500 cycles of MFMA work.
+template <int BM, int BN, int WGM, int WGN, int MODE, int NSTAGE, bool GENERAL = false, int KT = 64>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
 #ifdef DMA_TRACE
   const int dt_lin = blockIdx.y * gridDim.x + blockIdx.x;
@@ -488,11 +492,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int FM = WM / 32, FN = WN / 32;
   constexpr int NW = WGM * WGN;                       // waves per workgroup (4 or 8)
-  constexpr int NA = BM / 8 / NW, NB = (BN / 8 + NW - 1) / NW;   // 1-KiB DMA pieces (8 rows) per wave per K-tile (B: last wave may own fewer)
+  constexpr int SL = KT / 8;                          // 16-byte slots per LDS row
+  constexpr int RPP = 512 / KT;                       // rows per 1-KiB DMA piece (8 or 16)
+  constexpr int NA = BM / RPP / NW, NB = (BN / RPP + NW - 1) / NW;   // pieces per wave per K-tile (B: last wave may own fewer)
   constexpr int LOOK = NSTAGE - 1;                    // K-tiles in flight
-  constexpr int TILE = (BM + BN) * BK;          // elements per LDS buffer
+  constexpr int TILE = (BM + BN) * KT;          // elements per LDS buffer
   static_assert(NA >= 1 && NB >= 1 && (NW == 4 || NW == 8) && (NSTAGE >= 2 && NSTAGE <= 4), "bad tile configuration");
-  static_assert(NSTAGE == 2 || (BN / 8) % NW == 0, "counted vmcnt needs the same piece count in every wave");
+  static_assert(NSTAGE == 2 || (BN / RPP) % NW == 0, "counted vmcnt needs the same piece count in every wave");
+  static_assert((KT == 64 || KT == 32) && BM % (RPP * NW) == 0, "bad K-tile width");
 
   __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * TILE];
 
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   xcd_tile(tile_x, tile_y, p.group_m);
   const int m0 = tile_y * BM, n0 = tile_x * BN;
 
-  const int nkt = (p.K + BK - 1) / BK;
+  const int nkt = (p.K + KT - 1) / KT;
   const int bz = blockIdx.z / p.splitk, sz = blockIdx.z - bz * p.splitk;
   p.A += bz * p.strideA;
   if (p.A2) p.A2 += bz * p.strideA;
@@ -513,8 +520,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
     if (p.flags & E4T_OUT_F32) p.C = (float*)p.C + bz * p.strideC;
     else p.C = (bf16_t*)p.C + bz * p.strideC;
   }
-  const int kt_begin = sz * p.ktiles_per_split;
-  int kt_end = kt_begin + p.ktiles_per_split;
+  const int kt_begin = sz * p.ktiles_per_split * (BK / KT);          // the launcher counts 64-wide tiles
+  int kt_end = kt_begin + p.ktiles_per_split * (BK / KT);
   if (kt_end > nkt) kt_end = nkt;
 
   // Operands are addressed through buffer resources (buffer_load ... lds): a 32-bit per-lane byte offset that changes only
@@ -526,7 +533,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFF0000u;          // >= every extent the launcher accepts
-  const int lrow = lane >> 3, lslot = lane & 7;   // position of this lane inside a 1-KiB piece
+  const int lrow = lane / SL, lslot = lane % SL;   // position of this lane inside a 1-KiB piece
+  auto swz = [](int r) { return KT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };      // source-side XOR swizzle of the 16-byte slots
 
   // rows this lane feeds: piece q = wave*NA + i covers tile rows q*8 .. q*8+7
   long long a_base[NA];
@@ -534,10 +542,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   bool a_ok[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int r = (wave * NA + i) * 8 + lrow;
+    const int r = (wave * NA + i) * RPP + lrow;
     const int gr = m0 + r;
     a_ok[i] = gr < p.M;
-    a_kc[i] = (lslot ^ ((r >> 1) & 7)) * 8;       // logical k offset (elements) this lane fetches for that row
+    a_kc[i] = (lslot ^ swz(r)) * 8;       // logical k offset (elements) this lane fetches for that row
     if (MODE == 0) {
       a_base[i] = (long long)gr; a_oy[i] = a_ox[i] = 0;
     } else {
@@ -554,10 +562,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   bool b_ok[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int r = (wave * NB + i) * 8 + lrow;
+    const int r = (wave * NB + i) * RPP + lrow;
     const int gn = n0 + r;
     b_ok[i] = gn < p.N && r < BN;
-    b_kc[i] = (lslot ^ ((r >> 1) & 7)) * 8;
+    b_kc[i] = (lslot ^ swz(r)) * 8;
     b_row[i] = (unsigned)(((size_t)(b_ok[i] ? gn : 0) * p.ldb + b_kc[i]) * 2);
   }
 
@@ -616,21 +624,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
     }
   };
   auto issue_tile = [&](int kt, bf16_t* buf) {
-    const int k0 = kt * BK;
+    const int k0 = kt * KT;
     bf16_t* As = buf;
-    bf16_t* Bs = buf + BM * BK;
-    const bool ragged = k0 + BK > p.K;                                      // wave-uniform conditions
+    bf16_t* Bs = buf + BM * KT;
+    const bool ragged = k0 + KT > p.K;                                      // wave-uniform conditions
     const bool fresh_a = kt == kt_begin || ragged || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0);
     if (fresh_a) place_a(k0);
-    else a_so += BK * 2;
+    else a_so += KT * 2;
     if (kt == kt_begin || ragged) place_b(k0);
-    else b_so += BK * 2;
+    else b_so += KT * 2;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[i], a_so, As + (wave * NA + i) * 512);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      if ((BN / 8) % NW == 0 || wave * NB + i < BN / 8)
+      if ((BN / RPP) % NW == 0 || wave * NB + i < BN / RPP)
         buf_dma16(rs_b, b_vo[i], b_so, Bs + (wave * NB + i) * 512);
   };
 
@@ -645,18 +653,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   const int frow = lane & 31, fhi = lane >> 5;
   // fragment offsets inside a stage (elements), one per (fragment, k-step): computed once; the stage base is a
   // compile-time constant of the unrolled loop below, so every ds_read_b128 is "vgpr + immediate"
-  int a_off[FM][BK / 16], b_off[FN][BK / 16];
+  int a_off[FM][KT / 16], b_off[FN][KT / 16];
 #pragma unroll
-  for (int ks = 0; ks < BK / 16; ++ks) {
+  for (int ks = 0; ks < KT / 16; ++ks) {
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int r = wm * WM + i * 32 + frow;
-      a_off[i][ks] = r * BK + (((ks * 2 + fhi) ^ ((r >> 1) & 7)) * 8);
+      a_off[i][ks] = r * KT + (((ks * 2 + fhi) ^ swz(r)) * 8);
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       const int r = wn * WN + j * 32 + frow;
-      b_off[j][ks] = BM * BK + r * BK + (((ks * 2 + fhi) ^ ((r >> 1) & 7)) * 8);
+      b_off[j][ks] = BM * KT + r * KT + (((ks * 2 + fhi) ^ swz(r)) * 8);
     }
   }
   // prologue: LOOK tiles in flight
@@ -685,9 +693,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
     for (int j = 0; j < FN; ++j) bfr[0][j] = *(const bf16x8*)(st + b_off[j][0]);
     if (kt + LOOK < kt_end) issue_tile(kt + LOOK, smem + NXT * TILE);   // after the first fragment reads are in flight
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
+    for (int ks = 0; ks < KT / 16; ++ks) {
       const int c = ks & 1, n = c ^ 1;
-      if (ks + 1 < BK / 16) {
+      if (ks + 1 < KT / 16) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) af[n][i] = *(const bf16x8*)(st + a_off[i][ks + 1]);
 #pragma unroll
@@ -1445,7 +1453,9 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   const int nkt = cdiv(p.K, BK);
   // --- tile selection: fill >= ~1.5 waves of the 256 CUs with 128x128 tiles, else drop to 64x64 ---
   int stages = 2;                         // LDS stages of the 64 / 128 / 160 DMA kernels; a hint of 3128 / 4160 / ... forces 3 or 4
+  bool kt32 = false;                      // 5128 / 5064: the 32-wide K-tile variant (4 stages in the LDS of 2 x 64-wide ones)
   if (tile_hint >= 3000 && tile_hint < 5000) { stages = tile_hint / 1000; tile_hint %= 1000; }
+  else if (tile_hint >= 5000 && tile_hint < 6000) { kt32 = true; stages = 4; tile_hint %= 1000; }
   int tile = tile_hint;
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
@@ -1473,7 +1483,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   }
   // epilogues with the exact GELU or a per-row row-bias lookup run the GENERAL instantiation, built for the 2-stage 64 / 128 / 160 tiles
   const bool general_epi = (p.flags & E4T_ACT_GELU) || (p.rowbias && p.rows_per_batch % 32 != 0);
-  if (general_epi) { stages = 2; if (tile == 256 || tile == 512 || tile == 640) tile = 128; }
+  if (general_epi) { stages = 2; kt32 = false; if (tile == 256 || tile == 512 || tile == 640) tile = 128; }
+  if (kt32 && tile != 128 && tile != 64) kt32 = false;
   if (tile == 256 && !allow256) tile = 128;
   if (tile == 160 && !allow256) tile = 128;
   if (tile == 640 && (!allow256 || p.A2)) tile = 128;
@@ -1547,12 +1558,12 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     if (p.flags & E4T_ACCUM) by += osz * (double)p.M * p.N;
     const char* sym = !(use_dma && buf_ok) ? "gemm_kernel" : tile == 512 ? (conv ? "gemm_pp_kernel<1>" : "gemm_pp_kernel<0>")
                       : tile == 640 ? (conv ? "gemm_pt_kernel<1>" : "gemm_pt_kernel<0>")
-                      : tile == 256 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3>")
+                      : tile == 256 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 64>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 64>")
                       : nullptr;
     char symbuf[64];
     if (!sym) {
-      snprintf(symbuf, sizeof(symbuf), "gemm_dma_kernel<%d, %d, %d, %d, %d, %d>", tile == 64 ? 64 : 128, tile == 160 ? 160 : tile, tile == 64 ? 2 : 4,
-               tile == 160 ? 1 : 2, conv ? 1 : 0, stages);
+      snprintf(symbuf, sizeof(symbuf), "gemm_dma_kernel<%d, %d, %d, %d, %d, %d, %s, %d>", tile == 64 ? 64 : 128, tile == 160 ? 160 : tile, tile == 64 ? 2 : 4,
+               tile == 160 ? 1 : 2, conv ? 1 : 0, stages, general_epi ? "true" : "false", kt32 ? 32 : 64);      // as rocprofv3 prints the symbol
       sym = symbuf;
     }
     if (conv) E4T_LOG_LAUNCH("%s|conv mode%d %dx%d->%dx%d Cin%d Cout%d M%d splitk%d|%.0f|%.0f", sym, p.mode, p.Hin, p.Win, p.Hout, p.Wout, p.Cin, p.N,
@@ -1592,7 +1603,15 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   } while (0)
       // 128x128: 8 waves (wave tile 32x64): ~4 waves/SIMD at 2 workgroups/CU hide the DMA/LDS latency that the 4-wave
       // version of the same tile exposed (measured +5..18 % on every E4T shape, 8192^3: 956 -> 980 TF)
-      if (tile == 160) E4T_LAUNCH_DMA(128, 160, 4, 1, 256);
+      if (kt32 && tile == 128) {
+        block = dim3(512);
+        if (conv) hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 4, 2, 1, 4, false, 32>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 4, 2, 0, 4, false, 32>), grid, block, 0, st, p);
+      } else if (kt32 && tile == 64) {
+        block = dim3(256);
+        if (conv) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 1, 4, false, 32>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 0, 4, false, 32>), grid, block, 0, st, p);
+      } else if (tile == 160) E4T_LAUNCH_DMA(128, 160, 4, 1, 256);
       else if (tile == 128) E4T_LAUNCH_DMA(128, 128, 4, 2, 512);
       else E4T_LAUNCH_DMA(64, 64, 2, 2, 256);
 #undef E4T_LAUNCH_DMA

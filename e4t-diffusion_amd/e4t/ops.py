@@ -67,8 +67,8 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch, conv=False):
     """Mirror of launch_gemm()'s tile / split-K heuristic (csrc/gemm.hip) -> workspace bytes it will want."""
     cd = lambda a, b: (a + b - 1) // b
     nkt = cd(K, 64)
-    if 3000 <= tile < 5000:
-        tile %= 1000            # thousands digit = forced LDS stage count (3128, 4160, ...)
+    if 3000 <= tile < 6000:
+        tile %= 1000            # thousands digit = forced LDS stage count (3128, 4160, ...) / 32-wide K-tiles (5128)
     if tile not in (64, 128, 256, 160, 512, 640):
         t128 = cd(M, 128) * cd(N, 128) * nb
         tile = 128 if (t128 >= 256 or (nkt >= 32 and t128 >= 64)) else 64
@@ -152,7 +152,7 @@ class HipBackend:
     @staticmethod
     def _tile(M, N, K, nb, tile, conv=False):
         """Mirror of launch_gemm()'s tile choice (csrc/gemm.hip), used only to label bench.py's per-kernel timings."""
-        if 3000 <= tile < 5000:
+        if 3000 <= tile < 6000:
             tile %= 1000
         if tile in (64, 128, 256, 160, 512, 640):
             return tile

@@ -8,5 +8,5 @@ for f in core gemm attention norm wo elementwise image; do
 done
 cp ../e4t/libe4t_hip.so /tmp/libe4t_hip.so.bak
 hipcc --offload-arch=gfx950 -shared -fPIC /tmp/dtobj/*.o -o ../e4t/libe4t_hip.so
-python $GRAFT_REPO_ROOT/tools/dma_trace.py "$@"
+python $GRAFT_REPO_ROOT/tools/dma_trace.py "$@"; if [ -n "$TRACE2" ]; then python $GRAFT_REPO_ROOT/tools/dma_trace.py $TRACE2; fi; if [ -n "$TRACE3" ]; then python $GRAFT_REPO_ROOT/tools/dma_trace.py $TRACE3; fi
 cp /tmp/libe4t_hip.so.bak ../e4t/libe4t_hip.so
