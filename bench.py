@@ -157,8 +157,8 @@ def main():
                  "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, 2, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2, false, 64>",
                  "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, 2, false, 64>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, 2, false, 64>",
                  "conv512": "gemm_pp_kernel<1>", "gemm512": "gemm_pp_kernel<0>", "gemm_tn": "gemm_tn_kernel",
-                 "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true>", "gn_fwd_2pass": "gn_stats_kernel + gn_apply_kernel<true>",
-                 "gn_bwd": "gn_bwd_stats_kernel + gn_bwd_apply_kernel", "ln_fwd": "ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel",
+                 "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true, *>", "gn_fwd_2pass": "gn_stats_kernel<*> + gn_apply_kernel<true, *>",
+                 "gn_bwd": "gn_bwd_stats_kernel<*> + gn_bwd_apply_kernel<*>", "ln_fwd": "ln_fwd_kernel<*>", "ln_bwd": "ln_bwd_kernel<*>",
                  "geglu_fwd": "geglu_fwd_kernel", "geglu_bwd": "geglu_bwd_kernel", "adamw": "adamw_kernel"}
         # HBM bytes per launch of each kernel symbol from the TCC counters: collected offline with tools/profile_round.sh on this
         # very command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 as
@@ -173,8 +173,21 @@ def main():
                 if line.startswith("#") or line.startswith("kernel,"):
                     continue
                 parts = line.rsplit(",", 4)
-                traffic_tab[parts[0]] = float(parts[4])
+                traffic_tab[parts[0].strip('"')] = (int(parts[1]), float(parts[4]))
         RIDGE = MFMA_PEAK / HBM_PEAK                 # 312 FLOP/B: below it a kernel cannot be MFMA-bound
+
+        def op_traffic(key):
+            """HBM bytes per launch of the op: one symbol -> its row; an op that always launches one kernel of each of several
+            templated symbols ("a<*> + b<*>") -> sum of their bytes over the launches of the first.  The two GroupNorm forward
+            paths share gn_apply_kernel<true, *>, so the symbol table cannot split them (per-shape table does): None."""
+            name = names.get(key, key)
+            if key in ("gn_fwd_colstats", "gn_fwd_2pass"):
+                return None
+            parts = [q.strip() for q in name.split("+")]
+            rows = [[v for k, v in traffic_tab.items() if (k.startswith(q[:-2]) if q.endswith("*>") else k == q)] for q in parts]
+            if not all(rows):
+                return None
+            return sum(n * b for r in rows for n, b in r) / sum(n for n, _ in rows[0])
 
         def entry(key):
             fl, nb, sec, n = agg[key]
@@ -187,7 +200,7 @@ def main():
                 d.update(bound="hbm", achieved=nb / sec / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=nb / sec / HBM_PEAK)
                 if fl:
                     d["mfma_frac"] = fl / sec / MFMA_PEAK
-            d["traffic"] = traffic_tab.get(names.get(key))
+            d["traffic"] = op_traffic(key)
             if d["traffic"]:
                 d["traffic_over_algorithmic"] = d["traffic"] / (nb / n)
             return d

@@ -648,7 +648,7 @@ extern "C" int e4t_groupnorm_stats(const void* x1, int C1, const void* x2, int C
   E4T_REQUIRE(workspace && ws_bytes >= (size_t)Bn * ch * G * 2 * sizeof(float), "groupnorm_stats: workspace too small");
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
   hipStream_t st = (hipStream_t)stream;
-  E4T_LOG_LAUNCH("gn_stats_kernel|B%d HW%d C%d G%d|%.0f|0", Bn, HW, C, G, 2.0 * Bn * (double)HW * C);
+  E4T_LOG_LAUNCH("gn_stats_kernel<%d>|B%d HW%d C%d G%d|%.0f|0", GN_TWO_SLOTS ? 2 : 1, Bn, HW, C, G, 2.0 * Bn * (double)HW * C);
   if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_stats_kernel<2>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
   else hipLaunchKernelGGL((gn_stats_kernel<1>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
   E4T_CHECK_LAUNCH("gn_stats_kernel");
@@ -665,7 +665,7 @@ extern "C" int e4t_groupnorm_apply(const void* x1, int C1, const void* x2, int C
   E4T_REQUIRE(mean_rstd && gamma && beta && y, "groupnorm_apply: null argument");
   const int ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch);
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
-  E4T_LOG_LAUNCH("gn_apply_kernel<false>|B%d HW%d C%d G%d|%.0f|0", Bn, HW, C1 + C2, G, 4.0 * Bn * (double)HW * (C1 + C2));
+  E4T_LOG_LAUNCH("gn_apply_kernel<false, %d>|B%d HW%d C%d G%d|%.0f|0", GN_TWO_SLOTS ? 2 : 1, Bn, HW, C1 + C2, G, 4.0 * Bn * (double)HW * (C1 + C2));
   if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_apply_kernel<false, 2>), dim3(ch, Bn), dim3(256), 0, (hipStream_t)stream, s, mean_rstd, gamma, beta, (bf16_t*)y, HW, G, ppc,
                      silu, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr);
   else hipLaunchKernelGGL((gn_apply_kernel<false, 1>), dim3(ch, Bn), dim3(256), 0, (hipStream_t)stream, s, mean_rstd, gamma, beta, (bf16_t*)y, HW, G, ppc,
@@ -720,7 +720,7 @@ extern "C" int e4t_groupnorm_fwd_cs(const void* x1, int C1, const float* cs1, co
   hipLaunchKernelGGL(gn_stats_cols_kernel, dim3(npart, Bn), dim3(256), (size_t)C * 2 * sizeof(float), st, cs1, C1, cs2, C2, nblk, nblk / npart, G,
                      (float*)workspace);
   E4T_CHECK_LAUNCH("gn_stats_cols_kernel");
-  E4T_LOG_LAUNCH("gn_apply_kernel<true>|B%d HW%d C%d G%d silu%d|%.0f|0", Bn, HW, C, G, silu, 4.0 * Bn * (double)HW * C);
+  E4T_LOG_LAUNCH("gn_apply_kernel<true, %d>|B%d HW%d C%d G%d silu%d|%.0f|0", GN_TWO_SLOTS ? 2 : 1, Bn, HW, C, G, silu, 4.0 * Bn * (double)HW * C);
   if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_apply_kernel<true, 2>), dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
                      (const float*)workspace, npart, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
   else hipLaunchKernelGGL((gn_apply_kernel<true, 1>), dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
@@ -738,11 +738,11 @@ extern "C" int e4t_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2,
   E4T_REQUIRE(workspace && ws_bytes >= (size_t)Bn * ch * G * 2 * sizeof(float), "groupnorm_fwd: workspace too small");
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
   hipStream_t st = (hipStream_t)stream;
-  E4T_LOG_LAUNCH("gn_stats_kernel|B%d HW%d C%d G%d|%.0f|0", Bn, HW, C, G, 2.0 * Bn * (double)HW * C);
+  E4T_LOG_LAUNCH("gn_stats_kernel<%d>|B%d HW%d C%d G%d|%.0f|0", GN_TWO_SLOTS ? 2 : 1, Bn, HW, C, G, 2.0 * Bn * (double)HW * C);
   if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_stats_kernel<2>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
   else hipLaunchKernelGGL((gn_stats_kernel<1>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, HW, G, ppc, (float*)workspace);
   E4T_CHECK_LAUNCH("gn_stats_kernel");
-  E4T_LOG_LAUNCH("gn_apply_kernel<true>|B%d HW%d C%d G%d silu%d|%.0f|0", Bn, HW, C, G, silu, 4.0 * Bn * (double)HW * C);
+  E4T_LOG_LAUNCH("gn_apply_kernel<true, %d>|B%d HW%d C%d G%d silu%d|%.0f|0", GN_TWO_SLOTS ? 2 : 1, Bn, HW, C, G, silu, 4.0 * Bn * (double)HW * C);
   if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_apply_kernel<true, 2>), dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
                      (const float*)workspace, ch, 1.f / ((float)(C / G) * (float)HW), eps, mean_rstd);
   else hipLaunchKernelGGL((gn_apply_kernel<true, 1>), dim3(ch, Bn), dim3(256), 0, st, s, (const float*)nullptr, gamma, beta, (bf16_t*)y, HW, G, ppc, silu,
@@ -764,8 +764,8 @@ extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2,
   float* gsum = partial + (size_t)Bn * ch * G * 2;
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
   hipStream_t st = (hipStream_t)stream;
-  E4T_LOG_LAUNCH("gn_bwd_stats_kernel|B%d HW%d C%d G%d|%.0f|0", Bn, HW, C, G, 4.0 * Bn * (double)HW * C);
-  E4T_LOG_LAUNCH("gn_bwd_apply_kernel|B%d HW%d C%d G%d add%d|%.0f|0", Bn, HW, C, G, (add1 != nullptr) + (add2 != nullptr),
+  E4T_LOG_LAUNCH("gn_bwd_stats_kernel<%d>|B%d HW%d C%d G%d|%.0f|0", GN_TWO_SLOTS ? 2 : 1, Bn, HW, C, G, 4.0 * Bn * (double)HW * C);
+  E4T_LOG_LAUNCH("gn_bwd_apply_kernel<%d>|B%d HW%d C%d G%d add%d|%.0f|0", GN_TWO_SLOTS ? 2 : 1, Bn, HW, C, G, (add1 != nullptr) + (add2 != nullptr),
                  2.0 * Bn * (double)HW * (3.0 * C + (add1 ? C1 : 0) + (add2 ? C2 : 0)));
   if (GN_TWO_SLOTS) hipLaunchKernelGGL((gn_bwd_stats_kernel<2>), dim3(ch, Bn), dim3(256), gn_lds_bytes(C), st, s, (const bf16_t*)dy, mean_rstd,
                      gamma, beta, HW, G, ppc, silu, partial, dgamma_dbeta_partial);
@@ -787,8 +787,8 @@ extern "C" int e4t_layernorm_fwd(const void* x, const float* gamma, const float*
                                  float eps, e4t_stream stream) {
   E4T_REQUIRE(x && gamma && beta && y && M > 0, "layernorm_fwd: null argument");
   E4T_REQUIRE(D % 8 == 0 && D <= LN_MAXC * 64 * 8, "layernorm: D=%d must be a multiple of 8 and <= 1536", D);
-  E4T_LOG_LAUNCH("ln_fwd_kernel|M%d D%d|%.0f|0", M, D, 4.0 * (double)M * D);
   const int ncl = cdiv(D / 8, 64);      // 16-byte chunks per lane: the kernels are instantiated per count (no dead loads)
+  E4T_LOG_LAUNCH("ln_fwd_kernel<%d>|M%d D%d|%.0f|0", ncl < 3 ? ncl : 3, M, D, 4.0 * (double)M * D);
 #define E4T_LN_FWD(NC_) hipLaunchKernelGGL((ln_fwd_kernel<NC_>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, M, D, eps)
   if (ncl == 1) E4T_LN_FWD(1); else if (ncl == 2) E4T_LN_FWD(2); else E4T_LN_FWD(3);
 #undef E4T_LN_FWD
@@ -800,8 +800,8 @@ extern "C" int e4t_layernorm_bwd(const void* x, const void* dy, const float* gam
                                  int M, int D, e4t_stream stream) {
   E4T_REQUIRE(x && dy && gamma && mean_rstd && dx && M > 0, "layernorm_bwd: null argument");
   E4T_REQUIRE(D % 8 == 0 && D <= LN_MAXC * 64 * 8, "layernorm: D=%d must be a multiple of 8 and <= 1536", D);
-  E4T_LOG_LAUNCH("ln_bwd_kernel|M%d D%d add%d|%.0f|0", M, D, add != nullptr, 2.0 * (double)M * D * (add ? 4 : 3));
   const int ncl = cdiv(D / 8, 64);
+  E4T_LOG_LAUNCH("ln_bwd_kernel<%d>|M%d D%d add%d|%.0f|0", ncl < 3 ? ncl : 3, M, D, add != nullptr, 2.0 * (double)M * D * (add ? 4 : 3));
 #define E4T_LN_BWD(NC_) hipLaunchKernelGGL((ln_bwd_kernel<NC_>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean_rstd, (const bf16_t*)add, (bf16_t*)dx, M, D)
   if (ncl == 1) E4T_LN_BWD(1); else if (ncl == 2) E4T_LN_BWD(2); else E4T_LN_BWD(3);
 #undef E4T_LN_BWD
