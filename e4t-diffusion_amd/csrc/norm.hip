@@ -452,53 +452,79 @@ constexpr int LN_MAXC = 3;
 // Every load of a row (x, gamma, beta / x, dy, gamma, add) is issued up front from one basic block: chunk indices past the row end are
 // clamped to the last chunk (loads unconditional, contributions and stores masked) — the guarded loads of the first version each
 // cost a full memory round trip (3 + 3 in a row for D = 1280: 17 us for the ViT's 4112-row LayerNorms at 1.2 TB/s).
-template <int NC>
+// One wave normalises R rows at once (a block = 4 waves = 4R rows): the forward has a single 2-byte stream to read, so with one
+// row per wave the bytes in flight per CU (occupancy x one 16-B load per lane) cover only about a third of the HBM
+// latency-bandwidth product — measured 3.0 TB/s algorithmic at M65536 D320 against 5.9 TB/s for the backward of the same
+// tensor, which has three streams in flight.  R rows = R independent load / reduce chains per wave.
+template <int NC, int R>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
                                                      float* mean_rstd, int M, int D, float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R, lane = threadIdx.x & 63;
+  if (row0 >= M) return;
   const int nc = D >> 3;
-  uint4 raw[NC];
+  uint4 raw[R][NC];
   float ga[NC][8], be[NC][8];
-  int cc[NC];
+  int cc[NC], rr[R];
   bool act[NC];
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = lane + i * 64;
     act[i] = c < nc;
     cc[i] = act[i] ? c : nc - 1;
-    raw[i] = *(const uint4*)(x + (size_t)row * D + cc[i] * 8);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    rr[r] = row0 + r < M ? row0 + r : M - 1;          // ragged last wave: re-read the last row, store nothing
+#pragma unroll
+    for (int i = 0; i < NC; ++i) raw[r][i] = *(const uint4*)(x + (size_t)rr[r] * D + cc[i] * 8);
   }
 #pragma unroll
   for (int i = 0; i < NC; ++i) { ld8f(gamma + cc[i] * 8, ga[i]); ld8f(beta + cc[i] * 8, be[i]); }
-  float v[NC][8];
-  float s = 0.f;
+  float mean[R], rstd[R];
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    unpack8(raw[i], v[i]);
-    if (act[i])
+  for (int r = 0; r < R; ++r) {
+    float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[i][j];
+    for (int i = 0; i < NC; ++i) {
+      float v[8];
+      unpack8(raw[r][i], v);
+      if (act[i])
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    mean[r] = s;
   }
-  const float mean = wave_sum(s) / D;
-  float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < NC; ++i)
-    if (act[i])
+  for (int r = 0; r < R; ++r) mean[r] = wave_sum(mean[r]) / D;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
-  const float rstd = rsqrtf(wave_sum(q) / D + eps);
-  if (lane == 0 && mean_rstd) { mean_rstd[(size_t)row * 2] = mean; mean_rstd[(size_t)row * 2 + 1] = rstd; }
+  for (int r = 0; r < R; ++r) {
+    float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    float o[8];
+    for (int i = 0; i < NC; ++i) {
+      float v[8];
+      unpack8(raw[r][i], v);
+      if (act[i])
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * ga[i][j] + be[i][j];
-    if (act[i]) *(uint4*)(y + (size_t)row * D + cc[i] * 8) = pack8(o);
+        for (int j = 0; j < 8; ++j) { const float d = v[j] - mean[r]; q += d * d; }
+    }
+    rstd[r] = q;
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(wave_sum(rstd[r]) / D + eps);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const bool live = row0 + r < M;
+    if (lane == 0 && mean_rstd && live) { mean_rstd[(size_t)rr[r] * 2] = mean[r]; mean_rstd[(size_t)rr[r] * 2 + 1] = rstd[r]; }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      float v[8], o[8];
+      unpack8(raw[r][i], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (v[j] - mean[r]) * rstd[r] * ga[i][j] + be[i][j];
+      if (act[i] && live) *(uint4*)(y + (size_t)rr[r] * D + cc[i] * 8) = pack8(o);
+    }
   }
 }
-
-// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
 template <int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* mean_rstd,
                                                      const bf16_t* add, bf16_t* dx, int M, int D) {
@@ -788,9 +814,12 @@ extern "C" int e4t_layernorm_fwd(const void* x, const float* gamma, const float*
   E4T_REQUIRE(x && gamma && beta && y && M > 0, "layernorm_fwd: null argument");
   E4T_REQUIRE(D % 8 == 0 && D <= LN_MAXC * 64 * 8, "layernorm: D=%d must be a multiple of 8 and <= 1536", D);
   const int ncl = cdiv(D / 8, 64);      // 16-byte chunks per lane: the kernels are instantiated per count (no dead loads)
-  E4T_LOG_LAUNCH("ln_fwd_kernel<%d>|M%d D%d|%.0f|0", ncl < 3 ? ncl : 3, M, D, 4.0 * (double)M * D);
-#define E4T_LN_FWD(NC_) hipLaunchKernelGGL((ln_fwd_kernel<NC_>), dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, M, D, eps)
-  if (ncl == 1) E4T_LN_FWD(1); else if (ncl == 2) E4T_LN_FWD(2); else E4T_LN_FWD(3);
+  // rows per wave: 4 / 2 / 2 for 1 / 2 / 3 chunks per lane; small M keeps one row per wave (enough blocks to fill the chip first)
+  const int rpw = (long long)M * ncl < 256 * 4 * 8 ? 1 : ncl == 1 ? 4 : 2;
+  E4T_LOG_LAUNCH("ln_fwd_kernel<%d, %d>|M%d D%d|%.0f|0", ncl < 3 ? ncl : 3, rpw, M, D, 4.0 * (double)M * D);
+#define E4T_LN_FWD(NC_, R_) hipLaunchKernelGGL((ln_fwd_kernel<NC_, R_>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, M, D, eps)
+  if (rpw == 1) { if (ncl == 1) E4T_LN_FWD(1, 1); else if (ncl == 2) E4T_LN_FWD(2, 1); else E4T_LN_FWD(3, 1); }
+  else if (ncl == 1) E4T_LN_FWD(1, 4); else if (ncl == 2) E4T_LN_FWD(2, 2); else E4T_LN_FWD(3, 2);
 #undef E4T_LN_FWD
   E4T_CHECK_LAUNCH("ln_fwd_kernel");
   return 0;

@@ -7,8 +7,18 @@ is propagated: LayerNorm (residual gradient folded in) -> one (tokens x 3w) GEMM
 the residual in its epilogue -> LayerNorm -> fc1 -> quick_gelu / gelu -> fc2 (+ residual).  Trainable weights
 (tuning_e4t.py --train_text_encoder, :145-146): the same kernels; the fused q|k|v weight is re-assembled every forward
 as a differentiable torch.cat of the three parameters, so the TN weight-gradient GEMM's result is split back onto them by
-autograd, and the LayerNorm / bias gradients come from the kernels' parameter-gradient outputs.  There is no other path."""
+autograd, and the LayerNorm / bias gradients come from the kernels' parameter-gradient outputs.  There is no other path.
+
+Launch-bound: at B x 77 tokens every kernel of the 12 (23) layers runs 5-25 us while the Python side of an op costs ~30 us, so in the
+training step the GPU idled ~2.5 ms per step in front of these launches (tools/idle_report.py).  With frozen weights the layer
+stack is therefore captured once per input shape into two HIP graphs (forward | backward w.r.t. the embeddings,
+torch.cuda.make_graphed_callables) and replayed: same kernels, same order, bit-identical results, ~250 launches -> 2 per step.
+E4T_TEXT_GRAPH=0 switches it off; it is off by itself under E4T_LAUNCH_LOG (the per-launch log the roofline tools join with
+rocprofv3's trace only sees launches that go through the host)."""
 from __future__ import annotations
+
+import os
+import warnings
 
 import torch
 from torch import nn
@@ -22,6 +32,8 @@ class CLIPTextModel(_CLIPTextTree):
     def __init__(self, **cfg):
         super().__init__(**cfg)
         self._fused = None
+        self._graphs = {}            # (shape, dtype) -> (fused-weights key, graphed callable)
+        self._graph_ok = os.environ.get("E4T_TEXT_GRAPH", "1") != "0" and not os.environ.get("E4T_LAUNCH_LOG")
 
     def _prepare(self, trainable):
         """Per layer: fused q|k|v weight + bias and the PreparedLinear handles of every projection.  Frozen: detached copies made
@@ -52,6 +64,31 @@ class CLIPTextModel(_CLIPTextTree):
         trainable = torch.is_grad_enabled() and any(p.requires_grad for p in tm.encoder.parameters())
         if inputs_embeds is None:
             inputs_embeds = tm.embeddings.token_embedding(input_ids)
+        if (self._graph_ok and not trainable and inputs_embeds.is_cuda and torch.is_grad_enabled() and inputs_embeds.requires_grad
+                and not torch.cuda.is_current_stream_capturing()):
+            return (self._replay(inputs_embeds),)
+        return (self._encode(inputs_embeds, trainable),)
+
+    def _replay(self, inputs_embeds):
+        """The frozen layer stack as a forward and a backward HIP graph per input shape; re-captured when the weights were
+        reloaded (the graphs read the fused q|k|v copies `_prepare` made).  Outputs are copied out of the graphs' static
+        buffers: the UNet's cross-attention keeps the context until its own backward."""
+        self._prepare(False)
+        sig = (tuple(inputs_embeds.shape), inputs_embeds.dtype)
+        hit = self._graphs.get(sig)
+        if hit is None or hit[0] != self._fused[0]:
+            sample = torch.zeros_like(inputs_embeds).requires_grad_(True)
+            try:
+                fn = torch.cuda.make_graphed_callables(lambda e: self._encode(e, False), (sample,))
+            except Exception as ex:          # capture unsupported in this process: run the launches from the host as before
+                warnings.warn(f"CLIP text encoder: HIP graph capture failed ({type(ex).__name__}: {ex}); running eagerly")
+                self._graph_ok = False
+                return self._encode(inputs_embeds, False)
+            hit = self._graphs[sig] = (self._fused[0], fn)
+        return hit[1](inputs_embeds).clone()
+
+    def _encode(self, inputs_embeds, trainable):
+        tm = self.text_model
         B, S, W = inputs_embeds.shape
         cfg = self.config
         H = cfg["num_heads"]
@@ -68,4 +105,4 @@ class CLIPTextModel(_CLIPTextTree):
             x = Fn.linear(h, l.mlp.fc2.weight, l.mlp.fc2.bias, f["pfc2"], residual=xs)
         fl = tm.final_layer_norm
         y = Fn.layer_norm(x, fl.weight, fl.bias, fl.eps)
-        return (y.view(B, S, W),)
+        return y.view(B, S, W)

@@ -237,7 +237,8 @@ def check_norms(hip, emu, dev):
             out.append((tag + " bwd dx2", rel(dx2, ex2), TOL1))
         out.append((tag + " bwd dgamma", rel(dga, ega), 1e-3))
         out.append((tag + " bwd dbeta", rel(dbe, ebe), 1e-3))
-    for i, (M, D) in enumerate([(37, 64), (1000, 320), (4112, 1280), (300, 768), (128, 1024)]):
+    # the last three take the several-rows-per-wave forward (4 / 2 / 2 rows for 1 / 2 / 3 chunks per lane) with a ragged last wave
+    for i, (M, D) in enumerate([(37, 64), (1000, 320), (4112, 1280), (300, 768), (128, 1024), (8195, 320), (4101, 640), (4111, 1280)]):
         g = gen(160 + i, dev)
         x = rnd(g, M, D, dev=dev) + 0.5
         gamma, beta = rnd(g, D, dtype=f32, dev=dev) * 0.3 + 1.0, rnd(g, D, dtype=f32, dev=dev) * 0.2
