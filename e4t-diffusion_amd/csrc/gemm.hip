@@ -1473,6 +1473,14 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     static const bool no_pp = getenv("E4T_GEMM_NOPP") != nullptr;     // A/B switch
     if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && p.K % BK == 0 && nkt >= (conv ? 16 : 32) && (!p.A2 || p.K1 % BK == 0) &&
         (long long)cdiv(p.M, 256) * (p.N / 256) * batch >= 512) tile = 512;
+    // ... and, with split-K, for the very K-deep shapes of the 16x16 level that give it only 64-255 tiles (1280-channel 3x3
+    // convs, the GEGLU input gradient K = 10240): tools/sweep_step_shapes.py, conv 1280->1280 M4096 128 vs 141 us, conv
+    // 1280->2560 209 vs 290 us, conv 2560->1280 221 vs 265 us, GEMM 4096x1280x10240 126 vs 138 us; at K = 5120 it loses.
+    {
+      const long long tpp = (long long)cdiv(p.M, 256) * (p.N / 256) * batch;
+      if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && p.K % BK == 0 && nkt >= 128 && (!p.A2 || p.K1 % BK == 0) && tpp >= 64 && tpp < 512)
+        tile = 512;
+    }
     // The 512 x 128 variant of the same machine (tile code 640) is NOT chosen automatically: on the shapes it was built for
     // (the VAE's 128-channel convs, K = 1152 = 18 K-tiles) it measured 526 vs 588 TF/s for the 128 x 128 tile — one 160-KiB
     // workgroup per CU leaves nothing to overlap its (large) epilogue and prologue with, and 18 K-tiles do not amortise
@@ -1510,7 +1518,10 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   if (splitk <= 0) {
     splitk = 1;
     const long long tiles = (long long)gx * gy * batch;
-    if (tile >= 128 && tiles < 512 && nkt >= 32) {
+    if (tile == 512 && tiles < 256) {
+      splitk = (int)(256 / tiles);                   // one 512-thread workgroup per CU: fill one round
+      if (splitk > nkt / 16) splitk = nkt / 16;
+    } else if (tile >= 128 && tiles < 512 && nkt >= 32) {
       // 2 workgroups/CU = 512 slots: aim at one full round (<= 256 tiles) or two (measured, tools/sweep_sk.py: 8x8 convs
       // 80 tiles -> 6 splits -16..19 %, 16x16 convs 320 tiles -> 3 splits -10..17 %), keeping >= 16 K-tiles per split
       splitk = (int)((tiles <= 256 ? 512 : 1024) / tiles);

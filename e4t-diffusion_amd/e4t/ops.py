@@ -76,6 +76,9 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch, conv=False):
             tile = 160
         if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= (16 if conv else 32) and cd(M, 256) * (N // 256) * nb >= 512:
             tile = 512
+        tpp = cd(M, 256) * (N // 256) * nb
+        if tile == 128 and N % 256 == 0 and K % 64 == 0 and nkt >= 128 and 64 <= tpp < 512:
+            tile = 512
         if _AUTO_PT and tile == 128 and N % 128 == 0 and N % 256 and K % 64 == 0 and nkt >= 16 and cd(M, 512) * (N // 128) * nb >= 512:
             tile = 640          # opt-in (E4T_GEMM_PT=1): measured slower than 128x128 on the shapes it targets
     if tile in (512, 640) and K % 64:
@@ -84,7 +87,9 @@ def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch, conv=False):
     tiles = cd(N, tn) * cd(M, tm) * nb
     if splitk <= 0:
         splitk = 1
-        if tile >= 128 and tiles < 512 and nkt >= 32:
+        if tile == 512 and tiles < 256:
+            splitk = min(256 // tiles, nkt // 16)
+        elif tile >= 128 and tiles < 512 and nkt >= 32:
             splitk = min((512 if tiles <= 256 else 1024) // tiles, 8, nkt // 16)
             if tiles > 256 and nkt < 128:
                 splitk = 1
@@ -162,6 +167,9 @@ class HipBackend:
         if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
             tile = 160
         if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= (16 if conv else 32) and cd(M, 256) * (N // 256) * nb >= 512:
+            tile = 512
+        tpp = cd(M, 256) * (N // 256) * nb
+        if tile == 128 and N % 256 == 0 and K % 64 == 0 and nkt >= 128 and 64 <= tpp < 512:
             tile = 512
         if _AUTO_PT and tile == 128 and N % 128 == 0 and N % 256 and K % 64 == 0 and cd(K, 64) >= 16 and cd(M, 512) * (N // 128) * nb >= 512:
             tile = 640

@@ -54,6 +54,7 @@ def check_gemm(hip, emu, dev):
         (700, 320, 1280, 256, 2), (900, 320, 384, 160, 1), (300, 480, 128, 160, 2), (513, 200, 72, 160, 1),
         (512, 512, 512, 512, 1), (700, 520, 256, 512, 1), (300, 256, 64, 512, 1), (1000, 300, 128, 512, 1), (513, 1000, 1152, 512, 2),
         (2048, 1280, 1920, 512, 0), (257, 64, 192, 512, 1),
+        (4096, 1280, 10240, 0, 0), (4096, 2560, 8192, 0, 0),       # auto: K-deep, 64-255 tiles of 256 x 256 -> ping-pong + split-K (3 | 1)
         (1024, 128, 512, 640, 1), (700, 128, 1152, 640, 1), (1300, 384, 256, 640, 1), (513, 100, 64, 640, 1), (2048, 128, 2048, 640, 0), (4096, 128, 4096, 640, 3),
     ]
     for i, (M, N, K, tile, sk) in enumerate(cases):
