@@ -169,7 +169,7 @@ class HipBackend:
         if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= (16 if conv else 32) and cd(M, 256) * (N // 256) * nb >= 512:
             tile = 512
         tpp = cd(M, 256) * (N // 256) * nb
-        if tile == 128 and N % 256 == 0 and K % 64 == 0 and nkt >= 128 and 64 <= tpp < 512:
+        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= 128 and 64 <= tpp < 512:
             tile = 512
         if _AUTO_PT and tile == 128 and N % 128 == 0 and N % 256 and K % 64 == 0 and cd(K, 64) >= 16 and cd(M, 512) * (N // 128) * nb >= 512:
             tile = 640
