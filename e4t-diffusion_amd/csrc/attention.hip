@@ -417,8 +417,10 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
 // ================================================================================================
 // backward dK, dV: one wave = 32 keys, loop over query tiles
 // ================================================================================================
-template <int DH>
-__global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_kernel(AttnArgs p) {
+// OCC = workgroups per CU the register allocation is bounded for.  OCC = 3 (dh <= 64 only) gives up the register prefetch of the
+// next Q / dO tile to fit 168 VGPRs: three waves per SIMD instead of two cover the tile loads' latency by occupancy instead.
+template <int DH, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * C::LDE];
   __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * C::LDE];
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? DKV_WAVES : 1)) void attn_bwd_dkv_
       d_next = qq < p.T ? p.Delta[((long long)b * p.H + h) * p.T + qq] : 0.f;
     }
   };
-  constexpr bool PF = DH <= 80;            // register prefetch of the next tile (dh=160 would spill: load in place)
+  constexpr bool PF = DH <= 80 && OCC < 3;  // register prefetch of the next tile (dh=160 would spill: load in place)
   const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(Qb, (unsigned)(((long long)(p.T - 1) * p.ldq + DH) * 2));
   const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(dOb, (unsigned)(((long long)(p.T - 1) * p.ldo + DH) * 2));
   qr.init(p.ldq); dor.init(p.ldo);
@@ -536,17 +538,26 @@ int launch_bwd(const AttnArgs& p, int Bn, hipStream_t st) {
   const long long total = (long long)Bn * p.H * p.T;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
+  static const int dkv_env = getenv("E4T_ATTN_DKV_OCC") ? atoi(getenv("E4T_ATTN_DKV_OCC")) : 0;    // A/B switch (tools/ab_dkv.py)
+  // measured (tools/ab_dkv.py, dh 40, B16 H8 T4096): S = 4096 1.790 vs 1.835 ms per backward with 3 workgroups per CU, S = 77
+  // 0.194 vs 0.167 ms (one workgroup per (batch, head): nothing to cover the un-prefetched tile loads) -> long key ranges only
+  const int dkv_occ = DH > 64 ? 1 : (dkv_env == 3 || dkv_env == 2) ? dkv_env : (p.S >= 2048 ? 3 : DKV_WAVES);
   if (e4t_launch_log_enabled()) {
     const double el = (double)Bn * p.H * DH;      // elements per token row over all heads
     E4T_LOG_LAUNCH("attn_delta_kernel<%d>|B%d H%d T%d|%.0f|0", DH, Bn, p.H, p.T, 4.0 * el * p.T + 4.0 * Bn * p.H * p.T);
-    E4T_LOG_LAUNCH("attn_bwd_dkv_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
+    E4T_LOG_LAUNCH("attn_bwd_dkv_kernel<%d, %d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, dkv_occ, Bn, p.H, p.T, p.S, p.causal,
                    2.0 * el * (2.0 * p.T + 4.0 * p.S) + 8.0 * Bn * p.H * p.T, 8.0 * Bn * p.H * (double)p.T * p.S * DH);
     E4T_LOG_LAUNCH("attn_bwd_dq_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
                    2.0 * el * (3.0 * p.T + 2.0 * p.S) + 8.0 * Bn * p.H * p.T, 6.0 * Bn * p.H * (double)p.T * p.S * DH);
   }
   hipLaunchKernelGGL((attn_delta_kernel<DH>), dim3(blocks), dim3(256), 0, st, p, Bn);
   E4T_CHECK_LAUNCH("attn_delta_kernel");
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH>), dim3(cdiv(p.S, 128), p.H, Bn), dim3(256), 0, st, p);
+  if constexpr (DH <= 64) {
+    if (dkv_occ == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 3>), dim3(cdiv(p.S, 128), p.H, Bn), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, DKV_WAVES>), dim3(cdiv(p.S, 128), p.H, Bn), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 1>), dim3(cdiv(p.S, 128), p.H, Bn), dim3(256), 0, st, p);
+  }
   E4T_CHECK_LAUNCH("attn_bwd_dkv_kernel");
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
   E4T_CHECK_LAUNCH("attn_bwd_dq_kernel");

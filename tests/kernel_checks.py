@@ -161,6 +161,7 @@ def check_attention(hip, emu, dev):
     cases = [  # B, H, T, S, DH (, causal)
         (2, 2, 64, 64, 32), (2, 3, 200, 200, 40), (1, 2, 128, 77, 40), (2, 2, 96, 77, 80), (1, 2, 64, 64, 160),
         (1, 2, 257, 257, 80), (2, 2, 130, 33, 64), (1, 8, 1024, 1024, 40),
+        (1, 2, 300, 2100, 40), (1, 1, 2050, 2050, 64),       # S >= 2048: the dK/dV kernel's three-workgroups-per-CU instantiation, ragged tiles
         (3, 12, 77, 77, 64, True), (2, 3, 200, 200, 40, True), (1, 2, 128, 128, 80, True),      # causal: CLIP text encoder
     ]
     for i, case in enumerate(cases):
