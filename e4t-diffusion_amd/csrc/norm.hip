@@ -438,6 +438,187 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GNSrc s, const bf16_t
   else gn_bwd_apply_body<NS, false>(s, m, b, HW, C, cpg, p0, p1, mr_lds, gs_lds, inv_n, dy, gamma, beta, add1, add2, dx1, dx2, silu);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small maps: one workgroup per (batch, group) SLAB, everything in one launch.
+// At the 8x8 / 16x16 levels a GroupNorm moves 5-20 MB; the chunked kernels above need two launches each way (statistics, then
+// apply with the partials finalised in its prologue) and each is launch latency plus two dependent memory round trips:
+// 8 + 15 us forward and 10 + 12 us backward for 5 MB at 8x8 x 1280 (profiles/r02_roofline_per_shape.csv), ~70 such pairs per
+// step.  A slab of HW x (C/G) <= 10240 elements (<= 40 per thread) fits in registers: load once, reduce over the block in double
+// (same finalisation as gn_finalize_kernel), normalise, store.  Requirements (else the chunked path): C/G % 4 == 0 (8-byte
+// quads), no group straddling the two concat sources, no per-channel parameter gradients wanted in the backward.
+// NI = quads per thread (template: the loads of all NI quads are issued before the first use).
+// ------------------------------------------------------------------------------------------------
+constexpr int GN_SLAB_MAX = 10240;
+
+struct GNSlab {
+  const bf16_t* x;      // source holding this group: x + pix * ldx + cx
+  int ldx, cx;          // row stride of that source, first channel of the group inside it
+  int c0;               // first channel of the group in the concatenated numbering (gamma / beta / y / dy index)
+  bool first;
+  __device__ GNSlab(const GNSrc& s, int g, int cpg) {
+    c0 = g * cpg;
+    first = c0 < s.C1;
+    x = first ? s.x1 : s.x2;
+    ldx = first ? s.C1 : s.C2;
+    cx = first ? c0 : c0 - s.C1;
+  }
+};
+__device__ __forceinline__ double gn_slab_block_sum(double v, double* red) {      // all 256 threads; result broadcast
+  v = wave_sum_f64(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double r = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return r;
+}
+
+template <int NI, bool SILU>
+__global__ __launch_bounds__(256) void gn_slab_fwd_kernel(GNSrc s, const float* gamma, const float* beta, bf16_t* y, float* mean_rstd,
+                                                          int HW, int G, float inv_n, float eps) {
+  __shared__ double red[4];
+  const int C = s.C1 + s.C2, cpg = C / G, q4 = cpg >> 2, items = HW * q4;
+  const int b = blockIdx.y, g = blockIdx.x;
+  const GNSlab sl(s, g, cpg);
+  int row[NI], qd[NI];
+  bool in[NI];
+  uint2 raw[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int it = threadIdx.x + k * 256;
+    in[k] = it < items;
+    const int ic = in[k] ? it : items - 1;
+    row[k] = ic / q4; qd[k] = (ic - row[k] * q4) * 4;
+    raw[k] = *(const uint2*)(sl.x + ((size_t)b * HW + row[k]) * sl.ldx + sl.cx + qd[k]);
+  }
+  float ga[NI][4], be[NI][4];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const float4 g4 = *(const float4*)(gamma + sl.c0 + qd[k]), b4 = *(const float4*)(beta + sl.c0 + qd[k]);
+    ga[k][0] = g4.x; ga[k][1] = g4.y; ga[k][2] = g4.z; ga[k][3] = g4.w;
+    be[k][0] = b4.x; be[k][1] = b4.y; be[k][2] = b4.z; be[k][3] = b4.w;
+  }
+  float sm = 0.f, sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    float f[4];
+    unpack4(raw[k], f);
+    const float w = in[k] ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float v = f[j] * w; sm += v; sq += v * v; }
+  }
+  const double S = gn_slab_block_sum((double)sm, red), Q = gn_slab_block_sum((double)sq, red);
+  const double mean_d = S * inv_n;
+  double var = Q * inv_n - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) { mean_rstd[((size_t)b * G + g) * 2] = mean; mean_rstd[((size_t)b * G + g) * 2 + 1] = rstd; }
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    float f[4];
+    unpack4(raw[k], f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sc = rstd * ga[k][j];
+      const float z = f[j] * sc + (be[k][j] - mean * sc);
+      f[j] = SILU ? silu_f(z) : z;
+    }
+    if (in[k]) *(uint2*)(y + ((size_t)b * HW + row[k]) * C + sl.c0 + qd[k]) = pack4(f);
+  }
+}
+
+// dx = rstd * (dz*gamma - (S1 + xhat*S2)/n) (+ add) with S1 = sum gamma*dz, S2 = sum gamma*dz*xhat over the slab
+template <int NI, bool SILU>
+__global__ __launch_bounds__(256) void gn_slab_bwd_kernel(GNSrc s, const bf16_t* dy, const float* mean_rstd, const float* gamma,
+                                                          const float* beta, const bf16_t* add1, const bf16_t* add2, bf16_t* dx1,
+                                                          bf16_t* dx2, int HW, int G, float inv_n) {
+  __shared__ double red[4];
+  const int C = s.C1 + s.C2, cpg = C / G, q4 = cpg >> 2, items = HW * q4;
+  const int b = blockIdx.y, g = blockIdx.x;
+  const GNSlab sl(s, g, cpg);
+  const bf16_t* add = sl.first ? add1 : add2;
+  bf16_t* dx = sl.first ? dx1 : dx2;
+  const float wa = add ? 1.f : 0.f;
+  int row[NI], qd[NI];
+  bool in[NI];
+  uint2 rx[NI], rd[NI], ra[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int it = threadIdx.x + k * 256;
+    in[k] = it < items;
+    const int ic = in[k] ? it : items - 1;
+    row[k] = ic / q4; qd[k] = (ic - row[k] * q4) * 4;
+    const size_t pix = (size_t)b * HW + row[k];
+    rx[k] = *(const uint2*)(sl.x + pix * sl.ldx + sl.cx + qd[k]);
+    rd[k] = *(const uint2*)(dy + pix * C + sl.c0 + qd[k]);
+    ra[k] = add ? *(const uint2*)(add + pix * sl.ldx + sl.cx + qd[k]) : rd[k];      // wave-uniform select, no shortcut gradient: ignored
+  }
+  const float2 mr = *(const float2*)(mean_rstd + ((size_t)b * G + g) * 2);
+  const float mean = mr.x, rstd = mr.y;
+  float xh[NI][4], gd[NI][4];      // xhat and gamma * dz
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const float4 g4 = *(const float4*)(gamma + sl.c0 + qd[k]), b4 = *(const float4*)(beta + sl.c0 + qd[k]);
+    const float ga[4] = {g4.x, g4.y, g4.z, g4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
+    float f[4], d[4];
+    unpack4(rx[k], f);
+    unpack4(rd[k], d);
+    const float w = in[k] ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[k][j] = (f[j] - mean) * rstd;
+      float dz = d[j];
+      if (SILU) dz *= dsilu_f(ga[j] * xh[k][j] + be[j]);
+      gd[k][j] = dz * ga[j];
+      s1 += gd[k][j] * w; s2 += gd[k][j] * xh[k][j] * w;
+    }
+  }
+  const float g1 = (float)gn_slab_block_sum((double)s1, red) * inv_n, g2 = (float)gn_slab_block_sum((double)s2, red) * inv_n;
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    float a[4], o[4];
+    unpack4(ra[k], a);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = rstd * (gd[k][j] - g1 - xh[k][j] * g2) + a[j] * wa;
+    if (in[k]) *(uint2*)(dx + ((size_t)b * HW + row[k]) * sl.ldx + sl.cx + qd[k]) = pack4(o);
+  }
+}
+
+// quads per thread of the slab kernels for this shape, 0 = not eligible
+int gn_slab_ni(int C1, int C2, int HW, int G) {
+  static const bool off = getenv("E4T_GN_NOSLAB") != nullptr;      // A/B switch
+  const int C = C1 + C2, cpg = C / G;
+  if (off || cpg % 4 != 0 || (C2 > 0 && C1 % cpg != 0) || (long long)HW * cpg > GN_SLAB_MAX) return 0;
+  const int ni = cdiv(HW * (cpg / 4), 256);
+  return ni <= 3 ? 3 : ni <= 5 ? 5 : 10;
+}
+
+
+template <int NI>
+void gn_slab_fwd_launch(const GNSrc& s, const float* gamma, const float* beta, bf16_t* y, float* mean_rstd, int Bn, int HW, int G, float eps,
+                        int silu, hipStream_t st) {
+  const float inv_n = 1.f / ((float)((s.C1 + s.C2) / G) * (float)HW);
+  if (silu) hipLaunchKernelGGL((gn_slab_fwd_kernel<NI, true>), dim3(G, Bn), dim3(256), 0, st, s, gamma, beta, y, mean_rstd, HW, G, inv_n, eps);
+  else hipLaunchKernelGGL((gn_slab_fwd_kernel<NI, false>), dim3(G, Bn), dim3(256), 0, st, s, gamma, beta, y, mean_rstd, HW, G, inv_n, eps);
+}
+int gn_slab_fwd(int ni, const GNSrc& s, const float* gamma, const float* beta, bf16_t* y, float* mean_rstd, int Bn, int HW, int G, float eps,
+                int silu, hipStream_t st) {
+  E4T_LOG_LAUNCH("gn_slab_fwd_kernel<%d, %s>|B%d HW%d C%d G%d|%.0f|0", ni, silu ? "true" : "false", Bn, HW, s.C1 + s.C2, G,
+                 4.0 * Bn * (double)HW * (s.C1 + s.C2));
+  if (ni == 3) gn_slab_fwd_launch<3>(s, gamma, beta, y, mean_rstd, Bn, HW, G, eps, silu, st);
+  else if (ni == 5) gn_slab_fwd_launch<5>(s, gamma, beta, y, mean_rstd, Bn, HW, G, eps, silu, st);
+  else gn_slab_fwd_launch<10>(s, gamma, beta, y, mean_rstd, Bn, HW, G, eps, silu, st);
+  E4T_CHECK_LAUNCH("gn_slab_fwd_kernel");
+  return 0;
+}
+template <int NI>
+void gn_slab_bwd_launch(const GNSrc& s, const bf16_t* dy, const float* mean_rstd, const float* gamma, const float* beta, const bf16_t* add1,
+                        const bf16_t* add2, bf16_t* dx1, bf16_t* dx2, int Bn, int HW, int G, int silu, hipStream_t st) {
+  const float inv_n = 1.f / ((float)((s.C1 + s.C2) / G) * (float)HW);
+  if (silu) hipLaunchKernelGGL((gn_slab_bwd_kernel<NI, true>), dim3(G, Bn), dim3(256), 0, st, s, dy, mean_rstd, gamma, beta, add1, add2, dx1, dx2, HW, G, inv_n);
+  else hipLaunchKernelGGL((gn_slab_bwd_kernel<NI, false>), dim3(G, Bn), dim3(256), 0, st, s, dy, mean_rstd, gamma, beta, add1, add2, dx1, dx2, HW, G, inv_n);
+}
+
 size_t gn_lds_bytes(int C) {
   const int QW = C / 8;
   const int PG = QW <= 256 ? 256 / QW : 1;
@@ -736,6 +917,10 @@ extern "C" int e4t_groupnorm_fwd_cs(const void* x1, int C1, const float* cs1, co
                                     void* workspace, size_t ws_bytes, e4t_stream stream) {
   if (int e = gn_check(x1, C1, x2, C2, Bn, HW, G)) return e;
   E4T_REQUIRE(cs1 && ((cs2 != nullptr) == (C2 > 0)) && gamma && beta && y && mean_rstd && HW % 32 == 0, "groupnorm_fwd_cs: bad arguments");
+  if (const int ni = gn_slab_ni(C1, C2, HW, G)) {      // small map: one launch, the column statistics are not needed
+    GNSrc ss{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
+    return gn_slab_fwd(ni, ss, gamma, beta, (bf16_t*)y, mean_rstd, Bn, HW, G, eps, silu, (hipStream_t)stream);
+  }
   const int C = C1 + C2, ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch), nblk = HW / 32;
   const int npart = ch < nblk ? ch : nblk;                   // chunks of whole 32-pixel blocks
   E4T_REQUIRE(nblk % npart == 0, "groupnorm_fwd_cs: %d blocks do not split into %d chunks", nblk, npart);
@@ -760,6 +945,10 @@ extern "C" int e4t_groupnorm_fwd(const void* x1, int C1, const void* x2, int C2,
                                  e4t_stream stream) {
   if (int e = gn_check(x1, C1, x2, C2, Bn, HW, G)) return e;
   E4T_REQUIRE(gamma && beta && y && mean_rstd, "groupnorm_fwd: null argument");
+  if (const int ni = gn_slab_ni(C1, C2, HW, G)) {
+    GNSrc ss{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
+    return gn_slab_fwd(ni, ss, gamma, beta, (bf16_t*)y, mean_rstd, Bn, HW, G, eps, silu, (hipStream_t)stream);
+  }
   const int C = C1 + C2, ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch);
   E4T_REQUIRE(workspace && ws_bytes >= (size_t)Bn * ch * G * 2 * sizeof(float), "groupnorm_fwd: workspace too small");
   GNSrc s{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
@@ -783,6 +972,16 @@ extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2,
                                  size_t ws_bytes, e4t_stream stream) {
   if (int e = gn_check(x1, C1, x2, C2, Bn, HW, G)) return e;
   E4T_REQUIRE(dy && mean_rstd && gamma && beta && dx1 && ((dx2 != nullptr) == (C2 > 0)) && (!add2 || C2 > 0), "groupnorm_bwd: null argument");
+  if (const int ni = dgamma_dbeta_partial ? 0 : gn_slab_ni(C1, C2, HW, G)) {      // (per-channel parameter gradients: chunked path)
+    GNSrc ss{(const bf16_t*)x1, (const bf16_t*)x2, C1, C2};
+    E4T_LOG_LAUNCH("gn_slab_bwd_kernel<%d, %s>|B%d HW%d C%d G%d add%d|%.0f|0", ni, silu ? "true" : "false", Bn, HW, C1 + C2, G,
+                   (add1 != nullptr) + (add2 != nullptr), 2.0 * Bn * (double)HW * (3.0 * (C1 + C2) + (add1 ? C1 : 0) + (add2 ? C2 : 0)));
+    if (ni == 3) gn_slab_bwd_launch<3>(ss, (const bf16_t*)dy, mean_rstd, gamma, beta, (const bf16_t*)add1, (const bf16_t*)add2, (bf16_t*)dx1, (bf16_t*)dx2, Bn, HW, G, silu, (hipStream_t)stream);
+    else if (ni == 5) gn_slab_bwd_launch<5>(ss, (const bf16_t*)dy, mean_rstd, gamma, beta, (const bf16_t*)add1, (const bf16_t*)add2, (bf16_t*)dx1, (bf16_t*)dx2, Bn, HW, G, silu, (hipStream_t)stream);
+    else gn_slab_bwd_launch<10>(ss, (const bf16_t*)dy, mean_rstd, gamma, beta, (const bf16_t*)add1, (const bf16_t*)add2, (bf16_t*)dx1, (bf16_t*)dx2, Bn, HW, G, silu, (hipStream_t)stream);
+    E4T_CHECK_LAUNCH("gn_slab_bwd_kernel");
+    return 0;
+  }
   const int C = C1 + C2, ch = gn_chunks(Bn, HW), ppc = cdiv(HW, ch), BG = Bn * G;
   const size_t need = ((size_t)Bn * ch * G * 2 + (size_t)BG * 2) * sizeof(float);
   E4T_REQUIRE(workspace && ws_bytes >= need, "groupnorm_bwd: workspace too small (%zu < %zu)", ws_bytes, need);

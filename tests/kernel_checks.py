@@ -206,8 +206,12 @@ def check_attention(hip, emu, dev):
 
 def check_norms(hip, emu, dev):
     out = []
+    # the last six take the one-launch slab kernels (HW x C/G <= 10240, C/G % 4 == 0, no group straddling the concat): 3 / 5 / 10
+    # quads per thread, two sources, ragged item counts, with and without SiLU / shortcut gradients
     for i, (B, HW, C1, C2, G, silu) in enumerate([(2, 64, 64, 0, 32, True), (3, 256, 320, 0, 32, True), (2, 100, 320, 640, 32, True),
-                                                  (2, 64, 1280, 1280, 32, False), (16, 4096, 320, 0, 32, True)]):
+                                                  (2, 64, 1280, 1280, 32, False), (16, 4096, 320, 0, 32, True),
+                                                  (2, 64, 1280, 0, 32, True), (3, 256, 1280, 0, 32, True), (2, 64, 1280, 1280, 32, True),
+                                                  (2, 60, 640, 0, 32, True), (1, 256, 640, 640, 32, False), (2, 64, 640, 640, 32, True)]):
         g = gen(140 + i, dev)
         x1 = rnd(g, B * HW, C1, dev=dev) + 0.3
         x2 = rnd(g, B * HW, C2, scale=2.0, dev=dev) if C2 else None
@@ -228,7 +232,13 @@ def check_norms(hip, emu, dev):
             out.append((tag + " via column statistics: y", rel(y3, y), 2e-3))
             out.append((tag + " via column statistics: stats", rel(st3, st), 1e-4))
         y2, st2 = hip.groupnorm_fwd_unfused(x1, x2, gamma, beta, B, HW, G, 1e-5, silu)
-        out.append((tag + " fused == stats/finalize/apply entry points", float((y2 != y).sum() + (st2 != st).sum()), 0.0))
+        cpg = Cn // G
+        slab = cpg % 4 == 0 and HW * cpg <= 10240 and (C2 == 0 or C1 % cpg == 0)
+        if slab:     # one-launch kernel: same arithmetic, different summation tree
+            out.append((tag + " slab kernel ~ stats/finalize/apply entry points: y", rel(y, y2), 2e-3))
+            out.append((tag + " slab kernel ~ stats/finalize/apply entry points: stats", rel(st, st2), 1e-5))
+        else:
+            out.append((tag + " fused == stats/finalize/apply entry points", float((y2 != y).sum() + (st2 != st).sum()), 0.0))
         dy = rnd(g, B * HW, Cn, dev=dev)
         add = rnd(g, B * HW, C1, dev=dev) if i % 2 == 0 else None            # gradient through the block's shortcut
         add2 = rnd(g, B * HW, C2, dev=dev) if (C2 and i != 3) else None
@@ -239,6 +249,11 @@ def check_norms(hip, emu, dev):
             out.append((tag + " bwd dx2", rel(dx2, ex2), TOL1))
         out.append((tag + " bwd dgamma", rel(dga, ega), 1e-3))
         out.append((tag + " bwd dbeta", rel(dbe, ebe), 1e-3))
+        # frozen gamma / beta (pre-training): no parameter-gradient partials -> slab kernel where eligible
+        fx1, fx2, _, _ = hip.groupnorm_bwd(x1, x2, dy, str_, gamma, beta, add, B, HW, G, silu, want_param_grads=False, add2=add2)
+        out.append((tag + " bwd dx1 (no param grads)", rel(fx1, ex1), TOL1))
+        if C2:
+            out.append((tag + " bwd dx2 (no param grads)", rel(fx2, ex2), TOL1))
     # the last three take the several-rows-per-wave forward (4 / 2 / 2 rows for 1 / 2 / 3 chunks per lane) with a ragged last wave
     for i, (M, D) in enumerate([(37, 64), (1000, 320), (4112, 1280), (300, 768), (128, 1024), (8195, 320), (4101, 640), (4111, 1280)]):
         g = gen(160 + i, dev)
