@@ -157,8 +157,9 @@ def main():
                  "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, 2, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2, false, 64>",
                  "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, 2, false, 64>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, 2, false, 64>",
                  "conv512": "gemm_pp_kernel<1>", "gemm512": "gemm_pp_kernel<0>", "gemm_tn": "gemm_tn_kernel",
-                 "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true, *>", "gn_fwd_2pass": "gn_stats_kernel<*> + gn_apply_kernel<true, *>",
-                 "gn_bwd": "gn_bwd_stats_kernel<*> + gn_bwd_apply_kernel<*>", "ln_fwd": "ln_fwd_kernel<*>", "ln_bwd": "ln_bwd_kernel<*>",
+                 "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",
+                 "gn_fwd_2pass": "gn_stats_kernel<*> + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",
+                 "gn_bwd": "gn_bwd_stats_kernel<*> + gn_bwd_apply_kernel<*>",      # (small maps: gn_slab_bwd_kernel<*>) "ln_fwd": "ln_fwd_kernel<*>", "ln_bwd": "ln_bwd_kernel<*>",
                  "geglu_fwd": "geglu_fwd_kernel", "geglu_bwd": "geglu_bwd_kernel", "adamw": "adamw_kernel"}
         # HBM bytes per launch of each kernel symbol from the TCC counters: collected offline with tools/profile_round.sh on this
         # very command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 as
