@@ -97,3 +97,35 @@ def test_text_encoder_matches_installed_transformers_clip():
         o.load_state_dict(flat)
         with torch.no_grad():
             torch.testing.assert_close(o(input_ids=ids), want, rtol=1e-5, atol=1e-5)
+
+
+def test_prepared_linear_recasts_in_place_after_an_optimiser_step(emu_fp32):
+    """A trainable weight is re-cast once per optimiser step (weights epoch bumped by the raw-pointer AdamW): the compute copies
+    and the descriptor table are kept — same storage, new values — and an unchanged weight is not re-cast at all."""
+    from e4t import functional as Fn
+    from e4t import ops
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(24, 16))
+    prep = Fn.PreparedLinear(w)
+    a, aT = prep.get()
+    table = prep._table
+    pa, paT = a.data_ptr(), aT.data_ptr()
+    torch.testing.assert_close(a.float()[:, :16], w.detach(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(aT.float()[:, :24], w.detach().t(), rtol=1e-2, atol=1e-2)
+    b, _ = prep.get()                                    # nothing changed: no re-cast, same objects
+    assert b is a and prep._table is table
+    with torch.no_grad():
+        w.data.mul_(2.0)                                 # what the fused AdamW does: raw write, then bump the epoch
+    ops.bump_weights_epoch()
+    c, cT = prep.get()
+    assert c.data_ptr() == pa and cT.data_ptr() == paT and prep._table is table
+    torch.testing.assert_close(c.float()[:, :16], w.detach(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(cT.float()[:, :24], w.detach().t(), rtol=1e-2, atol=1e-2)
+    # a frozen weight ignores the epoch
+    f = torch.nn.Parameter(torch.randn(8, 8), requires_grad=False)
+    pf = Fn.PreparedLinear(f)
+    x, _ = pf.get()
+    key = pf.key
+    ops.bump_weights_epoch()
+    y, _ = pf.get()
+    assert y is x and pf.key == key
