@@ -264,15 +264,21 @@ class E4TEncoder(nn.Module):
         key = (w0._version, self.first_linears[-1].weight._version, ops.weights_epoch(), self._wstack.data_ptr())
         if key != self._stack_key:
             n, hid, _ = self._wstack.shape
-            flat = self._wstack.view(n * hid, hid)
-            self._ws = torch.empty((n * hid, hid), dtype=ops.ACT, device=flat.device)
-            tmpT = torch.empty((hid, n * hid), dtype=ops.ACT, device=flat.device)
-            # one grouped launch: n plain-weight entries, each writing its [hid, hid] block and its transposed block
-            ents = [ops.WOEntry(row=hid, col=hid, W=self._wstack[i], weff=self._ws[i * hid:(i + 1) * hid],
-                                weffT=tmpT[:, i * hid:(i + 1) * hid]) for i in range(n)]
-            ops.backend().weight_prepare(ops.WOTable(ents))
+            # The compute copies and the 129-entry descriptor table are built ONCE per parameter storage and re-used after every
+            # optimiser step: re-creating 129 descriptors in Python and re-uploading them cost ~0.9 ms of idle GPU per step
+            # (tools/idle_report.py: the one wo_apply -> wo_apply gap), the re-cast itself is a single grouped launch.
+            tab = getattr(self, "_stack_table", None)
+            if tab is None or tab[0] != (self._wstack.data_ptr(), n, hid, ops.ACT, self._wstack.device):
+                ws = torch.empty((n * hid, hid), dtype=ops.ACT, device=self._wstack.device)
+                tmpT = torch.empty((hid, n * hid), dtype=ops.ACT, device=self._wstack.device)
+                # one grouped launch: n plain-weight entries, each writing its [hid, hid] block and its transposed block
+                ents = [ops.WOEntry(row=hid, col=hid, W=self._wstack[i], weff=ws[i * hid:(i + 1) * hid],
+                                    weffT=tmpT[:, i * hid:(i + 1) * hid]) for i in range(n)]
+                tab = self._stack_table = ((self._wstack.data_ptr(), n, hid, ops.ACT, self._wstack.device), ops.WOTable(ents), ws, tmpT)
+            _, table, ws, tmpT = tab
+            ops.backend().weight_prepare(table)
             self._wsT = tmpT.view(hid, n, hid).permute(1, 0, 2)      # [n, hid(in), hid(out)] view, row stride n*hid
-            self._ws = self._ws.view(n, hid, hid)
+            self._ws = ws.view(n, hid, hid)
             self._stack_key = key
         return self._ws, self._wsT
 

@@ -17,16 +17,19 @@ ad = ad[-(n + 1):]
 t0, t1 = rows[ad[0]][1], rows[ad[-1]][1]
 sel = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 busy, cur_s, cur_e = 0, None, None
-gaps = []
+gaps, pairs = [], []
+last_name = None         # the kernel that finished last before a gap
 for s, e, name, q in sel:
     if cur_e is None:
-        cur_s, cur_e = s, e
+        cur_s, cur_e, last_name = s, e, name
     elif s <= cur_e:
-        cur_e = max(cur_e, e)
+        if e >= cur_e:
+            cur_e, last_name = e, name
     else:
         busy += cur_e - cur_s
         gaps.append((s - cur_e, name))
-        cur_s, cur_e = s, e
+        pairs.append((s - cur_e, last_name, name))
+        cur_s, cur_e, last_name = s, e, name
 busy += cur_e - cur_s
 wall = t1 - t0
 print(f"{n} steps: wall {wall / n / 1e6:.2f} ms/step, some kernel running {busy / n / 1e6:.2f} ms/step, idle {(wall - busy) / n / 1e6:.2f} ms/step ({100 * (wall - busy) / wall:.1f} %), "
@@ -41,3 +44,11 @@ for name, g in by.most_common(25):
     print(f"  {g / n / 1e3:8.1f} us  {cnt[name] / n:6.1f} gaps  avg {g / cnt[name] / 1e3:6.1f} us  {name[:70]}")
 big = sorted(gaps, reverse=True)[:10]
 print("largest single gaps (us):", [(round(g / 1e3, 1), nm[:40]) for g, nm in big])
+
+print("gaps over 100 us as (kernel that finished last) -> (kernel that ended the gap), per step:")
+pc, pn = collections.Counter(), collections.Counter()
+for g, a, b in pairs:
+    if g > 100e3:
+        pc[(a[:48], b[:48])] += g; pn[(a[:48], b[:48])] += 1
+for (a, b), g in pc.most_common(12):
+    print(f"  {g / n / 1e3:8.1f} us  {pn[(a, b)] / n:5.1f} gaps  {a}  ->  {b}")
