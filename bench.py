@@ -159,7 +159,8 @@ def main():
                  "conv512": "gemm_pp_kernel<1>", "gemm512": "gemm_pp_kernel<0>", "gemm_tn": "gemm_tn_kernel",
                  "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",
                  "gn_fwd_2pass": "gn_stats_kernel<*> + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",
-                 "gn_bwd": "gn_bwd_stats_kernel<*> + gn_bwd_apply_kernel<*>",      # (small maps: gn_slab_bwd_kernel<*>) "ln_fwd": "ln_fwd_kernel<*>", "ln_bwd": "ln_bwd_kernel<*>",
+                 "gn_bwd": "gn_bwd_stats_kernel<*> + gn_bwd_apply_kernel<*>",      # (small maps: gn_slab_bwd_kernel<*>)
+                 "ln_fwd": "ln_fwd_kernel<*>", "ln_bwd": "ln_bwd_kernel<*>",
                  "geglu_fwd": "geglu_fwd_kernel", "geglu_bwd": "geglu_bwd_kernel", "adamw": "adamw_kernel"}
         # HBM bytes per launch of each kernel symbol from the TCC counters: collected offline with tools/profile_round.sh on this
         # very command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 as
