@@ -52,9 +52,10 @@ def _worker(rank, world, port, out_dir, unfreeze):
     torch.set_num_threads(2)
     from e4t.trainer import E4TTrainer
     _, _, n_unet, n_enc, text = _build()
-    if unfreeze:
+    if unfreeze == "vit":
         n_enc.clip_vision.requires_grad_(True)
-    tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"))
+    tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"),
+                    **_MODE_KW[unfreeze])
     assert tr.world == world
     b = _batch(rank)
     tr.train_step(b["pixels"], b["ids"], b["pidx"], noise=b["noise"], timesteps=b["t"], latents=b["latents"])
@@ -63,9 +64,14 @@ def _worker(rank, world, port, out_dir, unfreeze):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("unfreeze", [False, True], ids=["vit_frozen", "vit_trainable"])
+_MODE_KW = {"": {}, "vit": {}, "tuning": dict(tuning=True, max_grad_norm=1.0)}
+
+
+@pytest.mark.parametrize("unfreeze", ["", "vit", "tuning"], ids=["vit_frozen", "vit_trainable", "tuning"])
 def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
-    """vit_trainable: no hook announces the head region during the backward, the post-backward sweep must reduce it"""
+    """vit_trainable: no hook announces the head region during the backward, the post-backward sweep must reduce it.
+    tuning: the whole UNet is in the U / D regions and the gradient-norm clip runs on the AVERAGED gradient (tuning_e4t.py:329-335
+    under accelerate's DDP)."""
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), unfreeze), nprocs=world, join=True)
     p0, p1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
@@ -77,14 +83,16 @@ def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
     try:
         from e4t.trainer import E4TTrainer
         _, _, n_unet, n_enc, text = _build()
-        if unfreeze:
+        if unfreeze == "vit":
             n_enc.clip_vision.requires_grad_(True)
-        tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"))
+        tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"),
+                        **_MODE_KW[unfreeze])
         for r in range(world):
             b = _batch(r)
             loss, _, _ = tr.losses(b["pixels"], b["latents"], b["noise"], b["t"], b["ids"], b["pidx"])
             loss.backward()
         tr.world = world
+        tr.clip_grad_norm()            # (no-op without max_grad_norm; on the averaged gradient with it)
         tr.optimizer_step()
         # Adam's first step moves a coordinate by ~lr*g/|g|: where g is at rounding-noise level the summation order
         # (all-reduce vs in-place accumulation) may flip it.  Everything else must agree to fp32 rounding.
