@@ -25,7 +25,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* lds_lo, const uint16_t
 }
 
 // ---- error plumbing (never throws across the ABI) -------------------------------------------
-extern "C" void e4t_set_error(const char* msg);
+// library-internal helpers shared by the translation units (not part of the C ABI: hidden)
+extern "C" __attribute__((visibility("hidden"))) void e4t_set_error(const char* msg);
 #define E4T_FAIL(code, ...)                                  \
   do {                                                       \
     char _b[512];                                            \
@@ -46,8 +47,8 @@ extern "C" void e4t_set_error(const char* msg);
 // ---- launch log (diagnostics): one text line per kernel launch — symbol | shape | algorithmic bytes | flops — so that a
 // rocprofv3 kernel trace / PMC collection of the same process can be joined per SHAPE (tools/roofline_report.py).
 // Off unless E4T_LAUNCH_LOG=<path> is set (or e4t_set_launch_log() was called); one branch per launch when off.
-extern "C" int e4t_launch_log_enabled(void);
-extern "C" void e4t_launch_logf(const char* fmt, ...);
+extern "C" __attribute__((visibility("hidden"))) int e4t_launch_log_enabled(void);
+extern "C" __attribute__((visibility("hidden"))) void e4t_launch_logf(const char* fmt, ...);
 #define E4T_LOG_LAUNCH(...)                                          \
   do {                                                               \
     if (e4t_launch_log_enabled()) e4t_launch_logf(__VA_ARGS__);      \

@@ -24,6 +24,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"libe4t_hip.so does not export {s}"
 
 
+def test_library_exports_nothing_but_the_declared_abi():
+    """every dynamic `e4t_*` symbol of the library is declared in the header (helpers shared by the translation units are hidden)"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _C.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("e4t_")}
+    assert exported == header_symbols(), exported ^ header_symbols()
+
+
 def test_binding_table_covers_header():
     assert header_symbols() == set(_C.SIGNATURES), set(_C.SIGNATURES) ^ header_symbols()
 
