@@ -6,8 +6,8 @@ OUT=../e4t/libe4t_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
 mkdir -p obj
 pids=()
-for f in core gemm attention norm wo elementwise image; do
-  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ ../../include/e4t_hip.h -nt obj/$f.o ]; then
+for f in core gemm gemm_ps attention norm wo elementwise image; do
+  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || { [[ $f == gemm* ]] && [ gemm_common.h -nt obj/$f.o ]; } || [ ../../include/e4t_hip.h -nt obj/$f.o ]; then
     EXTRA=""
     [ $f = image ] && EXTRA="-ffp-contract=off"      # byte-exact INTER_AREA: float ops must not be fused (see image.hip)
     hipcc $FLAGS $EXTRA -c $f.hip -o obj/$f.o &

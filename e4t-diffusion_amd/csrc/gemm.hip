@@ -25,237 +25,15 @@
 // e4t/models/transformer_2d.py:153,205,258-261 ; [3P diffusers] ResnetBlock2D/Downsample2D/Upsample2D
 // constructed at e4t/models/unet_2d_blocks.py:481,760,804,881,1732,1774,1855,1872 ;
 // e4t/models/unet_2d_condition.py:106-108,285-287 ; [3P open_clip] ViT linears (e4t/encoder.py:154).
-#include "common.h"
-#include "../../include/e4t_hip.h"
-#include <stdlib.h>
-#include <type_traits>
+#include "gemm_common.h"
+
+#ifndef E4T_GEMM_PS_DEFAULT
+#define E4T_GEMM_PS_DEFAULT 0      // automatic choice of the persistent 256 x BN kernel (gemm_ps.hip); E4T_GEMM_PS=0/1 overrides
+#endif
+extern "C" __attribute__((visibility("hidden"))) int e4t_launch_gemm_ps(const GemmArgs* p, int conv, int bn, int general, int ncu, hipStream_t st);
 
 namespace {
 
-constexpr int BK = 64;        // K-tile (bf16 elements)
-constexpr int LDS_LD = BK + 8;  // padded LDS row stride (elements): 144 B
-
-struct GemmArgs {
-  // A operand
-  const bf16_t* A;
-  const bf16_t* A2;
-  int K1;  // columns [0,K1) come from A, [K1,K) from A2 (K1 == K when A2 == nullptr)
-  int lda, lda2;
-  // conv geometry (MODE != 0)
-  int Hin, Win, Cin, Hout, Wout, mode;
-  // B operand [N][K]
-  const bf16_t* B;
-  int ldb;
-  // output / epilogue
-  void* C;
-  int ldc;
-  const float* bias;
-  const void* residual;
-  int ldr;
-  const float* rowbias;
-  int rows_per_batch, ldrb;
-  int M, N, K;
-  float alpha;
-  int flags;
-  // split-K / batch
-  float* ws;
-  int ktiles_per_split;
-  int splitk;       // splits per batch entry (grid.z = batch * splitk)
-  int group_m;      // row panels per raster group (xcd_tile)
-  int reduce_batch; // partials of all (batch, split) pairs are summed into ONE C
-  int fast_epi;     // bf16 C, 16-byte aligned rows: LDS-staged vectorised epilogue
-  long long strideA, strideB, strideC, strideBias;
-  float* colstats;                       // optional [M/32][N][2] column statistics of the output (fast bf16 epilogue only)
-  unsigned a_bytes, a2_bytes, b_bytes;   // operand extents from the (batch-adjusted) base pointers, for buffer resources (pp kernel)
-};
-
-__device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int row, int col) {
-  v *= p.alpha;
-  if (p.bias) v += p.bias[col];
-  if (p.rowbias) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
-  if (p.flags & E4T_ACT_GELU) v = gelu_f(v);
-  if (p.residual) {
-    if (p.flags & E4T_RES_F32) v += ((const float*)p.residual)[(size_t)row * p.ldr + col];
-    else v += bf2f(((const bf16_t*)p.residual)[(size_t)row * p.ldr + col]);
-  }
-  if (p.flags & E4T_OUT_F32) {
-    float* c = (float*)p.C + (size_t)row * p.ldc + col;
-    if (p.flags & E4T_ACCUM) v += *c;
-    *c = v;
-  } else {
-    bf16_t* c = (bf16_t*)p.C + (size_t)row * p.ldc + col;
-    if (p.flags & E4T_ACCUM) v += bf2f(*c);
-    *c = f2bf(v);
-  }
-}
-
-// Write one wave's WM x WN accumulator tile (origin mw, nw) with the fused epilogue.
-#ifdef DMA_TRACE
-#define WT_STAMP(k) do { if (dt_ptr) dt_ptr[k] = __builtin_readcyclecounter(); } while (0)
-#else
-#define WT_STAMP(k) do { } while (0)
-#endif
-// GENERAL: the epilogue variant with the exact-GELU activation and the per-row row-bias lookup (rows_per_batch not a multiple of
-// 32).  It is a separate INSTANTIATION, not a branch: inlined next to the plain path its erff expansion over 16 x FM x FN
-// elements set the register allocation of the whole kernel (288 instead of 208 registers in the 128 x 160 tile = one
-// workgroup per CU instead of two).  The launcher picks the variant (launch_gemm).
-template <int WM, int WN, int FM, int FN, bool GENERAL = false>
-__device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][FN], bf16_t* smem, int wave, int lane, int mw, int nw,
-                                           unsigned long long* dt_ptr = nullptr) {
-  const int frow = lane & 31, fhi = lane >> 5;
-  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  const bool partial = p.ws != nullptr;
-  if (!partial && p.fast_epi) {
-    // bf16 output: stage the wave's WM x WN tile through LDS (the operand tiles are dead after the loop's final
-    // barrier) so that C is written — and the residual read — as 16-byte chunks, 128 B contiguous per row.
-    // alpha, bias, row bias and GELU are applied in fp32 before the bf16 rounding; the residual is added to the
-    // rounded value in fp32 and rounded again, which is exactly what a bf16 linear followed by a bf16 add does.
-    constexpr int ELD = WN + 8;
-    bf16_t* stage = smem + wave * (WM * ELD);
-    // Everything the epilogue reads from global memory is fetched by UNCONDITIONAL loads issued back to back (indices clamped
-    // into range, values masked afterwards).  The first version guarded each load (`col < N ? bias[col] : 0`, the row-bias
-    // inside the 16-element loop, the residual chunk inside the store loop): the compiler answered every guarded load with its
-    // own s_waitcnt vmcnt(0) — FN serialized L2 round trips for the bias, 16 x FM x FN for the ResBlock time-embedding row-bias
-    // (85 in the 128 x 160 conv tile), one per 16-byte residual chunk (10) — in the epilogue of EVERY workgroup (ISA, round 2).
-    float bv[FN], rbv[FM][FN];
-    const bool rb_blocked = p.rowbias && (p.rows_per_batch % 32 == 0);        // a 32-row fragment lies inside one batch entry
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = min(nw + j * 32 + frow, p.N - 1);
-      bv[j] = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int row = min(mw + i * 32, p.M - 1);
-        rbv[i][j] = rb_blocked ? p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col] : 0.f;
-      }
-    }
-    WT_STAMP(13);
-    // The uniform special cases (GELU epilogue, per-row row-bias lookup) are decided ONCE, outside the 16 x FM x FN element loop: as
-    // per-element `if`s they were two scalar branches per element — the staging of a 32 x 160 wave tile took 8300 of the
-    // workgroup's 32000 cycles on the K = 320 projections (cycle stamps, tools/dma_trace.sh), 1400 without them.
-    const bool rb_slow = p.rowbias && !rb_blocked;
-    if constexpr (!GENERAL) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int cl = j * 32 + frow;
-          const float add = bv[j] + rbv[i][j];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-            stage[rl * ELD + cl] = f2bf(acc[i][j][r] * p.alpha + add);
-          }
-          // one fragment at a time: without the fence the scheduler pulls the accumulator reads of ALL fragments (80 AGPR -> VGPR
-          // copies in the 128 x 160 tile) in front of the first write, and the kernel loses one of its two waves per SIMD
-          __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
-      const bool gelu = (p.flags & E4T_ACT_GELU) != 0;
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int cl = j * 32 + frow;
-          const int col = nw + cl;
-          const float add = bv[j] + rbv[i][j];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-            float v = acc[i][j][r] * p.alpha + add;
-            if (rb_slow) {      // odd geometry (rows_per_batch not a multiple of 32): per-row lookup
-              const int row = mw + rl;
-              if (row < p.M && col < p.N) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
-            }
-            if (gelu) v = gelu_f(v);
-            stage[rl * ELD + cl] = f2bf(v);
-          }
-        }
-    }
-    WT_STAMP(14);
-    __syncthreads();                     // (a wave only reads back its own region; the barrier orders the LDS traffic)
-    WT_STAMP(15);
-    constexpr int CPR = WN / 8;          // 16-byte chunks per row
-    constexpr int NIT = (WM * CPR + 63) / 64;
-    bf16_t* Cb = (bf16_t*)p.C;
-    const bf16_t* Rb = (const bf16_t*)p.residual;
-    // residual chunks are fetched RB at a time ahead of their use (all loads of a batch back to back); RB = 4 keeps the 128 x 160
-    // kernel at 2 waves per SIMD (10 chunks in flight at once cost 40 VGPRs and one of the two resident workgroups per CU)
-    constexpr int RB = NIT < 4 ? NIT : 4;
-#pragma unroll
-    for (int it0 = 0; it0 < NIT; it0 += RB) {
-      uint4 rres[RB];
-      if (Rb) {
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-          const int idx = min((it0 + u) * 64 + lane, WM * CPR - 1);
-          const int rl = idx / CPR, cch = idx - rl * CPR;
-          const int row = min(mw + rl, p.M - 1), col = min(nw + cch * 8, p.N - 8);
-          rres[u] = *(const uint4*)(Rb + (size_t)row * p.ldr + col);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const int it = it0 + u;
-        if (it >= NIT) break;
-        const int idx = it * 64 + lane;
-        const int rl = idx / CPR, cch = idx - rl * CPR;
-        const int row = mw + rl, col = nw + cch * 8;
-        if (idx < WM * CPR && row < p.M && col < p.N) {
-          uint4 v = *(const uint4*)(stage + rl * ELD + cch * 8);
-          if (Rb) {
-            float a[8], b[8];
-            unpack8(v, a);
-            unpack8(rres[u], b);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a[k] += b[k];
-            v = pack8(a);
-            if (p.colstats) *(uint4*)(stage + rl * ELD + cch * 8) = v;      // the statistics are those of the FINAL values
-          }
-          *(uint4*)(Cb + (size_t)row * p.ldc + col) = v;
-        }
-      }
-    }
-    if (p.colstats) {
-      // Per-column (sum, sum of squares) of this wave's output rows, one record per 32-row block: the GroupNorm that consumes
-      // this tensor reduces these few floats instead of re-reading the whole activation (norm.hip, gn_finalize_cols_kernel).
-      // The wave reads back its own staged (bf16, final) tile; LDS operations of one wave execute in order.
-#pragma unroll
-      for (int c0 = 0; c0 < WN; c0 += 64) {
-        const int cl = c0 + lane, col = nw + cl;
-        if (cl < WN && col < p.N) {
-#pragma unroll
-          for (int rb = 0; rb < WM / 32; ++rb) {
-            if (mw + rb * 32 >= p.M) break;                               // M % 32 == 0 whenever statistics are requested
-            float sm = 0.f, sq = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-              const float x = bf2f(stage[(rb * 32 + r) * ELD + cl]);
-              sm += x; sq += x * x;
-            }
-            float* o = p.colstats + ((size_t)((mw >> 5) + rb) * p.N + col) * 2;
-            o[0] = sm; o[1] = sq;
-          }
-        }
-      }
-    }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = nw + j * 32 + frow;
-      if (col >= p.N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-        if (row >= p.M) continue;
-        if (partial) p.ws[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[i][j][r];  // z = batch*splitk + split
-        else epilogue_store(p, acc[i][j][r], row, col);
-      }
-    }
-}
 
 // MODE 0: dense A.  MODE 1: implicit 3x3 conv over NHWC A.
 template <int BM, int BN, int WGM, int WGN, int MODE>
@@ -410,7 +188,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  write_tile<WM, WN, FM, FN, true>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
+  write_tile<WM, WN, FM, FN, true>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,49 +205,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 //   * out-of-range rows / conv padding / K tail: the lane's source pointer is redirected to a 16-byte
 //     zero word in global memory (DMA cannot synthesise zeros).
 // ------------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) uint4 g_zero16 = {0u, 0u, 0u, 0u};
-
-__device__ __forceinline__ void dma16(const bf16_t* src, bf16_t* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// The same DMA through a buffer resource: 32-bit per-lane byte offset + wave-uniform SGPR byte offset; out-of-range offsets read
-// as zero.  (Kept in a non-template helper: the builtin is not instantiable from a value-dependent context on the host pass.)
-__device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff, bf16_t* lds_wave_base) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
-}
-
-// Workgroup -> output-tile mapping.  The dispatcher deals consecutive workgroups (x fastest) round-robin over the 8 XCDs,
-// each with its own 4-MiB L2: with the plain blockIdx mapping the tiles sharing an A row panel (and, for the 3x3 convs,
-// the neighbouring image rows of the halo) sit in 8 different L2s and every panel is fetched 8 times.  Re-deal so that
-// the workgroups of one XCD own one CONTIGUOUS chunk of the tile raster, and walk that chunk in groups of 8 row panels
-// so the ~64 tiles in flight on an XCD form a compact 8 x 8 block of the output.
-__device__ __forceinline__ void xcd_tile(int& bx, int& by, int GM) {
-  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
-  const int lin = blockIdx.y * gx + blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, v = lin & 7;
-  const int lin2 = (v < r ? v * (q + 1) : r * (q + 1) + (v - r) * q) + (lin >> 3);
-  const int per = GM * gx, grp = lin2 / per, l = lin2 - grp * per;
-  const int first = grp * GM, gsz = min(gy - first, GM);
-  bx = l / gsz;
-  by = first + (l - bx * gsz);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// The K-loop barrier of the DMA kernels.  After it, some wave starts the LDS-DMA of a new tile INTO THE STAGE EVERY WAVE READ IN
-// THE ITERATION BEFORE, so every wave's fragment reads of that stage must have COMPLETED, not merely been issued, when it
-// arrives.  s_barrier alone does not order that: the compiler sinks the last k-step's MFMA — and the lgkmcnt wait in front of
-// it — below the barrier (gfx950 needs no counter drain at s_barrier), leaving ds_reads in flight across it.  Measured: with
-// three 4-wave workgroups per CU (64 x 64 tile, 3 stages) 0-2 of 1280 output tiles per launch came out wrong, not
-// reproducibly — a DMA that hit in L2 landed before a ds_read queued behind the other workgroups' LDS traffic had executed.
-// Draining lgkmcnt first closes the window for every stage count.
-__device__ __forceinline__ void loop_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-}
 
 #ifdef DMA_TRACE    // debug builds only (tools/dma_trace.sh): cycle stamps of wave 0 of every 8th workgroup
 __device__ unsigned long long g_dma_trace[128 * 16];
@@ -724,9 +459,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   __syncthreads();   // all fragment reads done before the epilogue reuses the LDS
   DT(11);
 #ifdef DMA_TRACE
-  write_tile<WM, WN, FM, FN, GENERAL>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN, dt_on ? g_dma_trace + dt_wg * 16 : nullptr);
+  write_tile<WM, WN, FM, FN, GENERAL>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN, dt_on ? g_dma_trace + dt_wg * 16 : nullptr);
 #else
-  write_tile<WM, WN, FM, FN, GENERAL>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
+  write_tile<WM, WN, FM, FN, GENERAL>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
 #endif
   DT(12);
 }
@@ -775,7 +510,7 @@ __device__ unsigned long long g_pp_trace[2 * 6 * 64];
 #else
 #define PP_LDSREAD(ptr) (*(const bf16x8*)(ptr))
 #endif
-template <int MODE>
+template <int MODE, bool GENERAL = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, HK = 32;
   constexpr int QUART = 256 * HK;                        // elements per quarter
@@ -1012,9 +747,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   if (tracing) for (int i = 0; i < 6 * 64; ++i) g_pp_trace[wr * 6 * 64 + i] = tr[wr][i];
 #endif
   // two 64-row halves: keeps the (fully unrolled) epilogue at the size of the 128-wide kernels'
-  write_tile<64, 64, 2, 2>(p, *(f32x16(*)[2][2])(acc + 0), smem, wave, lane, m0 + wr * 128, n0 + wc * 64);
+  write_tile<64, 64, 2, 2, GENERAL>(p, *(f32x16(*)[2][2])(acc + 0), wave_stage<64, 64>(smem, wave), lane, m0 + wr * 128, n0 + wc * 64);
   __syncthreads();
-  write_tile<64, 64, 2, 2>(p, *(f32x16(*)[2][2])(acc + 2), smem, wave, lane, m0 + wr * 128 + 64, n0 + wc * 64);
+  write_tile<64, 64, 2, 2, GENERAL>(p, *(f32x16(*)[2][2])(acc + 2), wave_stage<64, 64>(smem, wave), lane, m0 + wr * 128 + 64, n0 + wc * 64);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1244,9 +979,9 @@ __global__ __launch_bounds__(512) void gemm_pt_kernel(GemmArgs p) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();   // every fragment read and every DMA is done before the epilogue reuses the LDS
-  write_tile<64, 64, 2, 2>(p, acc[0], smem, wave, lane, m0 + wr * 256 + wc * 64, n0);
+  write_tile<64, 64, 2, 2>(p, acc[0], wave_stage<64, 64>(smem, wave), lane, m0 + wr * 256 + wc * 64, n0);
   __syncthreads();
-  write_tile<64, 64, 2, 2>(p, acc[1], smem, wave, lane, m0 + wr * 256 + wc * 64, n0 + 64);
+  write_tile<64, 64, 2, 2>(p, acc[1], wave_stage<64, 64>(smem, wave), lane, m0 + wr * 256 + wc * 64, n0 + 64);
 }
 
 #ifdef PP_TRACE
@@ -1377,7 +1112,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
     if (kt < kt_end) body(std::integral_constant<int, 0>{}, kt);
   }
   __syncthreads();
-  write_tile<WM, WN, 1, FN>(p, acc, smem, wave, lane, m0 + wm * WM, n0 + wn * WN);
+  write_tile<WM, WN, 1, FN>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
 }
 
 // sums `nz` consecutive partial slabs starting at slab blockIdx.y*nz, then runs the epilogue for batch entry blockIdx.y
@@ -1449,17 +1184,49 @@ __global__ __launch_bounds__(256) void splitk_reduce8_kernel(GemmArgs p, int nz)
   }
 }
 
-int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int splitk_req, int batch, hipStream_t st) {
+// What launch_gemm() will run for a problem: the ONE place where tiles and split-K are chosen (e4t_gemm_plan / e4t_conv3x3_plan
+// export it, so that callers size workspaces and label timings from the launcher's own decision instead of mirroring it).
+struct GemmPlan {
+  int tile;        // 64 | 128 | 160 (128x160) | 256 (256x128 DMA) | 512 (256x256 ping-pong) | 640 (512x128 ping-pong) | 1128 / 1160 (persistent 256x128 / 256x160)
+  int stages;      // LDS stages of the 64 / 128 / 160 DMA kernels
+  bool kt32;       // 32-wide K-tiles (experimental codes 5064 / 5128 / 5256)
+  bool general_epi;
+  bool buf_ok;     // operands addressable through buffer resources (< 4 GB)
+  int tm, tn, gx, gy;
+  int splitk, ktiles_per_split;
+  unsigned a_bytes, a2_bytes, b_bytes;
+};
+
+int device_cu_count() {
+  static int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  return ncu;
+}
+
+// The persistent 256 x BN kernel (gemm_ps.hip) pays when its one-workgroup-per-CU rounds are (nearly) full.
+bool ps_rounds_ok(long long units, int ncu) {
+  if (units < ncu) return false;
+  const long long rounds = (units + ncu - 1) / ncu;
+  return units * 100 >= rounds * ncu * 85;
+}
+
+GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, int batch) {
+  GemmPlan pl;
   const int nkt = cdiv(p.K, BK);
   // --- tile selection: fill >= ~1.5 waves of the 256 CUs with 128x128 tiles, else drop to 64x64 ---
   int stages = 2;                         // LDS stages of the 64 / 128 / 160 DMA kernels; a hint of 3128 / 4160 / ... forces 3 or 4
-  bool kt32 = false;                      // 5128 / 5064: the 32-wide K-tile variant (4 stages in the LDS of 2 x 64-wide ones)
+  bool kt32 = false;                      // 5128 / 5064 / 5256: the 32-wide K-tile variant (4 stages in the LDS of 2 x 64-wide ones; 5256: 3)
   if (tile_hint >= 3000 && tile_hint < 5000) { stages = tile_hint / 1000; tile_hint %= 1000; }
   else if (tile_hint >= 5000 && tile_hint < 6000) { kt32 = true; stages = 4; tile_hint %= 1000; }
   int tile = tile_hint;
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
-  if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512 && tile != 640) {
+  const bool whole_k = p.K % BK == 0 && (!p.A2 || p.K1 % BK == 0);
+  const bool ps_ok = allow256 && whole_k && batch == 1 && !p.reduce_batch && splitk_req <= 1;      // what gemm_ps_kernel accepts
+  if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512 && tile != 640 && tile != 1128 && tile != 1160) {
     // measured on MI355X (tools/sweep_small.py): 128x128 wins from one full round of the 256 CUs, and already from
     // a quarter round when K is long (3x3 convs at the 16x16 / 8x8 levels) if split-K fills the chip
     const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch;
@@ -1471,14 +1238,14 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     // K-deep shapes whose N is a multiple of 256 and that fill the chip at least twice with 256x256 tiles (the VAE's 256-
     // and 512-channel convs): the ping-pong kernel (conv 512->512 @128^2: 1075 vs 928 TF, 8192^3: 1173 vs 971 TF)
     static const bool no_pp = getenv("E4T_GEMM_NOPP") != nullptr;     // A/B switch
-    if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && p.K % BK == 0 && nkt >= (conv ? 16 : 32) && (!p.A2 || p.K1 % BK == 0) &&
+    if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && whole_k && nkt >= (conv ? 16 : 32) &&
         (long long)cdiv(p.M, 256) * (p.N / 256) * batch >= 512) tile = 512;
     // ... and, with split-K, for the very K-deep shapes of the 16x16 level that give it only 64-255 tiles (1280-channel 3x3
     // convs, the GEGLU input gradient K = 10240): tools/sweep_step_shapes.py, conv 1280->1280 M4096 128 vs 141 us, conv
     // 1280->2560 209 vs 290 us, conv 2560->1280 221 vs 265 us, GEMM 4096x1280x10240 126 vs 138 us; at K = 5120 it loses.
     {
       const long long tpp = (long long)cdiv(p.M, 256) * (p.N / 256) * batch;
-      if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && p.K % BK == 0 && nkt >= 128 && (!p.A2 || p.K1 % BK == 0) && tpp >= 64 && tpp < 512)
+      if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && whole_k && nkt >= 128 && tpp >= 64 && tpp < 512)
         tile = 512;
     }
     // The 512 x 128 variant of the same machine (tile code 640) is NOT chosen automatically: on the shapes it was built for
@@ -1488,16 +1255,28 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     static const bool auto_pt = getenv("E4T_GEMM_PT") != nullptr;
     if (auto_pt && allow256 && tile == 128 && p.N % 128 == 0 && p.N % 256 != 0 && p.K % BK == 0 && nkt >= 16 && !p.A2 &&
         (long long)cdiv(p.M, 512) * (p.N / 128) * batch >= 512) tile = 640;
+    // The persistent 256 x 160 / 256 x 128 streaming kernel (gemm_ps.hip) for the big-M shapes the 128-wide tiles run today,
+    // when its rounds of one workgroup per CU come out (nearly) full.  E4T_GEMM_PS=0 is the A/B switch.
+    static const int auto_ps = getenv("E4T_GEMM_PS") ? atoi(getenv("E4T_GEMM_PS")) : E4T_GEMM_PS_DEFAULT;
+    if (auto_ps && ps_ok && (tile == 128 || tile == 160)) {
+      const int ncu = device_cu_count();
+      const long long rows = cdiv(p.M, 256);
+      if (p.N % 160 == 0 && ps_rounds_ok(rows * (p.N / 160), ncu)) tile = 1160;
+      else if ((p.N % 128 == 0 || p.N < 128) && ps_rounds_ok(rows * cdiv(p.N, 128), ncu)) tile = 1128;
+    }
   }
-  // epilogues with the exact GELU or a per-row row-bias lookup run the GENERAL instantiation, built for the 2-stage 64 / 128 / 160 tiles
+  // epilogues with the exact GELU or a per-row row-bias lookup run the GENERAL instantiation, built for the 2-stage 64 / 128 / 160 tiles,
+  // the 256 x 256 ping-pong kernel and the persistent kernels
   const bool general_epi = (p.flags & E4T_ACT_GELU) || (p.rowbias && p.rows_per_batch % 32 != 0);
-  if (general_epi) { stages = 2; kt32 = false; if (tile == 256 || tile == 512 || tile == 640) tile = 128; }
-  if (kt32 && tile != 128 && tile != 64) kt32 = false;
+  if (general_epi) { stages = 2; kt32 = false; if (tile == 256 || tile == 640) tile = 128; }
+  if (kt32 && tile != 128 && tile != 64 && tile != 256) kt32 = false;
+  if (kt32 && tile == 256) stages = 3;
   if (tile == 256 && !allow256) tile = 128;
   if (tile == 160 && !allow256) tile = 128;
   if (tile == 640 && (!allow256 || p.A2)) tile = 128;
+  if ((tile == 1128 || tile == 1160) && !ps_ok) tile = tile == 1160 && p.N % 160 == 0 ? 160 : 128;
   // The DMA kernels address their operands through buffer resources (32-bit byte offsets): operands beyond 4 GB fall back to
-  // the register-staged kernel.  The ping-pong kernel additionally needs whole K-tiles.
+  // the register-staged kernel.  The ping-pong kernels additionally need whole K-tiles.
   bool buf_ok = true;
   {
     const unsigned long long lim = 0xFFFF0000ull;
@@ -1505,16 +1284,18 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     if (conv) ab = (unsigned long long)((long long)p.M / ((long long)p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 2;   // batch * Hin * Win * Cin
     else { ab = ((unsigned long long)(p.M - 1) * p.lda + p.K1) * 2; if (p.A2) a2b = ((unsigned long long)(p.M - 1) * p.lda2 + (p.K - p.K1)) * 2; }
     buf_ok = ab < lim && a2b < lim && bb < lim;
-    if (tile == 512 && (!allow256 || !buf_ok || p.K % BK != 0 || (p.A2 && p.K1 % BK != 0))) tile = 128;
+    if (tile == 512 && (!allow256 || !buf_ok || !whole_k)) tile = 128;
     if (tile == 640 && (!buf_ok || p.K % BK != 0)) tile = 128;
-    p.a_bytes = (unsigned)(buf_ok ? ab : 0); p.a2_bytes = (unsigned)(buf_ok ? a2b : 0); p.b_bytes = (unsigned)(buf_ok ? bb : 0);
+    pl.a_bytes = (unsigned)(buf_ok ? ab : 0); pl.a2_bytes = (unsigned)(buf_ok ? a2b : 0); pl.b_bytes = (unsigned)(buf_ok ? bb : 0);
     if (!buf_ok && tile != 64) tile = 128;       // the register-staged fallback exists as 128x128 and 64x64 only
   }
-  // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong, 640 = 512x128 ping-pong
-  const int tm = tile == 160 ? 128 : (tile == 512 ? 256 : (tile == 640 ? 512 : tile)), tn = tile == 256 ? 128 : (tile == 512 ? 256 : (tile == 640 ? 128 : tile));
+  // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong, 640 = 512x128 ping-pong, 1128 / 1160 = persistent 256x128 / 256x160
+  const int tm = tile == 160 ? 128 : (tile == 512 || tile >= 1000 ? 256 : (tile == 640 ? 512 : tile));
+  const int tn = tile == 256 ? 128 : (tile == 512 ? 256 : (tile == 640 ? 128 : (tile >= 1000 ? tile - 1000 : tile)));
   const int gx = cdiv(p.N, tn), gy = cdiv(p.M, tm);
   // --- split-K: only when the grid underfills the chip and K is long ---
   int splitk = splitk_req;
+  if (tile >= 1000) splitk = 1;
   if (splitk <= 0) {
     splitk = 1;
     const long long tiles = (long long)gx * gy * batch;
@@ -1535,8 +1316,27 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     if (splitk < 1) splitk = 1;
   }
   if (splitk > nkt) splitk = nkt;
-  p.ktiles_per_split = cdiv(nkt, splitk);
-  splitk = cdiv(nkt, p.ktiles_per_split);
+  pl.ktiles_per_split = cdiv(nkt, splitk);
+  pl.splitk = cdiv(nkt, pl.ktiles_per_split);
+  pl.tile = tile; pl.stages = stages; pl.kt32 = kt32; pl.general_epi = general_epi; pl.buf_ok = buf_ok;
+  pl.tm = tm; pl.tn = tn; pl.gx = gx; pl.gy = gy;
+  return pl;
+}
+
+size_t plan_workspace_bytes(const GemmPlan& pl, const GemmArgs& p, int batch) {
+  return (pl.splitk > 1 || p.reduce_batch) ? (size_t)pl.splitk * batch * p.M * p.N * sizeof(float) : 0;
+}
+
+int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int splitk_req, int batch, hipStream_t st) {
+  const GemmPlan pl = plan_gemm(p, conv, tile_hint, splitk_req, batch);
+  const int nkt = cdiv(p.K, BK);
+  const int tile = pl.tile, stages = pl.stages, gx = pl.gx, gy = pl.gy;
+  const bool kt32 = pl.kt32, general_epi = pl.general_epi, buf_ok = pl.buf_ok;
+  int splitk = pl.splitk;
+  p.ktiles_per_split = pl.ktiles_per_split;
+  p.a_bytes = pl.a_bytes; p.a2_bytes = pl.a2_bytes; p.b_bytes = pl.b_bytes;
+  static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
+  (void)allow256;
   const bool need_ws = splitk > 1 || p.reduce_batch;
   const size_t need = (size_t)splitk * batch * p.M * p.N * sizeof(float);
   if (need_ws && (p.ws == nullptr || ws_bytes < need)) {
@@ -1567,11 +1367,17 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     double by = 2.0 * a_el + 2.0 * (double)p.N * p.K * (p.strideB || batch == 1 ? batch : 1) + osz * (double)p.M * p.N * (p.reduce_batch ? 1 : batch);
     if (p.residual) by += ((p.flags & E4T_RES_F32) ? 4.0 : 2.0) * (double)p.M * p.N;
     if (p.flags & E4T_ACCUM) by += osz * (double)p.M * p.N;
-    const char* sym = !(use_dma && buf_ok) ? "gemm_kernel" : tile == 512 ? (conv ? "gemm_pp_kernel<1>" : "gemm_pp_kernel<0>")
+    const char* sym = !(use_dma && buf_ok) ? "gemm_kernel"
+                      : tile == 512 ? (general_epi ? (conv ? "gemm_pp_kernel<1, true>" : "gemm_pp_kernel<0, true>") : (conv ? "gemm_pp_kernel<1, false>" : "gemm_pp_kernel<0, false>"))
                       : tile == 640 ? (conv ? "gemm_pt_kernel<1>" : "gemm_pt_kernel<0>")
-                      : tile == 256 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 64>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 64>")
+                      : tile == 256 && !kt32 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 64>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 64>")
+                      : tile == 256 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>")
                       : nullptr;
     char symbuf[64];
+    if (!sym && tile >= 1000) {
+      snprintf(symbuf, sizeof(symbuf), "gemm_ps_kernel<%d, %d, %s>", conv ? 1 : 0, tile - 1000, general_epi ? "true" : "false");
+      sym = symbuf;
+    }
     if (!sym) {
       snprintf(symbuf, sizeof(symbuf), "gemm_dma_kernel<%d, %d, %d, %d, %d, %d, %s, %d>", tile == 64 ? 64 : 128, tile == 160 ? 160 : tile, tile == 64 ? 2 : 4,
                tile == 160 ? 1 : 2, conv ? 1 : 0, stages, general_epi ? "true" : "false", kt32 ? 32 : 64);      // as rocprofv3 prints the symbol
@@ -1585,14 +1391,28 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                              p.M, p.N, p.reduce_batch ? splitk * batch : splitk, 4.0 * (double)p.M * p.N * splitk * batch + osz * (double)p.M * p.N);
   }
   if (use_dma && buf_ok) {
-    if (tile == 512) {
+    if (tile >= 1000) {
+      static const bool ps_pre = getenv("E4T_PS_PRE") == nullptr || atoi(getenv("E4T_PS_PRE")) != 0;      // A/B switch
+      p.ps_pre = ps_pre && p.fast_epi && nkt >= 2 && (!p.rowbias || p.rows_per_batch % 256 == 0);
+      const int rc = e4t_launch_gemm_ps(&p, conv ? 1 : 0, tile - 1000, general_epi ? 1 : 0, device_cu_count(), st);
+      if (rc < 0) return rc;
+    } else if (tile == 512) {
       block = dim3(512);
-      if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1>), grid, block, 0, st, p);
-      else hipLaunchKernelGGL((gemm_pp_kernel<0>), grid, block, 0, st, p);
+      if (general_epi) {
+        if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_pp_kernel<0, true>), grid, block, 0, st, p);
+      } else {
+        if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_pp_kernel<0>), grid, block, 0, st, p);
+      }
     } else if (tile == 640) {
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_pt_kernel<1>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_pt_kernel<0>), grid, block, 0, st, p);
+    } else if (tile == 256 && kt32) {
+      block = dim3(512);       // experimental (5256): 256 x 128 with 32-wide K-tiles, 3 x 24 KiB stages = two workgroups per CU
+      if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>), grid, block, 0, st, p);
     } else if (tile == 256) {
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3>), grid, block, 0, st, p);
@@ -1654,6 +1474,76 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
 
 }  // namespace
 
+namespace {
+
+void fill_gemm_args(const e4t_gemm_desc* d, GemmArgs& p) {
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16_t*)d->A; p.A2 = (const bf16_t*)d->A2; p.K1 = d->A2 ? d->K1 : d->K; p.lda = d->lda; p.lda2 = d->lda2;
+  p.B = (const bf16_t*)d->B; p.ldb = d->ldb; p.C = d->C; p.ldc = d->ldc; p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr;
+  p.rowbias = d->rowbias; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1; p.ldrb = d->ldrb > 0 ? d->ldrb : d->N;
+  p.M = d->M; p.N = d->N; p.K = d->K; p.alpha = d->alpha; p.flags = d->flags; p.ws = (float*)d->workspace;
+  p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.strideBias = d->strideBias;
+  p.reduce_batch = (d->flags & E4T_REDUCE_BATCH) ? 1 : 0;
+  p.colstats = d->colstats;
+}
+
+void fill_conv_args(const e4t_conv_desc* d, GemmArgs& p) {
+  const int Cin = d->Cin, Cout = d->Cout;
+  memset(&p, 0, sizeof(p));
+  p.A = (const bf16_t*)d->X; p.K1 = 9 * Cin; p.Hin = d->Hin; p.Win = d->Win; p.Cin = Cin; p.Hout = d->Hout; p.Wout = d->Wout;
+  p.mode = d->mode; p.B = (const bf16_t*)d->W; p.ldb = 9 * Cin; p.C = d->Y; p.ldc = Cout; p.bias = d->bias;
+  p.residual = d->residual; p.ldr = Cout; p.rowbias = d->rowbias; p.rows_per_batch = d->Hout * d->Wout; p.ldrb = d->ldrb > 0 ? d->ldrb : Cout;
+  p.M = d->B * d->Hout * d->Wout; p.N = Cout; p.K = 9 * Cin; p.alpha = 1.f; p.flags = d->flags; p.ws = (float*)d->workspace;
+  p.colstats = d->colstats;
+}
+
+// split count of the TN (weight-gradient) kernel: few output tiles, very long K -> fill the 512 workgroup slots by splitting K
+int tn_splitk(int M, int N, int K, int req) {
+  const int nkt = cdiv(K, BK);
+  const long long tiles = (long long)cdiv(N, 128) * cdiv(M, 128);
+  int splitk = req;
+  if (splitk <= 0) {
+    splitk = (int)(512 / tiles);
+    if (splitk > 32) splitk = 32;
+    if (splitk > nkt / 16) splitk = nkt / 16;
+    if (splitk < 1) splitk = 1;
+  }
+  if (splitk > nkt) splitk = nkt;
+  return cdiv(nkt, cdiv(nkt, splitk));
+}
+
+void export_plan(const GemmPlan& pl, const GemmArgs& p, int batch, e4t_gemm_plan_t* out) {
+  out->tile = pl.tile; out->tile_m = pl.tm; out->tile_n = pl.tn; out->splitk = pl.splitk;
+  out->workspace_bytes = plan_workspace_bytes(pl, p, batch);
+}
+
+}  // namespace
+
+extern "C" int e4t_gemm_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out) {
+  E4T_REQUIRE(d && out && d->M > 0 && d->N > 0 && d->K > 0, "gemm_plan: bad arguments");
+  GemmArgs p;
+  fill_gemm_args(d, p);
+  const int batch = d->batch > 0 ? d->batch : 1;
+  export_plan(plan_gemm(p, false, d->tile, d->splitk, batch), p, batch, out);
+  return 0;
+}
+
+extern "C" int e4t_conv3x3_plan(const e4t_conv_desc* d, e4t_gemm_plan_t* out) {
+  E4T_REQUIRE(d && out && d->B > 0 && d->Hout > 0 && d->Wout > 0 && d->Cin > 0 && d->Cout > 0, "conv3x3_plan: bad arguments");
+  GemmArgs p;
+  fill_conv_args(d, p);
+  export_plan(plan_gemm(p, true, d->tile, d->splitk, 1), p, 1, out);
+  return 0;
+}
+
+extern "C" int e4t_gemm_tn_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out) {
+  E4T_REQUIRE(d && out && d->M > 0 && d->N > 0 && d->K > 0, "gemm_tn_plan: bad arguments");
+  out->tile = 128; out->tile_m = out->tile_n = 128;
+  out->splitk = tn_splitk(d->M, d->N, d->K, d->splitk);
+  out->workspace_bytes = out->splitk > 1 ? (size_t)out->splitk * d->M * d->N * sizeof(float) : 0;
+  return 0;
+}
+
 extern "C" int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream) {
   E4T_REQUIRE(d && d->A && d->B && d->C, "gemm_nt: null operand");
   E4T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -1668,20 +1558,14 @@ extern "C" int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream) {
   E4T_REQUIRE(batch == 1 || (d->strideA % 8 == 0 && d->strideB % 8 == 0), "gemm_nt: batch strides must keep 16-B alignment");
   E4T_REQUIRE(!(d->flags & E4T_REDUCE_BATCH) || !d->A2, "gemm_nt: reduce-batch with two-source A unsupported");
   GemmArgs p;
-  memset(&p, 0, sizeof(p));
-  p.A = (const bf16_t*)d->A; p.A2 = (const bf16_t*)d->A2; p.K1 = d->A2 ? d->K1 : d->K; p.lda = d->lda; p.lda2 = d->lda2;
-  p.B = (const bf16_t*)d->B; p.ldb = d->ldb; p.C = d->C; p.ldc = d->ldc; p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr;
-  p.rowbias = d->rowbias; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1; p.ldrb = d->ldrb > 0 ? d->ldrb : d->N;
-  p.M = d->M; p.N = d->N; p.K = d->K; p.alpha = d->alpha; p.flags = d->flags; p.ws = (float*)d->workspace;
-  p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.strideBias = d->strideBias;
-  p.reduce_batch = (d->flags & E4T_REDUCE_BATCH) ? 1 : 0;
-  p.colstats = d->colstats;
+  fill_gemm_args(d, p);
   return launch_gemm(p, false, d->tile, d->workspace_bytes, d->splitk, batch, (hipStream_t)stream);
 }
 
 extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
   E4T_REQUIRE(d && d->A && d->B && d->C, "gemm_tn: null operand");
   E4T_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch <= 1 && !d->A2 && !d->rowbias, "gemm_tn: bad / unsupported arguments");
+  E4T_REQUIRE(!(d->flags & E4T_ACT_GELU), "gemm_tn: the GELU epilogue is not built for the TN kernel");
   E4T_REQUIRE(d->M % 8 == 0 && d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && ((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0,
               "gemm_tn: M, N, lda, ldb must be multiples of 8 and the operands 16-byte aligned");
   GemmArgs p;
@@ -1692,22 +1576,13 @@ extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
   p.rows_per_batch = 1; p.ldrb = d->N;
   p.ws = (float*)d->workspace;
   const int nkt = cdiv(p.K, BK), gx = cdiv(p.N, 128), gy = cdiv(p.M, 128);
-  const long long tiles = (long long)gx * gy;
   {   // operand extents for the buffer resources (32-bit byte offsets)
     const unsigned long long ab = ((unsigned long long)(p.K - 1) * p.lda + p.M) * 2, bb = ((unsigned long long)(p.K - 1) * p.ldb + p.N) * 2;
     E4T_REQUIRE(ab < 0xFFFF0000ull && bb < 0xFFFF0000ull, "gemm_tn: operands beyond 4 GB are not supported");
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
   }
-  int splitk = d->splitk;
-  if (splitk <= 0) {      // weight gradients: few output tiles, very long K -> fill the 512 workgroup slots by splitting K
-    splitk = (int)(512 / tiles);
-    if (splitk > 32) splitk = 32;
-    if (splitk > nkt / 16) splitk = nkt / 16;
-    if (splitk < 1) splitk = 1;
-  }
-  if (splitk > nkt) splitk = nkt;
+  int splitk = tn_splitk(p.M, p.N, p.K, d->splitk);
   p.ktiles_per_split = cdiv(nkt, splitk);
-  splitk = cdiv(nkt, p.ktiles_per_split);
   const size_t need = (size_t)splitk * p.M * p.N * sizeof(float);
   if (splitk > 1 && (p.ws == nullptr || d->workspace_bytes < need)) {
     if (d->splitk > 1) E4T_FAIL(-12, "gemm_tn: split-K=%d needs %zu workspace bytes, have %zu", splitk, need, d->workspace_bytes);
@@ -1750,11 +1625,6 @@ extern "C" int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream) {
   if (mode == E4T_CONV_S2T) E4T_REQUIRE(Hin == (Hout - 1) / 2 + 1 && Win == (Wout - 1) / 2 + 1, "conv3x3 S2T: bad sizes");
   if (mode == E4T_CONV_S2A) E4T_REQUIRE(Hout == (Hin - 2) / 2 + 1 && Wout == (Win - 2) / 2 + 1, "conv3x3 S2A: bad output size");
   GemmArgs p;
-  memset(&p, 0, sizeof(p));
-  p.A = (const bf16_t*)d->X; p.K1 = 9 * Cin; p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.Hout = Hout; p.Wout = Wout;
-  p.mode = mode; p.B = (const bf16_t*)d->W; p.ldb = 9 * Cin; p.C = d->Y; p.ldc = Cout; p.bias = d->bias;
-  p.residual = d->residual; p.ldr = Cout; p.rowbias = d->rowbias; p.rows_per_batch = Hout * Wout; p.ldrb = d->ldrb > 0 ? d->ldrb : Cout;
-  p.M = d->B * Hout * Wout; p.N = Cout; p.K = 9 * Cin; p.alpha = 1.f; p.flags = d->flags; p.ws = (float*)d->workspace;
-  p.colstats = d->colstats;
+  fill_conv_args(d, p);
   return launch_gemm(p, true, d->tile, d->workspace_bytes, d->splitk, 1, (hipStream_t)stream);
 }

@@ -1,0 +1,307 @@
+// Pieces shared by the GEMM translation units (gemm.hip, gemm_ps.hip): argument block, fused epilogue, LDS-DMA helpers,
+// XCD-aware tile raster.  Everything lives in an anonymous namespace: each translation unit gets its own copy.
+#pragma once
+#include "common.h"
+#include "../../include/e4t_hip.h"
+#include <stdlib.h>
+#include <type_traits>
+
+struct GemmArgs {
+  // A operand
+  const bf16_t* A;
+  const bf16_t* A2;
+  int K1;  // columns [0,K1) come from A, [K1,K) from A2 (K1 == K when A2 == nullptr)
+  int lda, lda2;
+  // conv geometry (MODE != 0)
+  int Hin, Win, Cin, Hout, Wout, mode;
+  // B operand [N][K]
+  const bf16_t* B;
+  int ldb;
+  // output / epilogue
+  void* C;
+  int ldc;
+  const float* bias;
+  const void* residual;
+  int ldr;
+  const float* rowbias;
+  int rows_per_batch, ldrb;
+  int M, N, K;
+  float alpha;
+  int flags;
+  // split-K / batch
+  float* ws;
+  int ktiles_per_split;
+  int splitk;       // splits per batch entry (grid.z = batch * splitk)
+  int group_m;      // row panels per raster group (xcd_tile)
+  int reduce_batch; // partials of all (batch, split) pairs are summed into ONE C
+  int fast_epi;     // bf16 C, 16-byte aligned rows: LDS-staged vectorised epilogue
+  int ps_pre;       // persistent kernel: bias / row bias prefetched into LDS by DMA (write_tile<..., PRE>)
+  long long strideA, strideB, strideC, strideBias;
+  float* colstats;                       // optional [M/32][N][2] column statistics of the output (fast bf16 epilogue only)
+  unsigned a_bytes, a2_bytes, b_bytes;   // operand extents from the (batch-adjusted) base pointers, for buffer resources (pp kernel)
+};
+
+namespace {
+
+constexpr int BK = 64;        // K-tile (bf16 elements)
+constexpr int LDS_LD = BK + 8;  // padded LDS row stride (elements): 144 B
+
+
+__device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int row, int col) {
+  v *= p.alpha;
+  if (p.bias) v += p.bias[col];
+  if (p.rowbias) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
+  if (p.flags & E4T_ACT_GELU) v = gelu_f(v);
+  if (p.residual) {
+    if (p.flags & E4T_RES_F32) v += ((const float*)p.residual)[(size_t)row * p.ldr + col];
+    else v += bf2f(((const bf16_t*)p.residual)[(size_t)row * p.ldr + col]);
+  }
+  if (p.flags & E4T_OUT_F32) {
+    float* c = (float*)p.C + (size_t)row * p.ldc + col;
+    if (p.flags & E4T_ACCUM) v += *c;
+    *c = v;
+  } else {
+    bf16_t* c = (bf16_t*)p.C + (size_t)row * p.ldc + col;
+    if (p.flags & E4T_ACCUM) v += bf2f(*c);
+    *c = f2bf(v);
+  }
+}
+
+// LDS staging area of wave `wave` for write_tile<WM, WN, ...> when the waves' areas are packed back to back from `smem`.
+template <int WM, int WN>
+__device__ __forceinline__ bf16_t* wave_stage(bf16_t* smem, int wave) { return smem + wave * (WM * (WN + 8)); }
+
+// Write one wave's WM x WN accumulator tile (origin mw, nw) with the fused epilogue.
+#ifdef DMA_TRACE
+#define WT_STAMP(k) do { if (dt_ptr) dt_ptr[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WT_STAMP(k) do { } while (0)
+#endif
+// GENERAL: the epilogue variant with the exact-GELU activation and the per-row row-bias lookup (rows_per_batch not a multiple of
+// 32).  It is a separate INSTANTIATION, not a branch: inlined next to the plain path its erff expansion over 16 x FM x FN
+// elements set the register allocation of the whole kernel (288 instead of 208 registers in the 128 x 160 tile = one
+// workgroup per CU instead of two).  The launcher picks the variant (launch_gemm).
+// PRE (persistent kernel, gemm_ps.hip): bias and row bias of the tile's columns were brought into LDS ahead of time (pre_bias /
+// pre_rb point at the entry of column nw; one row-bias row per tile) and the staging barrier is a raw s_barrier: no global load
+// and no compiler-placed vmcnt(0) sits between the K loop and the staging writes, so the operand DMA of the NEXT tile, in flight
+// at this point, is not drained in front of the epilogue (vmcnt is an in-order counter: waiting for a load issued here means
+// waiting for every DMA issued before it).
+template <int WM, int WN, int FM, int FN, bool GENERAL = false, bool PRE = false>
+__device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][FN], bf16_t* stage, int lane, int mw, int nw,
+                                           unsigned long long* dt_ptr = nullptr, const float* pre_bias = nullptr, const float* pre_rb = nullptr) {
+  const int frow = lane & 31, fhi = lane >> 5;
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  const bool partial = p.ws != nullptr;
+  if (!partial && p.fast_epi) {
+    // bf16 output: stage the wave's WM x WN tile through LDS (the operand tiles are dead after the loop's final
+    // barrier) so that C is written — and the residual read — as 16-byte chunks, 128 B contiguous per row.
+    // alpha, bias, row bias and GELU are applied in fp32 before the bf16 rounding; the residual is added to the
+    // rounded value in fp32 and rounded again, which is exactly what a bf16 linear followed by a bf16 add does.
+    constexpr int ELD = WN + 8;          // `stage`: this wave's own WM x ELD staging area in LDS (see wave_stage())
+    // Everything the epilogue reads from global memory is fetched by UNCONDITIONAL loads issued back to back (indices clamped
+    // into range, values masked afterwards).  The first version guarded each load (`col < N ? bias[col] : 0`, the row-bias
+    // inside the 16-element loop, the residual chunk inside the store loop): the compiler answered every guarded load with its
+    // own s_waitcnt vmcnt(0) — FN serialized L2 round trips for the bias, 16 x FM x FN for the ResBlock time-embedding row-bias
+    // (85 in the 128 x 160 conv tile), one per 16-byte residual chunk (10) — in the epilogue of EVERY workgroup (ISA, round 2).
+    float bv[FN], rbv[FM][FN];
+    const bool rb_blocked = p.rowbias && (p.rows_per_batch % 32 == 0);        // a 32-row fragment lies inside one batch entry
+    if constexpr (PRE) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        bv[j] = pre_bias[j * 32 + frow];
+        const float rb = pre_rb[j * 32 + frow];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) rbv[i][j] = rb;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = min(nw + j * 32 + frow, p.N - 1);
+        bv[j] = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int row = min(mw + i * 32, p.M - 1);
+          rbv[i][j] = rb_blocked ? p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col] : 0.f;
+        }
+      }
+    }
+    WT_STAMP(13);
+    // The uniform special cases (GELU epilogue, per-row row-bias lookup) are decided ONCE, outside the 16 x FM x FN element loop: as
+    // per-element `if`s they were two scalar branches per element — the staging of a 32 x 160 wave tile took 8300 of the
+    // workgroup's 32000 cycles on the K = 320 projections (cycle stamps, tools/dma_trace.sh), 1400 without them.
+    const bool rb_slow = !PRE && p.rowbias && !rb_blocked;
+    if constexpr (!GENERAL) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int cl = j * 32 + frow;
+          const float add = bv[j] + rbv[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+            stage[rl * ELD + cl] = f2bf(acc[i][j][r] * p.alpha + add);
+          }
+          // one fragment at a time: without the fence the scheduler pulls the accumulator reads of ALL fragments (80 AGPR -> VGPR
+          // copies in the 128 x 160 tile) in front of the first write, and the kernel loses one of its two waves per SIMD
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+      const bool gelu = (p.flags & E4T_ACT_GELU) != 0;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int cl = j * 32 + frow;
+          const int col = nw + cl;
+          const float add = bv[j] + rbv[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+            float v = acc[i][j][r] * p.alpha + add;
+            if (rb_slow) {      // odd geometry (rows_per_batch not a multiple of 32): per-row lookup
+              const int row = mw + rl;
+              if (row < p.M && col < p.N) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
+            }
+            if (gelu) v = gelu_f(v);
+            stage[rl * ELD + cl] = f2bf(v);
+          }
+        }
+    }
+    WT_STAMP(14);
+    // (a wave only reads back its own region; the barrier orders the LDS traffic)
+    if constexpr (PRE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    else __syncthreads();
+    WT_STAMP(15);
+    constexpr int CPR = WN / 8;          // 16-byte chunks per row
+    constexpr int NIT = (WM * CPR + 63) / 64;
+    bf16_t* Cb = (bf16_t*)p.C;
+    const bf16_t* Rb = (const bf16_t*)p.residual;
+    // residual chunks are fetched RB at a time ahead of their use (all loads of a batch back to back); RB = 4 keeps the 128 x 160
+    // kernel at 2 waves per SIMD (10 chunks in flight at once cost 40 VGPRs and one of the two resident workgroups per CU)
+    constexpr int RB = NIT < 4 ? NIT : 4;
+    // RES: a residual is added.  PRE splits the two cases into separate bodies (a uniform branch): in ONE body the compiler waits
+    // for the conditional residual loads unconditionally (vmcnt(0) at the join) and the residual-free GEMMs would drain the next
+    // tile's DMA in front of their first C store.
+    auto store_rows = [&](auto RESc) {
+      constexpr bool RES = decltype(RESc)::value;
+#pragma unroll
+      for (int it0 = 0; it0 < NIT; it0 += RB) {
+        uint4 rres[RB];
+        if (RES && Rb) {
+#pragma unroll
+          for (int u = 0; u < RB; ++u) {
+            const int idx = min((it0 + u) * 64 + lane, WM * CPR - 1);
+            const int rl = idx / CPR, cch = idx - rl * CPR;
+            const int row = min(mw + rl, p.M - 1), col = min(nw + cch * 8, p.N - 8);
+            rres[u] = *(const uint4*)(Rb + (size_t)row * p.ldr + col);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int it = it0 + u;
+          if (it >= NIT) break;
+          const int idx = it * 64 + lane;
+          const int rl = idx / CPR, cch = idx - rl * CPR;
+          const int row = mw + rl, col = nw + cch * 8;
+          if (idx < WM * CPR && row < p.M && col < p.N) {
+            uint4 v = *(const uint4*)(stage + rl * ELD + cch * 8);
+            if (RES && Rb) {
+              float a[8], b[8];
+              unpack8(v, a);
+              unpack8(rres[u], b);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) a[k] += b[k];
+              v = pack8(a);
+              if (p.colstats) *(uint4*)(stage + rl * ELD + cch * 8) = v;      // the statistics are those of the FINAL values
+            }
+            *(uint4*)(Cb + (size_t)row * p.ldc + col) = v;
+          }
+        }
+      }
+    };
+    if constexpr (PRE) {
+      if (Rb) store_rows(std::true_type{});
+      else store_rows(std::false_type{});
+    } else {
+      store_rows(std::true_type{});
+    }
+    if (p.colstats) {
+      // Per-column (sum, sum of squares) of this wave's output rows, one record per 32-row block: the GroupNorm that consumes
+      // this tensor reduces these few floats instead of re-reading the whole activation (norm.hip, gn_finalize_cols_kernel).
+      // The wave reads back its own staged (bf16, final) tile; LDS operations of one wave execute in order.
+#pragma unroll
+      for (int c0 = 0; c0 < WN; c0 += 64) {
+        const int cl = c0 + lane, col = nw + cl;
+        if (cl < WN && col < p.N) {
+#pragma unroll
+          for (int rb = 0; rb < WM / 32; ++rb) {
+            if (mw + rb * 32 >= p.M) break;                               // M % 32 == 0 whenever statistics are requested
+            float sm = 0.f, sq = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) {
+              const float x = bf2f(stage[(rb * 32 + r) * ELD + cl]);
+              sm += x; sq += x * x;
+            }
+            float* o = p.colstats + ((size_t)((mw >> 5) + rb) * p.N + col) * 2;
+            o[0] = sm; o[1] = sq;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int col = nw + j * 32 + frow;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+        if (row >= p.M) continue;
+        if (partial) p.ws[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[i][j][r];  // z = batch*splitk + split
+        else epilogue_store(p, acc[i][j][r], row, col);
+      }
+    }
+}
+
+// The same DMA through a buffer resource: 32-bit per-lane byte offset + wave-uniform SGPR byte offset; out-of-range offsets read
+// as zero.  (Kept in a non-template helper: the builtin is not instantiable from a value-dependent context on the host pass.)
+__device__ __forceinline__ void buf_dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff, bf16_t* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+// Workgroup -> output-tile mapping.  The dispatcher deals consecutive workgroups (x fastest) round-robin over the 8 XCDs,
+// each with its own 4-MiB L2: with the plain blockIdx mapping the tiles sharing an A row panel (and, for the 3x3 convs,
+// the neighbouring image rows of the halo) sit in 8 different L2s and every panel is fetched 8 times.  Re-deal so that
+// the workgroups of one XCD own one CONTIGUOUS chunk of the tile raster, and walk that chunk in groups of 8 row panels
+// so the ~64 tiles in flight on an XCD form a compact 8 x 8 block of the output.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by, int GM) {
+  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
+  const int lin = blockIdx.y * gx + blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, v = lin & 7;
+  const int lin2 = (v < r ? v * (q + 1) : r * (q + 1) + (v - r) * q) + (lin >> 3);
+  const int per = GM * gx, grp = lin2 / per, l = lin2 - grp * per;
+  const int first = grp * GM, gsz = min(gy - first, GM);
+  bx = l / gsz;
+  by = first + (l - bx * gsz);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// The K-loop barrier of the DMA kernels.  After it, some wave starts the LDS-DMA of a new tile INTO THE STAGE EVERY WAVE READ IN
+// THE ITERATION BEFORE, so every wave's fragment reads of that stage must have COMPLETED, not merely been issued, when it
+// arrives.  s_barrier alone does not order that: the compiler sinks the last k-step's MFMA — and the lgkmcnt wait in front of
+// it — below the barrier (gfx950 needs no counter drain at s_barrier), leaving ds_reads in flight across it.  Measured: with
+// three 4-wave workgroups per CU (64 x 64 tile, 3 stages) 0-2 of 1280 output tiles per launch came out wrong, not
+// reproducibly — a DMA that hit in L2 landed before a ds_read queued behind the other workgroups' LDS traffic had executed.
+// Draining lgkmcnt first closes the window for every stage count.
+__device__ __forceinline__ void loop_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+}  // namespace

@@ -35,6 +35,11 @@ class ConvDesc(C.Structure):
     ]
 
 
+class GemmPlan(C.Structure):
+    """e4t_gemm_plan_t: what the launcher will run for a descriptor (tile code, tile dims, split-K, workspace it wants)"""
+    _fields_ = [("tile", i32), ("tile_m", i32), ("tile_n", i32), ("splitk", i32), ("workspace_bytes", sz)]
+
+
 class WODesc(C.Structure):
     _fields_ = (
         [(n, vp) for n in ("v", "w1", "b1", "w2", "b2", "wc", "bc", "wr", "br", "W", "vecs", "partial", "weff", "weffT", "dweff")]
@@ -53,6 +58,9 @@ SIGNATURES = {
     "e4t_gemm_nt": (i32, [C.POINTER(GemmDesc), vp]),
     "e4t_gemm_tn": (i32, [C.POINTER(GemmDesc), vp]),
     "e4t_conv3x3": (i32, [C.POINTER(ConvDesc), vp]),
+    "e4t_gemm_plan": (i32, [C.POINTER(GemmDesc), C.POINTER(GemmPlan)]),
+    "e4t_gemm_tn_plan": (i32, [C.POINTER(GemmDesc), C.POINTER(GemmPlan)]),
+    "e4t_conv3x3_plan": (i32, [C.POINTER(ConvDesc), C.POINTER(GemmPlan)]),
     "e4t_attention_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, i32, vp]),
     "e4t_attention_bwd": (i32, [vp] * 10 + [i32] * 9 + [i64] * 4 + [f32, i32, vp]),
     "e4t_groupnorm_num_chunks": (i32, [i32, i32]),

@@ -60,47 +60,6 @@ def _rowmajor(t: torch.Tensor, name: str):
 
 
 
-_AUTO_PT = os.environ.get("E4T_GEMM_PT") is not None      # mirror of the launcher's opt-in switch for the 512x128 tile
-
-
-def _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch, conv=False):
-    """Mirror of launch_gemm()'s tile / split-K heuristic (csrc/gemm.hip) -> workspace bytes it will want."""
-    cd = lambda a, b: (a + b - 1) // b
-    nkt = cd(K, 64)
-    if 3000 <= tile < 6000:
-        tile %= 1000            # thousands digit = forced LDS stage count (3128, 4160, ...) / 32-wide K-tiles (5128)
-    if tile not in (64, 128, 256, 160, 512, 640):
-        t128 = cd(M, 128) * cd(N, 128) * nb
-        tile = 128 if (t128 >= 256 or (nkt >= 32 and t128 >= 64)) else 64
-        if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
-            tile = 160
-        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= (16 if conv else 32) and cd(M, 256) * (N // 256) * nb >= 512:
-            tile = 512
-        tpp = cd(M, 256) * (N // 256) * nb
-        if tile == 128 and N % 256 == 0 and K % 64 == 0 and nkt >= 128 and 64 <= tpp < 512:
-            tile = 512
-        if _AUTO_PT and tile == 128 and N % 128 == 0 and N % 256 and K % 64 == 0 and nkt >= 16 and cd(M, 512) * (N // 128) * nb >= 512:
-            tile = 640          # opt-in (E4T_GEMM_PT=1): measured slower than 128x128 on the shapes it targets
-    if tile in (512, 640) and K % 64:
-        tile = 128
-    tn, tm = {256: 128, 512: 256, 640: 128}.get(tile, tile), {160: 128, 512: 256, 640: 512}.get(tile, tile)
-    tiles = cd(N, tn) * cd(M, tm) * nb
-    if splitk <= 0:
-        splitk = 1
-        if tile == 512 and tiles < 256:
-            splitk = min(256 // tiles, nkt // 16)
-        elif tile >= 128 and tiles < 512 and nkt >= 32:
-            splitk = min((512 if tiles <= 256 else 1024) // tiles, 8, nkt // 16)
-            if tiles > 256 and nkt < 128:
-                splitk = 1
-        elif tile == 64 and tiles < 256 and nkt >= 32:
-            splitk = min(cd(512, tiles), nkt // 16)
-        splitk = max(splitk, 1)
-    splitk = min(splitk, nkt)
-    splitk = cd(nkt, cd(nkt, splitk))
-    return 4 * splitk * nb * M * N if (splitk > 1 or reduce_batch) else 0
-
-
 @dataclass
 class WOEntry:
     """One WeightOffsets instance + the projection weight it modulates (row = in, col = out)."""
@@ -154,26 +113,12 @@ class HipBackend:
         self.prof.append((key, flops, float(nbytes() if callable(nbytes) else nbytes), e0, e1))
         return r
 
-    @staticmethod
-    def _tile(M, N, K, nb, tile, conv=False):
-        """Mirror of launch_gemm()'s tile choice (csrc/gemm.hip), used only to label bench.py's per-kernel timings."""
-        if 3000 <= tile < 6000:
-            tile %= 1000
-        if tile in (64, 128, 256, 160, 512, 640):
-            return tile
-        cd = lambda a, b: (a + b - 1) // b
-        t128 = cd(M, 128) * cd(N, 128) * nb
-        tile = 128 if (t128 >= 256 or (cd(K, 64) >= 32 and t128 >= 64)) else 64
-        if tile == 128 and N % 160 == 0 and N <= 960 and cd(M, 128) * (N // 160) * nb >= 128:
-            tile = 160
-        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= (16 if conv else 32) and cd(M, 256) * (N // 256) * nb >= 512:
-            tile = 512
-        tpp = cd(M, 256) * (N // 256) * nb
-        if tile == 128 and N % 256 == 0 and K % 64 == 0 and cd(K, 64) >= 128 and 64 <= tpp < 512:
-            tile = 512
-        if _AUTO_PT and tile == 128 and N % 128 == 0 and N % 256 and K % 64 == 0 and cd(K, 64) >= 16 and cd(M, 512) * (N // 128) * nb >= 512:
-            tile = 640
-        return tile
+    def _plan(self, fn, d, what):
+        """tile / split-K / workspace the launcher will use for descriptor `d` (e4t_gemm_plan & co.: the heuristic lives in the
+        library only; nothing here mirrors it)"""
+        pl = _C.GemmPlan()
+        _C.check(fn(C.byref(d), C.byref(pl)), what)
+        return pl
 
     # ------------------------------------------------------------------ workspaces
     def workspace(self, nbytes: int, device) -> torch.Tensor:
@@ -235,8 +180,8 @@ class HipBackend:
         d.strideA, d.strideB = sA, sB
         d.strideC = out.stride(0) if (batched and not reduce_batch) else 0
         d.strideBias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
-        need = _gemm_ws_need(M, N, K, nb, tile, splitk, reduce_batch)
-        ws = self.workspace(need, a.device) if need else None
+        pl = self._plan(self.lib.e4t_gemm_plan, d, "e4t_gemm_plan")
+        ws = self.workspace(pl.workspace_bytes, a.device) if pl.workspace_bytes else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
         cs = self._colstats_buf(out, M, N, colstats and not batched)
@@ -244,7 +189,7 @@ class HipBackend:
         # algorithmic bytes: A, B once; C once (+ once more when read: residual / accumulate)
         nbytes = lambda: (2.0 * nb * M * K + 2.0 * N * K * (nb if sB else 1) + out.element_size() * M * N * (1 if reduce_batch else nb) * (2 if accum else 1)
                           + (residual.element_size() * M * N if residual is not None else 0))
-        rc = self._timed(f"gemm{self._tile(M, N, K, nb, tile)}", 2.0 * M * N * K * nb,
+        rc = self._timed(f"gemm{pl.tile}", 2.0 * M * N * K * nb,
                          lambda: _C.check(self.lib.e4t_gemm_nt(C.byref(d), st), "e4t_gemm_nt"), nbytes)
         if cs is not None and rc == 1:
             out._e4t_colstats = cs          # consumed by groupnorm_fwd (the GroupNorm of this activation skips its statistics pass)
@@ -266,10 +211,8 @@ class HipBackend:
         d.lda, d.ldb, d.ldc = a.stride(0), b.stride(0), out.stride(0)
         flags = (_C.OUT_F32 if out.dtype == f32 else 0) | (_C.ACCUM if accum else 0)
         d.flags, d.splitk, d.batch, d.alpha = flags, splitk, 1, alpha
-        cd = lambda x, y: (x + y - 1) // y
-        nkt, tiles = cd(K, 64), cd(M, 128) * cd(N, 128)
-        sk = splitk if splitk > 0 else max(1, min(512 // tiles, 32, nkt // 16))
-        ws = self.workspace(4 * sk * M * N, a.device) if sk > 1 else None
+        pl = self._plan(self.lib.e4t_gemm_tn_plan, d, "e4t_gemm_tn_plan")
+        ws = self.workspace(pl.workspace_bytes, a.device) if pl.workspace_bytes else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
         self._timed("gemm_tn", 2.0 * M * N * K, lambda: _C.check(self.lib.e4t_gemm_tn(C.byref(d), st), "e4t_gemm_tn"),
@@ -296,8 +239,8 @@ class HipBackend:
             flags |= _C.ACCUM
         d.mode, d.flags, d.tile, d.splitk = mode, flags, tile, splitk
         d.ldrb = rowbias.stride(0) if rowbias is not None else 0
-        need = _gemm_ws_need(M, Cout, 9 * Cin, 1, tile, splitk, False, conv=True)
-        ws = self.workspace(need, x.device) if need else None
+        pl = self._plan(self.lib.e4t_conv3x3_plan, d, "e4t_conv3x3_plan")
+        ws = self.workspace(pl.workspace_bytes, x.device) if pl.workspace_bytes else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
         cs = self._colstats_buf(out, M, Cout, colstats)
@@ -305,7 +248,7 @@ class HipBackend:
         # algorithmic bytes: the input map once (not once per tap), the weights once, the output once (+ residual)
         nbytes = 2.0 * B * Hin * Win * Cin + 2.0 * Cout * 9 * Cin + out.element_size() * M * Cout * (2 if accum else 1) + \
             (residual.element_size() * M * Cout if residual is not None else 0)
-        rc = self._timed(f"conv{self._tile(M, Cout, 9 * Cin, 1, tile, conv=True)}", 2.0 * M * Cout * 9 * Cin,
+        rc = self._timed(f"conv{pl.tile}", 2.0 * M * Cout * 9 * Cin,
                          lambda: _C.check(self.lib.e4t_conv3x3(C.byref(d), st), "e4t_conv3x3"), nbytes)
         if cs is not None and rc == 1:
             out._e4t_colstats = cs

@@ -60,7 +60,8 @@ typedef struct {
   int lda, lda2, ldb, ldc, ldr;
   int rows_per_batch;
   int flags;
-  int tile;            /* 0 = auto; 64, 128, 160 (= 128x160), 256 (= 256x128), 512 (= 256x256 ping-pong), 640 (= 512x128);
+  int tile;            /* 0 = auto; 64, 128, 160 (= 128x160), 256 (= 256x128), 512 (= 256x256 ping-pong), 640 (= 512x128),
+                          1128 / 1160 (= persistent streaming 256x128 / 256x160, gemm_ps.hip; needs K % 64 == 0, batch 1, no split-K);
                           + 3000 / 4000 forces 3 / 4 LDS stages on the 64 / 128 / 160 tiles (e.g. 3128) */
   int splitk;          /* 0 = auto, >= 1 forced */
   int batch;           /* >= 1; operand base pointers advance by the strides below (elements) */
@@ -104,6 +105,21 @@ typedef struct {
   float* colstats;     /* optional out, as in e4t_gemm_desc (M = B*Hout*Wout, N = Cout) */
 } e4t_conv_desc;
 int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream);
+
+/* What the launcher will do for a descriptor, WITHOUT launching: the tile it picks (codes as e4t_gemm_desc.tile; tile_m x tile_n
+ * are its dimensions), the split-K factor, and the fp32 workspace (bytes) the call wants for it — e4t_gemm_nt / e4t_conv3x3 fall
+ * back to a single pass when handed less in auto mode, and fail with -12 when split-K or REDUCE_BATCH was requested explicitly.
+ * The pointer fields of the descriptor are not read (they may be NULL); shapes, strides, flags, tile, splitk and batch are.
+ * This is the one statement of the tile / split-K heuristic: callers size workspaces and label timings from it (SURVEY §8b
+ * "query size via e4t_<op>_workspace_bytes"). */
+typedef struct {
+  int tile, tile_m, tile_n;
+  int splitk;
+  size_t workspace_bytes;
+} e4t_gemm_plan_t;
+int e4t_gemm_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out);
+int e4t_gemm_tn_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out);
+int e4t_conv3x3_plan(const e4t_conv_desc* d, e4t_gemm_plan_t* out);
 
 /* ---------------------------------------------------------------- attention (attention.hip) -- */
 /* O = softmax(Q K^T * scale) V ; Q/K/V/O are (B, T|S, heads*DH) bf16 matrices with row strides ld*

@@ -56,6 +56,11 @@ def check_gemm(hip, emu, dev):
         (2048, 1280, 1920, 512, 0), (257, 64, 192, 512, 1),
         (4096, 1280, 10240, 0, 0), (4096, 2560, 8192, 0, 0),       # auto: K-deep, 64-255 tiles of 256 x 256 -> ping-pong + split-K (3 | 1)
         (1024, 128, 512, 640, 1), (700, 128, 1152, 640, 1), (1300, 384, 256, 640, 1), (513, 100, 64, 640, 1), (2048, 128, 2048, 640, 0), (4096, 128, 4096, 640, 3),
+        # persistent streaming tiles (gemm_ps.hip): 256 x 160 / 256 x 128; ragged M / N, one K-tile, several units per workgroup
+        (1000, 320, 320, 1160, 1), (513, 200, 128, 1128, 1), (4096, 640, 2560, 1160, 0), (70000, 320, 320, 1160, 1), (33000, 256, 192, 1128, 1),
+        (300, 480, 128, 1160, 1), (2048, 128, 64, 1128, 1), (256, 160, 64, 1160, 1), (66000, 100, 64, 1128, 1), (4112, 1280, 1280, 1160, 1),
+        (1000, 256, 328, 1128, 1),                                   # K % 64 != 0: falls back to the 128 x 128 tile
+        (900, 384, 512, 5256, 1), (5000, 640, 320, 5256, 1),         # experimental: 256 x 128, 32-wide K-tiles
     ]
     for i, (M, N, K, tile, sk) in enumerate(cases):
         g = gen(10 + i, dev)
@@ -80,7 +85,8 @@ def check_gemm(hip, emu, dev):
     hip.gemm_tn(a, b, out=wide[:, 100:428]); emu.gemm_tn(a, b, out=wide2[:, 100:428])
     out.append(("gemm_tn into a column slice", rel(wide, wide2), TOLF * 50))
     # column statistics left by the epilogue for the consuming GroupNorm (all tile variants; with / without residual)
-    for i, (M, N, K, tile) in enumerate([(256, 128, 128, 0), (4096, 320, 320, 160), (1024, 640, 1280, 128), (2048, 512, 2304, 512), (192, 72, 64, 64)]):
+    for i, (M, N, K, tile) in enumerate([(256, 128, 128, 0), (4096, 320, 320, 160), (1024, 640, 1280, 128), (2048, 512, 2304, 512), (192, 72, 64, 64),
+                                         (4096, 320, 320, 1160), (8192, 256, 128, 1128), (66560, 640, 192, 1160), (34816, 128, 64, 1128)]):
         g = gen(60 + i, dev)
         a, b = rnd(g, M, K, dev=dev), rnd(g, N, K, scale=K ** -0.5, dev=dev)
         res = rnd(g, M, N, dev=dev) if i % 2 == 0 else None
@@ -98,6 +104,9 @@ def check_gemm(hip, emu, dev):
     out.append(("gemm gelu fp32-out t512", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32, tile=512),
                                                 emu.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32)), TOLF * 50))
     out.append(("gemm gelu", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
+    for t in (512, 1128, 1160):      # the GENERAL epilogue instantiations of the ping-pong / persistent kernels
+        out.append((f"gemm gelu t{t}", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True, tile=t), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
+        out.append((f"gemm two-source A t{t}", rel(hip.gemm(a1, b, a2=a2, tile=t), emu.gemm(a1, b, a2=a2)), TOL1))
     c0 = rnd(g, M, N, dtype=f32, dev=dev)
     c1, c2 = c0.clone(), c0.clone()
     hip.gemm(a1, b[:, :K1].contiguous(), out=c1, accum=True, alpha=0.5)
@@ -106,6 +115,10 @@ def check_gemm(hip, emu, dev):
     rb = rnd(g, M // 96, N, dtype=f32, dev=dev)
     out.append(("gemm rowbias", rel(hip.gemm(a1, b[:, :K1].contiguous(), rowbias=rb, rows_per_batch=96),
                                     emu.gemm(a1, b[:, :K1].contiguous(), rowbias=rb, rows_per_batch=96)), TOL1))
+    for t in (1128, 1160):
+        out.append((f"gemm rowbias t{t}", rel(hip.gemm(a1, b[:, :K1].contiguous(), rowbias=rb, rows_per_batch=96, tile=t),
+                                              emu.gemm(a1, b[:, :K1].contiguous(), rowbias=rb, rows_per_batch=96)), TOL1))
+        out.append((f"gemm strided A view t{t}", rel(hip.gemm(a1[:, 64:], b[:, :64].contiguous(), tile=t), emu.gemm(a1[:, 64:], b[:, :64].contiguous())), TOL1))
     # strided views (column slices of a wider buffer)
     wide = rnd(g, M, 3 * K1, dev=dev)
     out.append(("gemm strided A view", rel(hip.gemm(wide[:, K1:2 * K1], b[:, :K1].contiguous()), emu.gemm(wide[:, K1:2 * K1], b[:, :K1].contiguous())), TOL1))
@@ -134,6 +147,11 @@ def check_conv(hip, emu, dev):
         (1, 64, 64, 128, 128, 5, 32, 32, 512, 1),
         (2, 32, 32, 128, 128, CONV_S1, 32, 32, 640, 1), (1, 48, 40, 64, 128, CONV_S1, 48, 40, 640, 1), (3, 16, 16, 128, 384, CONV_S1, 16, 16, 640, 2),
         (1, 64, 64, 128, 128, 5, 32, 32, 640, 1), (2, 16, 16, 128, 128, CONV_UP2, 32, 32, 640, 1), (2, 32, 32, 128, 128, CONV_S2, 16, 16, 640, 1),
+        # persistent streaming tiles: every gather mode; B16 64x64 = 256 row panels x 2 column tiles = two units per workgroup
+        (4, 32, 32, 320, 320, CONV_S1, 32, 32, 1160, 1), (2, 64, 64, 128, 128, CONV_S1, 64, 64, 1128, 1), (16, 64, 64, 64, 320, CONV_S1, 64, 64, 1160, 1),
+        (3, 24, 24, 64, 192, CONV_S1, 24, 24, 1128, 1), (3, 16, 16, 64, 128, CONV_S2, 8, 8, 1128, 1), (2, 8, 8, 64, 160, CONV_UP2, 16, 16, 1160, 1),
+        (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 1128, 1), (1, 64, 64, 128, 128, 5, 32, 32, 1128, 1), (18, 64, 64, 128, 128, CONV_S1, 64, 64, 1128, 1),
+        (2, 48, 40, 64, 320, CONV_S1, 48, 40, 5256, 1),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
         g = gen(50 + i, dev)
@@ -432,13 +450,15 @@ def check_gemm_races(hip, emu, dev):
     Grids of several waves, 2-5 workgroups per CU, operands larger than one XCD's L2."""
     out = []
     g = gen(400, dev)
-    for M, N, K in [(4096, 1280, 320), (8192, 1280, 512), (16384, 640, 640)]:
+    for M, N, K in [(4096, 1280, 320), (8192, 1280, 512), (16384, 640, 640), (131072, 320, 320)]:
         a, w = rnd(g, M, K, dev=dev), rnd(g, N, K, dev=dev)
         want = emu.gemm(a, w)
         ref = hip.gemm(a, w, tile=128)
         out.append((f"race-check reference {M}x{N}x{K}", rel(ref, want), TOL1))
-        for code in (64, 3064, 4064, 128, 3128, 4128, 160, 3160, 4160):
+        for code in (64, 3064, 4064, 128, 3128, 4128, 160, 3160, 4160, 1128, 1160, 5256, 512):
             if code % 1000 == 160 and N % 160:
+                continue
+            if code == 512 and N % 256:
                 continue
             differing = 0
             for _ in range(12):
@@ -446,7 +466,7 @@ def check_gemm_races(hip, emu, dev):
             out.append((f"gemm {M}x{N}x{K} tile code {code}: launches (of 12) differing from the reference", float(differing), 0.0))
     x, w = rnd(g, 16 * 32 * 32, 640, dev=dev), rnd(g, 640, 9 * 640, dev=dev)
     ref = hip.conv3x3(x, w, 16, 32, 32, 32, 32, CONV_S1, tile=128)
-    for code in (128, 3128, 160, 4160, 64, 3064):
+    for code in (128, 3128, 160, 4160, 64, 3064, 1128, 1160):
         differing = sum(int((hip.conv3x3(x, w, 16, 32, 32, 32, 32, CONV_S1, tile=code) != ref).sum() > 0) for _ in range(6))
         out.append((f"conv 32x32 640->640 tile code {code}: launches (of 6) differing", float(differing), 0.0))
     dy, xx = rnd(g, 16384, 640, dev=dev), rnd(g, 16384, 1280, dev=dev)
