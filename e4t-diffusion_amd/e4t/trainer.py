@@ -111,6 +111,15 @@ class E4TTrainer:
         self._setup_overlap(named, n)
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
+        # replica consistency (the reference gets it from the DDP constructor, which broadcasts rank 0's parameters and buffers when
+        # accelerate wraps the models, pretrain_e4t.py:410-412): every rank starts from rank 0's weights — trainable AND frozen —
+        # whatever its own seed / checkpoint read produced, and a checksum of the trainable state is compared every
+        # `replica_check_every` optimiser steps (E4T_REPLICA_CHECK_EVERY, default 100, 0 = off): diverged replicas abort loudly
+        # instead of training on silently.
+        self.replica_check_every = int(os.environ.get("E4T_REPLICA_CHECK_EVERY", "100"))
+        self.comm_timing = None          # bench.py sets a dict: per-region enqueue times and the exposed wait of the last step
+        if self.world > 1:
+            self.sync_replicas(include_frozen=True)
         ops.bump_weights_epoch()
         # constants of the loop (pretrain_e4t.py:561-583); with a trainable text encoder they are re-evaluated every step, detached,
         # as tuning_e4t.py:276-284 does
@@ -118,6 +127,48 @@ class E4TTrainer:
         self.empty_prompt_ids = (empty_prompt_ids if empty_prompt_ids is not None else torch.zeros((1, 77), dtype=torch.long)).to(self.device)
         self._refresh_text_constants()
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self._comm and self.device.type == "cuda") else None
+
+    # ---- replica consistency -----------------------------------------------------------------------------------------------
+    def sync_replicas(self, include_frozen=False, include_moments=False):
+        """rank 0's state -> every rank: the flat trainable buffer (+ Adam moments on resume), optionally every frozen parameter
+        and buffer of the models (DDP-constructor semantics).  No-op without a process group."""
+        if self.world <= 1:
+            return
+        bc = lambda t: torch.distributed.broadcast(t, src=torch.distributed.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+        bc(self.flat.data)
+        if include_moments:
+            bc(self.exp_avg); bc(self.exp_avg_sq)
+            cnt = torch.tensor([self.step_count], dtype=torch.int64, device=self.device)
+            bc(cnt)
+            self.step_count = int(cnt)
+        if include_frozen:
+            mine = {id(p) for p in self.flat.params}
+            for m in (self.unet, self.encoder, self.text_encoder, self.vae):
+                if m is None:
+                    continue
+                for t in list(m.parameters()) + list(m.buffers()):
+                    if id(t) not in mine and t.numel() and (t.is_floating_point() or t.dtype in (torch.int32, torch.int64)):
+                        bc(t.data)
+        ops.bump_weights_epoch()
+
+    def check_replicas(self):
+        """every rank must hold bit-identical trainable parameters (deterministic kernels + the same all-reduced gradient): compare
+        one checksum pair (sum of squares of the parameters and of exp_avg) across ranks; raises on every rank when they differ"""
+        if self.world <= 1:
+            return True
+        if self.flat.data.is_cuda:
+            be = ops.backend()
+            c = torch.stack([be.sumsq(self.flat.data), be.sumsq(self.exp_avg)]).double()
+        else:
+            c = torch.stack([self.flat.data.double().pow(2).sum(), self.exp_avg.double().pow(2).sum()])
+        lo, hi = c.clone(), c.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+        if not torch.equal(lo, hi):
+            raise RuntimeError(f"data-parallel replicas diverged at optimiser step {self.step_count}: checksum range {lo.tolist()} .. {hi.tolist()} "
+                               "(ranks no longer hold identical parameters — different seeds / checkpoints without the start-up broadcast, "
+                               "or a non-deterministic gradient path)")
+        return True
 
     def _refresh_text_constants(self):
         with torch.no_grad():
@@ -210,12 +261,17 @@ class E4TTrainer:
         pid = {id(p): n for n, p in named}          # `named` order == flat order only after the first_linears re-ordering
         flat_names = [pid[id(p)] for p in params]
         first_unet = next(i for i, n in enumerate(flat_names) if n.startswith("unet."))
+        first_text = next((i for i, n in enumerate(flat_names) if n.startswith("text_encoder.")), first_unet)
         first_up = next(i for i, n in enumerate(flat_names) if n.startswith("unet.up_blocks."))
         tail = ("unet.up_blocks.", "unet.conv_norm_out.", "unet.conv_out.")
         assert all(n.startswith(tail) for n in flat_names[first_up:]) and all(not n.startswith("unet.") for n in flat_names[:first_unet])
         assert not any(n.startswith(tail) for n in flat_names[first_unet:first_up])
+        assert all(n.startswith("e4t_encoder.") for n in flat_names[:first_text]) and all(n.startswith("text_encoder.") for n in flat_names[first_text:first_unet])
         o = self.flat.offsets
-        self.regions = dict(H=(0, o[first_unet]), D=(o[first_unet], o[first_up]), U=(o[first_up], self.flat.numel))
+        # T (trainable text encoder, tuning_e4t.py --train_text_encoder): its token embedding is the OLDEST autograd node of the step
+        # (inputs_embeds = embedding(input_ids) is evaluated first), so its gradient is final only when the backward ends — T has
+        # no hook and is reduced by the sweep after the backward, never together with H
+        self.regions = dict(H=(0, o[first_text]), T=(o[first_text], o[first_unet]), D=(o[first_unet], o[first_up]), U=(o[first_up], self.flat.numel))
         self._up_events = 0
 
         def up_event(*_):
@@ -235,6 +291,12 @@ class E4TTrainer:
             return
         self._done.add(key)
         a, b = self.regions[key]
+        if b <= a:
+            return
+        if self.comm_timing is not None and self.flat.grad.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.comm_timing.setdefault("enqueue", {})[key] = ev
         g = self.flat.grad
         bucket = 64 << 20          # 256 MB fp32: xGMI rings are per-link bound, large buckets run them at rate
         for o in range(a, b, bucket):
@@ -249,10 +311,18 @@ class E4TTrainer:
             for o in range(0, g.numel(), bucket):
                 torch.distributed.all_reduce(g[o:o + bucket], group=self.pg)
             return
-        for key in ("U", "H", "D"):           # whatever was not triggered during the backward
-            self._reduce_region(key, force=True)
+        for key in ("U", "H", "D", "T"):      # whatever was not triggered during the backward
+            if self.regions[key][1] > self.regions[key][0]:
+                self._reduce_region(key, force=True)
+        timing = self.comm_timing is not None and self.flat.grad.is_cuda
+        if timing:
+            self.comm_timing["wait_begin"] = torch.cuda.Event(enable_timing=True)
+            self.comm_timing["wait_begin"].record()
         for w in self._works:
             w.wait()
+        if timing:
+            self.comm_timing["wait_end"] = torch.cuda.Event(enable_timing=True)
+            self.comm_timing["wait_end"].record()
         self._works, self._done = [], set()
 
     def clip_grad_norm(self):
@@ -285,6 +355,7 @@ class E4TTrainer:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step_count"])
         self.flat.grad.zero_()
+        self.sync_replicas(include_moments=True)  # a per-rank-different checkpoint read must not start diverged replicas
         ops.bump_weights_epoch()                 # bf16 compute copies of the trainable weights are stale now
 
     def train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None,
@@ -307,6 +378,10 @@ class E4TTrainer:
         loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
         self._armed = bool(sync)             # micro-batches that only accumulate start no collectives
         self._up_events = 0
+        if self.comm_timing is not None and self.flat.grad.is_cuda:
+            self.comm_timing.clear()
+            self.comm_timing["backward_begin"] = torch.cuda.Event(enable_timing=True)
+            self.comm_timing["backward_begin"].record()
         Fn.set_inplace_param_grads(True)     # weight / bias gradients accumulate straight into the flat buffer (functional.py)
         try:
             (loss if loss_scale == 1.0 else loss * loss_scale).backward()
@@ -319,4 +394,18 @@ class E4TTrainer:
         self.clip_grad_norm()
         self.optimizer_step()
         self.zero_grad()
+        if self.world > 1 and self.replica_check_every > 0 and self.step_count % self.replica_check_every == 0:
+            self.check_replicas()
         return loss.detach(), loss_diff.detach(), loss_reg.detach()
+
+    def comm_report(self):
+        """ms since the start of the backward at which each gradient region's all-reduce was enqueued in the last synchronising
+        step, and the time the step's stream then spent waiting for the collectives ("exposed"): needs comm_timing = {} beforehand"""
+        t = self.comm_timing
+        if not t or "wait_end" not in t:
+            return None
+        torch.cuda.synchronize()
+        b = t["backward_begin"]
+        return dict(enqueue_ms_after_backward_start={k: b.elapsed_time(e) for k, e in t.get("enqueue", {}).items()},
+                    wait_begin_ms=b.elapsed_time(t["wait_begin"]), exposed_wait_ms=t["wait_begin"].elapsed_time(t["wait_end"]),
+                    region_bytes={k: 4 * (hi - lo) for k, (lo, hi) in (self.regions or {}).items()})

@@ -45,15 +45,28 @@ def _batch(rank):
                 pidx=torch.tensor([3]))
 
 
+def _perturb(models, rank):
+    """make this rank's weights differ from rank 0's (a per-rank seed / a different checkpoint read): trainable AND frozen ones"""
+    g = torch.Generator().manual_seed(900 + rank)
+    with torch.no_grad():
+        for m in models:
+            for p in m.parameters():
+                p.add_(torch.randn(p.shape, generator=g) * 1e-2 * rank)
+
+
 def _worker(rank, world, port, out_dir, unfreeze):
     _setup_paths()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), E4T_REPLICA_CHECK_EVERY="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from e4t.trainer import E4TTrainer
     _, _, n_unet, n_enc, text = _build()
     if unfreeze == "vit":
         n_enc.clip_vision.requires_grad_(True)
+    if unfreeze == "text":
+        text.requires_grad_(True)
+    if unfreeze in ("seeds", "text"):
+        _perturb((n_unet, n_enc, text), rank)          # rank 1 starts from different weights: the start-up broadcast must repair it
     tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"),
                     **_MODE_KW[unfreeze])
     assert tr.world == world
@@ -64,14 +77,19 @@ def _worker(rank, world, port, out_dir, unfreeze):
     dist.destroy_process_group()
 
 
-_MODE_KW = {"": {}, "vit": {}, "tuning": dict(tuning=True, max_grad_norm=1.0)}
+_MODE_KW = {"": {}, "vit": {}, "tuning": dict(tuning=True, max_grad_norm=1.0), "seeds": {}, "text": dict(tuning=True, max_grad_norm=1.0)}
 
 
-@pytest.mark.parametrize("unfreeze", ["", "vit", "tuning"], ids=["vit_frozen", "vit_trainable", "tuning"])
+@pytest.mark.parametrize("unfreeze", ["", "vit", "tuning", "seeds", "text"], ids=["vit_frozen", "vit_trainable", "tuning", "different_seeds", "text_trainable"])
 def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
     """vit_trainable: no hook announces the head region during the backward, the post-backward sweep must reduce it.
     tuning: the whole UNet is in the U / D regions and the gradient-norm clip runs on the AVERAGED gradient (tuning_e4t.py:329-335
-    under accelerate's DDP)."""
+    under accelerate's DDP).
+    different_seeds: rank 1 starts from perturbed weights (trainable and frozen); the trainer's start-up broadcast (the DDP
+    constructor's, pretrain_e4t.py:410-412) makes it rank 0's replica — the ranks end identical AND equal to the single-process step
+    from rank 0's weights; the per-step replica checksum (E4T_REPLICA_CHECK_EVERY=1) passes.
+    text_trainable: tuning_e4t.py --train_text_encoder.  The token-embedding gradient is complete only at the END of the backward
+    (region T, reduced by the sweep): reducing it with the E4T head's region from the head's hook dropped the late part."""
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), unfreeze), nprocs=world, join=True)
     p0, p1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
@@ -85,6 +103,8 @@ def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
         _, _, n_unet, n_enc, text = _build()
         if unfreeze == "vit":
             n_enc.clip_vision.requires_grad_(True)
+        if unfreeze == "text":
+            text.requires_grad_(True)
         tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"),
                         **_MODE_KW[unfreeze])
         for r in range(world):
@@ -152,3 +172,32 @@ def test_gradient_regions_are_reduced_as_soon_as_they_are_final(tmp_path, tuning
     assert by["U"] == 0 and by["H"] == 0 and by["D"] == 1, r["log"]       # U and H before the encoder-pass backward, D after
     (h0, h1), (d0, d1), (u0, u1) = r["regions"]["H"], r["regions"]["D"], r["regions"]["U"]
     assert h0 == 0 and h1 == d0 and d1 == u0 and u1 == r["numel"] and u1 > u0 > d0 > 0
+
+
+def _diverge_worker(rank, world, port, out_dir):
+    """replicas that DO diverge (rank 1's parameters nudged behind the trainer's back after the start-up broadcast) must abort"""
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), E4T_REPLICA_CHECK_EVERY="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from e4t.trainer import E4TTrainer
+    _, _, n_unet, n_enc, text = _build()
+    tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"))
+    if rank == 1:
+        tr.flat.data[5] += 1e-3
+    b = _batch(rank)
+    try:
+        tr.train_step(b["pixels"], b["ids"], b["pidx"], noise=b["noise"], timesteps=b["t"], latents=b["latents"])
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, f"msg{rank}.txt"), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_diverged_replicas_abort(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_diverge_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert "replicas diverged" in open(tmp_path / f"msg{r}.txt").read()
