@@ -55,9 +55,12 @@ def cpu_baseline_and_parity(model, threads, dev):
     del n
     torch.cuda.empty_cache()
     rep, _ = ps.evaluate(case, o, d, nat, dev, verbose=False, strict=False)      # its CPU fp32 oracle run = the warm-up step
+    # (strict=False so that the JSON line is still printed; main() turns n_bad != 0 into a non-zero exit code)
     torch.cuda.empty_cache()
-    par = dict(case=case.name, rule=rep["rule"], n_quantities=rep["n_quantities"], n_bad=rep["n_bad"], bad=rep["bad"])
-    for kind, key in (("losses", "loss_rel"), ("enc_maps", "enc_maps_rel"), ("grads", "grad_rel"), ("other", "latents_embed_rel")):
+    par = dict(case=case.name, rule=rep["rule"], n_quantities=rep["n_quantities"], n_bad=rep["n_bad"], bad=rep["bad"],
+               kink_elements_aligned=rep["kink_elements_aligned"], **{"kink_elements_within_1e-2": rep["kink_elements_within_1e-2"]})
+    for kind, key in (("losses", "loss_rel"), ("enc_maps", "enc_maps_rel"), ("grads", "grad_rel"), ("other", "latents_embed_ehat_rel"),
+                      ("adamw", "adamw_step_rel")):
         if kind in rep:
             w, q = rep[kind]["worst"], rep[kind]["tightest"]
             par[key] = dict(worst=w["native"], worst_name=w["name"], stock_autocast_same_quantity=w["autocast"],
@@ -75,6 +78,60 @@ def cpu_baseline_and_parity(model, threads, dev):
     return cpu, par
 
 
+def secondary_configs(dev, steps=4, warmup=2):
+    """BASELINE.json configs[3] and configs[4], driver-witnessed (rank 0, one GPU, after the timed region of the headline run):
+      C4  tuning_e4t.py step — every UNet weight + weight offsets + E4T head train, gradient-norm clip, ONE image expanded over
+          B = 16, VAE encoded once outside the loop (tuning_e4t.py:266-338): ms/step, images/s, MFMA fraction on 3.53 TFLOP/image;
+      C5  the SD-2.x UNet config (ctx 1024, dh 64, linear projections, v-prediction) pre-training step at 768 px (96 x 96 latents,
+          T = 9216 self-attention), B = 1 (= BASELINE's per-GPU batch) and B = 4: MFMA fraction on 7.13 TFLOP/image (hot path).
+    Their parity evidence is the -m gpu tests `tuning_real_width`, `full_sd21` (tests/test_configs_gpu.py)."""
+    from e4t.trainer import E4TTrainer
+    out = {}
+
+    def timed(fn, n):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    empty_ids = torch.tensor([[49406] + [49407] * 76], device=dev)
+    # ---- C4
+    unet, enc, text, vae = build_models(dev, "sd14", seed=0)
+    tr = E4TTrainer(unet, enc, text, vae, lr=1e-6, reg_lambda=0.1, class_token_id=1125, empty_prompt_ids=empty_ids, device=dev, tuning=True, max_grad_norm=1.0)
+    B = 16
+    image = torch.rand((1, 3, 512, 512), generator=gen, device=dev) * 2 - 1
+    with torch.no_grad():
+        lat1 = tr.encode_latents(image, torch.randn((1, 4, 64, 64), generator=gen, device=dev))          # tuning_e4t.py:268-269: once
+    px, lat = image.expand(B, -1, -1, -1).contiguous(), lat1.expand(B, -1, -1, -1).contiguous()
+    ids = torch.randint(0, 49000, (1, 77), generator=gen, device=dev).expand(B, -1).contiguous()
+    pidx = torch.full((B,), 5, device=dev)
+    sec = timed(lambda: tr.train_step(px, ids, pidx, latents=lat), steps)
+    out["C4_tuning_sd14_512px_b16"] = dict(ms_per_step=sec * 1e3, images_per_s=B / sec, trainable_parameters=tr.flat.numel,
+                                            step_mfma_frac=B / sec * 3.53e12 / MFMA_PEAK, flop_per_image=3.53e12,
+                                            parity_test="tests/test_configs_gpu.py::test_tuning_step_matches_oracle[tuning_real_width]")
+    del tr, unet, enc, text, vae
+    torch.cuda.empty_cache()
+    # ---- C5
+    unet, enc, text, vae = build_models(dev, "sd21", seed=0)
+    tr = E4TTrainer(unet, enc, text, vae, lr=1e-6, prediction_type="v_prediction", class_token_id=1125, empty_prompt_ids=empty_ids, device=dev)
+    for B in (1, 4):
+        px = torch.rand((B, 3, 768, 768), generator=gen, device=dev) * 2 - 1
+        ids = torch.randint(0, 49000, (B, 77), generator=gen, device=dev)
+        pidx = torch.randint(1, 20, (B,), generator=gen, device=dev)
+        sec = timed(lambda: tr.train_step(px, ids, pidx), steps)
+        out[f"C5_pretrain_sd21_768px_b{B}"] = dict(ms_per_step=sec * 1e3, images_per_s=B / sec, step_mfma_frac_necessary=B / sec * HOT_FLOP_PER_IMAGE["sd21"] / MFMA_PEAK,
+                                                    step_mfma_frac_whole_step=B / sec * STEP_FLOP_PER_IMAGE["sd21"] / MFMA_PEAK,
+                                                    parity_test="tests/test_configs_gpu.py::test_sd2_config_step_matches_oracle[full_sd21]")
+    del tr, unet, enc, text, vae
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] block (tuning step, SD-2.x @768)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,8 +203,10 @@ def main():
         # enter alone — and rank 0 records and reports.
         if rank == 0:
             hip.prof = []
+        tr.comm_timing = {} if world > 1 else None      # per-region all-reduce enqueue times + exposed wait of this step (N > 1)
         tr.train_step(*batch(10_000))
         torch.cuda.synchronize()
+    comm = tr.comm_report() if (world > 1 and not args.no_kernel_roofline) else None
     if rank == 0 and not args.no_kernel_roofline:
         agg = {}
         for key, fl, nb, e0, e1 in hip.prof:
@@ -156,7 +216,8 @@ def main():
         names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, 2, false, 64>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, 2, false, 64>",
                  "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, 2, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2, false, 64>",
                  "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, 2, false, 64>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, 2, false, 64>",
-                 "conv512": "gemm_pp_kernel<1>", "gemm512": "gemm_pp_kernel<0>", "gemm_tn": "gemm_tn_kernel",
+                 "conv512": "gemm_pp_kernel<1, false>", "gemm512": "gemm_pp_kernel<0, false>", "gemm_tn": "gemm_tn_kernel",
+                 "conv5256": "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>", "gemm5256": "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>",
                  "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",
                  "gn_fwd_2pass": "gn_stats_kernel<*> + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",
                  "gn_bwd": "gn_bwd_stats_kernel<*> + gn_bwd_apply_kernel<*>",      # (small maps: gn_slab_bwd_kernel<*>)
@@ -221,11 +282,14 @@ def main():
     if world > 1:
         dist.barrier()
 
-    cpu = parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = args.cpu_threads or min(os.cpu_count() or 8, 128)
+    cpu = parity = secondary = None
+    if rank == 0 and world == 1 and not (args.no_cpu_baseline and args.no_secondary):
         del tr, unet, enc, text, vae
         torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_secondary and args.model == "sd14":
+        secondary = secondary_configs(dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = args.cpu_threads or min(os.cpu_count() or 8, 128)
         cpu, parity = cpu_baseline_and_parity(args.model, threads, dev)
 
     if rank == 0:
@@ -236,10 +300,12 @@ def main():
                                          else "SD-2.x UNet (ctx 1024, linear proj) + ViT-H-14 E4T encoder pretrain step, 768px"),
                                per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}", trainable="weight offsets + E4T head (ViT frozen)",
                                frozen_on_stock_torch="none (CLIP text encoder and VAE encoder run on the HIP kernels; only embedding lookups / loss glue are torch ops)", last_loss=float(loss)),
-                   roofline=roof, roofline_hbm=roof_hbm, cpu_baseline=cpu, parity=parity)
-        print(json.dumps(out))
+                   roofline=roof, roofline_hbm=roof_hbm, cpu_baseline=cpu, parity=parity, secondary=secondary, comm=comm)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and parity is not None and parity["n_bad"]:
+        sys.exit(3)                                  # the run's own parity block failed: not a valid measurement
 
 
 if __name__ == "__main__":

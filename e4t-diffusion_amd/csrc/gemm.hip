@@ -233,7 +233,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   constexpr int LOOK = NSTAGE - 1;                    // K-tiles in flight
   constexpr int TILE = (BM + BN) * KT;          // elements per LDS buffer
   static_assert(NA >= 1 && NB >= 1 && (NW == 4 || NW == 8) && (NSTAGE >= 2 && NSTAGE <= 4), "bad tile configuration");
-  static_assert(NSTAGE == 2 || (BN / RPP) % NW == 0, "counted vmcnt needs the same piece count in every wave");
+  constexpr bool RAGGED_B = (BN / RPP) % NW != 0;     // the last wave(s) own fewer B pieces: their counted waits use their own count
+  static_assert(!RAGGED_B || NB <= 3, "counted vmcnt: per-wave piece counts are enumerated up to 3 B pieces");
   static_assert((KT == 64 || KT == 32) && BM % (RPP * NW) == 0, "bad K-tile width");
 
   __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * TILE];
@@ -241,6 +242,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
+  // B pieces this wave issues per K-tile (wave-uniform): NB, or fewer in the last wave(s) of a ragged split
+  const int nbw = RAGGED_B ? min(NB, max(0, BN / RPP - __builtin_amdgcn_readfirstlane(wave) * NB)) : NB;
   int tile_x, tile_y;
   xcd_tile(tile_x, tile_y, p.group_m);
   const int m0 = tile_y * BM, n0 = tile_x * BN;
@@ -413,8 +416,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
     constexpr int NXT = (CUR + LOOK) % NSTAGE;
     // this wave's pieces of tile kt have landed once at most the pieces of the newer tiles in flight (LOOK-1 of them, fewer
     // at the end of the K range) are outstanding: a counted wait, the loads of the deeper stages keep flying
-    if (LOOK >= 3 && kt + 2 < kt_end) wait_vmcnt<2 * (NA + NB)>();
-    else if (LOOK >= 2 && kt + 1 < kt_end) wait_vmcnt<NA + NB>();
+    auto wait_tiles = [&](auto Tc) {          // at most T newer K-tiles of this wave's pieces outstanding
+      constexpr int T = decltype(Tc)::value;
+      if (!RAGGED_B || nbw == NB) wait_vmcnt<T * (NA + NB)>();
+      else if (nbw == NB - 1) wait_vmcnt<T * (NA + (NB > 1 ? NB - 1 : 0))>();
+      else if (nbw == NB - 2) wait_vmcnt<T * (NA + (NB > 2 ? NB - 2 : 0))>();
+      else wait_vmcnt<T * NA>();
+    };
+    if (LOOK >= 3 && kt + 2 < kt_end) wait_tiles(std::integral_constant<int, 2>{});
+    else if (LOOK >= 2 && kt + 1 < kt_end) wait_tiles(std::integral_constant<int, 1>{});
     else wait_vmcnt<0>();
     loop_barrier();                                    // ... everyone's have; and everyone finished reading slot NXT
 #ifdef DMA_TRACE
@@ -461,7 +471,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
 #ifdef DMA_TRACE
   write_tile<WM, WN, FM, FN, GENERAL>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN, dt_on ? g_dma_trace + dt_wg * 16 : nullptr);
 #else
-  write_tile<WM, WN, FM, FN, GENERAL>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
+  if constexpr (NW * WM * (WN + 8) > NSTAGE * TILE || WM >= 128) {
+    // tall wave tiles (the 4-wave 256-row variants): two row halves, so that the staging fits the operand buffers and the
+    // (fully unrolled) epilogue stays at the size of the other kernels'
+    static_assert(FM % 2 == 0 && NW * (WM / 2) * (WN + 8) <= NSTAGE * TILE, "epilogue staging must fit");
+    write_tile<WM / 2, WN, FM / 2, FN, GENERAL>(p, *(f32x16(*)[FM / 2][FN])(acc + 0), wave_stage<WM / 2, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
+    __syncthreads();
+    write_tile<WM / 2, WN, FM / 2, FN, GENERAL>(p, *(f32x16(*)[FM / 2][FN])(acc + FM / 2), wave_stage<WM / 2, WN>(smem, wave), lane, m0 + wm * WM + WM / 2, n0 + wn * WN);
+  } else {
+    write_tile<WM, WN, FM, FN, GENERAL>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
+  }
 #endif
   DT(12);
 }
@@ -1224,6 +1243,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   int tile = tile_hint;
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
+  static const bool r2_rules = getenv("E4T_GEMM_R2RULES") != nullptr;   // A/B switch: the round-2 choices (before tools/sweep_ps.py, round 3)
   const bool whole_k = p.K % BK == 0 && (!p.A2 || p.K1 % BK == 0);
   const bool ps_ok = allow256 && whole_k && batch == 1 && !p.reduce_batch && splitk_req <= 1;      // what gemm_ps_kernel accepts
   if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512 && tile != 640 && tile != 1128 && tile != 1160) {
@@ -1238,16 +1258,16 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     // K-deep shapes whose N is a multiple of 256 and that fill the chip at least twice with 256x256 tiles (the VAE's 256-
     // and 512-channel convs): the ping-pong kernel (conv 512->512 @128^2: 1075 vs 928 TF, 8192^3: 1173 vs 971 TF)
     static const bool no_pp = getenv("E4T_GEMM_NOPP") != nullptr;     // A/B switch
-    if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && whole_k && nkt >= (conv ? 16 : 32) &&
-        (long long)cdiv(p.M, 256) * (p.N / 256) * batch >= 512) tile = 512;
-    // ... and, with split-K, for the very K-deep shapes of the 16x16 level that give it only 64-255 tiles (1280-channel 3x3
-    // convs, the GEGLU input gradient K = 10240): tools/sweep_step_shapes.py, conv 1280->1280 M4096 128 vs 141 us, conv
-    // 1280->2560 209 vs 290 us, conv 2560->1280 221 vs 265 us, GEMM 4096x1280x10240 126 vs 138 us; at K = 5120 it loses.
-    {
-      const long long tpp = (long long)cdiv(p.M, 256) * (p.N / 256) * batch;
-      if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && whole_k && nkt >= 128 && tpp >= 64 && tpp < 512)
-        tile = 512;
-    }
+    const long long tpp = (long long)cdiv(p.M, 256) * (p.N / 256) * batch;
+    if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && whole_k && nkt >= (conv ? 16 : (r2_rules ? 32 : 20)) && tpp >= 512) tile = 512;
+    // ... and, with split-K, for the very K-deep shapes of the 16x16 level that give it less than one round of tiles (1280-channel
+    // 3x3 convs, the GEGLU input gradient K = 10240): tools/sweep_step_shapes.py, conv 1280->1280 M4096 128 vs 141 us, conv
+    // 1280->2560 209 vs 290 us, conv 2560->1280 221 vs 265 us, GEMM 4096x1280x10240 126 vs 138 us; at K = 5120 it loses.  (Round 3:
+    // 256..511 tiles are NOT split any more — conv 1280->1280 M16384: 3 splits 545 us, 1 split 482 us, 128 x 160 tile 454 us.)
+    if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && whole_k && nkt >= 128 && tpp >= 64 && tpp < (r2_rules ? 512 : 256)) tile = 512;
+    // one (nearly) full round of ping-pong tiles, K >= 1280: the ViT's qkv projection M4112 N3840 (255 tiles) 44.9 vs 49.5 us,
+    // M4096 N3840 42.7 vs 48.3 us
+    if (!r2_rules && allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && whole_k && nkt >= 20 && tpp >= 224 && tpp <= 256) tile = 512;
     // The 512 x 128 variant of the same machine (tile code 640) is NOT chosen automatically: on the shapes it was built for
     // (the VAE's 128-channel convs, K = 1152 = 18 K-tiles) it measured 526 vs 588 TF/s for the 128 x 128 tile — one 160-KiB
     // workgroup per CU leaves nothing to overlap its (large) epilogue and prologue with, and 18 K-tiles do not amortise
@@ -1255,8 +1275,22 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     static const bool auto_pt = getenv("E4T_GEMM_PT") != nullptr;
     if (auto_pt && allow256 && tile == 128 && p.N % 128 == 0 && p.N % 256 != 0 && p.K % BK == 0 && nkt >= 16 && !p.A2 &&
         (long long)cdiv(p.M, 512) * (p.N / 128) * batch >= 512) tile = 640;
-    // The persistent 256 x 160 / 256 x 128 streaming kernel (gemm_ps.hip) for the big-M shapes the 128-wide tiles run today,
-    // when its rounds of one workgroup per CU come out (nearly) full.  E4T_GEMM_PS=0 is the A/B switch.
+    const bool general = (p.flags & E4T_ACT_GELU) || (p.rowbias && p.rows_per_batch % 32 != 0);
+    // Round 3 (tools/sweep_ps.py on the step's own shapes, cold operands):
+    //  * the 128 x 160 tile also for N > 960 when K is deep and the grid is large — conv 640->1920 M16384 350 vs 378 us, conv
+    //    1280->1280 M16384 454 vs 482 (ping-pong) / 492 (128 x 128), GEMM M4096 N5120 K1280 60 vs 64 us; on short K it loses
+    //    (M16384 N5120 K640: 145 vs 127 us), and its GELU instantiation is register-bound (M4112 N5120: 107 vs 85 us);
+    if (!r2_rules && allow256 && tile == 128 && !general && p.N % 160 == 0 && p.N > 960 && nkt >= 20 &&
+        (long long)cdiv(p.M, 128) * (p.N / 160) * batch >= 1024) tile = 160;
+    //  * 256 x 128 with 32-wide K-tiles (8 waves, wave tile 64 x 64, three 24-KiB stages = two workgroups per CU; code 5256) for
+    //    tall outputs whose N is a multiple of 128: half the B re-reads and 2/3 of the fragment LDS reads of the 128 x 128 tile per
+    //    flop.  VAE conv 128->128 @512^2 1449 vs 1744 us, stride-2 conv 455 vs 493, conv_in GEMM M4194304 N128 K32 261 vs 386 (no
+    //    padding of K to 64), GEMM M65536 N2560 K320 162 vs 185, M65536 N1280 K320 76 vs 81 us.
+    if (!r2_rules && allow256 && tile == 128 && !general && (p.N % 128 == 0 || p.N < 128) &&
+        (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch >= 768) { tile = 256; kt32 = true; stages = 3; }
+    // The persistent 256 x 160 / 256 x 128 streaming kernel (gemm_ps.hip).  NOT chosen automatically: correct, but slower than the
+    // tiles above on every shape of the step (its ping-pong phases are bound by the DMA-issue / fragment-read segment).
+    // E4T_GEMM_PS=1 turns the automatic choice on for experiments.
     static const int auto_ps = getenv("E4T_GEMM_PS") ? atoi(getenv("E4T_GEMM_PS")) : E4T_GEMM_PS_DEFAULT;
     if (auto_ps && ps_ok && (tile == 128 || tile == 160)) {
       const int ncu = device_cu_count();
@@ -1287,7 +1321,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     if (tile == 512 && (!allow256 || !buf_ok || !whole_k)) tile = 128;
     if (tile == 640 && (!buf_ok || p.K % BK != 0)) tile = 128;
     pl.a_bytes = (unsigned)(buf_ok ? ab : 0); pl.a2_bytes = (unsigned)(buf_ok ? a2b : 0); pl.b_bytes = (unsigned)(buf_ok ? bb : 0);
-    if (!buf_ok && tile != 64) tile = 128;       // the register-staged fallback exists as 128x128 and 64x64 only
+    if (!buf_ok && tile != 64) { tile = 128; kt32 = false; stages = 2; }      // the register-staged fallback exists as 128x128 and 64x64 only
   }
   // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong, 640 = 512x128 ping-pong, 1128 / 1160 = persistent 256x128 / 256x160
   const int tm = tile == 160 ? 128 : (tile == 512 || tile >= 1000 ? 256 : (tile == 640 ? 512 : tile));
@@ -1299,9 +1333,11 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   if (splitk <= 0) {
     splitk = 1;
     const long long tiles = (long long)gx * gy * batch;
-    if (tile == 512 && tiles < 256) {
-      splitk = (int)(256 / tiles);                   // one 512-thread workgroup per CU: fill one round
-      if (splitk > nkt / 16) splitk = nkt / 16;
+    if (tile == 512 && (tiles < 256 || !r2_rules)) {
+      if (tiles < 256) {
+        splitk = (int)(256 / tiles);                 // one 512-thread workgroup per CU: fill one round
+        if (splitk > nkt / 16) splitk = nkt / 16;
+      }                                              // (a second, partial round is not split: 3 splits of 320 tiles measured 545 vs 482 us)
     } else if (tile >= 128 && tiles < 512 && nkt >= 32) {
       // 2 workgroups/CU = 512 slots: aim at one full round (<= 256 tiles) or two (measured, tools/sweep_sk.py: 8x8 convs
       // 80 tiles -> 6 splits -16..19 %, 16x16 convs 320 tiles -> 3 splits -10..17 %), keeping >= 16 K-tiles per split
@@ -1513,7 +1549,7 @@ int tn_splitk(int M, int N, int K, int req) {
 }
 
 void export_plan(const GemmPlan& pl, const GemmArgs& p, int batch, e4t_gemm_plan_t* out) {
-  out->tile = pl.tile; out->tile_m = pl.tm; out->tile_n = pl.tn; out->splitk = pl.splitk;
+  out->tile = pl.kt32 ? 5000 + pl.tile : pl.tile; out->tile_m = pl.tm; out->tile_n = pl.tn; out->splitk = pl.splitk;
   out->workspace_bytes = plan_workspace_bytes(pl, p, batch);
 }
 

@@ -35,8 +35,10 @@ def test_tuning_step_matches_oracle(hip_env, name):
     assert rep["other"]["count"] >= 2           # domain embedding + global gradient norm
 
 
-@pytest.mark.parametrize("name", ["tiny_sd2", "sd2_real_width"])
+@pytest.mark.parametrize("name", ["tiny_sd2", "sd2_real_width", "full_sd21"])
 def test_sd2_config_step_matches_oracle(hip_env, name):
+    """full_sd21: BASELINE configs[4] at its real size — SD-2.x UNet config (ctx 1024, dh 64, linear projections, v-prediction) on
+    96 x 96 latents (T = 9216 self-attention), ViT-H-14, 23-layer text encoder, AutoencoderKL encoder at 768 px, B = 1."""
     _run(name)
 
 

@@ -21,3 +21,15 @@ def test_full_sd14_step_matches_oracle(hip_env):
     if os.path.isdir(out):
         with open(os.path.join(out, "parity_full_sd14.json"), "w") as fh:
             json.dump(rep, fh, indent=1)
+
+
+def test_full_sd14_batch16_step_matches_sixteen_single_sample_steps(hip_env):
+    """BASELINE configs[1] at the batch bench.py times (B = 16): the kernel instantiations launch_gemm() picks at M = 16 x tokens
+    (256-row tiles, other split-K factors, other attention grids) against the oracle-pinned B = 1 path, sample by sample."""
+    import parity_step
+    rep = parity_step.batch_consistency("full_sd14", torch.device("cuda:0"), B=16)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_full_sd14_batch16.json"), "w") as fh:
+            json.dump(rep, fh, indent=1)
+    assert rep["n_bad"] == 0, rep["bad"]

@@ -79,7 +79,7 @@ for x in todo:
             continue
         if tile in (1128, 5256) and N % 128 and N > 128:
             continue
-        if tile >= 1000 and K % 64:
+        if 1000 <= tile < 5000 and K % 64:
             continue
         t = pool_time(make, lambda a: call(a, tile, sk), nbytes)
         if t is not None:
