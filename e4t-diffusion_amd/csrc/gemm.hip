@@ -772,6 +772,257 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256 x BN ping-pong, BN = 256 | 320, phases = (k half) x (16-wide k step)      [round 3]
+//
+// The same machine as gemm_pp_kernel — two groups of four waves alternating an LDS/DMA segment with an MFMA segment, operand
+// quarters of 32 k moved by LDS-DMA, counted vmcnt — with the K-tile cut along K instead of along the wave tile's rows: a phase is
+// one 16-wide k step over the WHOLE wave tile.  Every phase then reads the same number of fragments (FM + FN ds_read_b128 for
+// FM x FN MFMAs) instead of alternating 8 / 4, holds one k step of fragments in registers instead of two (24 instead of 32 VGPRs
+// at BN = 256), and — what it was written for — makes a 256 x 320 tile fit: 8 waves = 4 (rows) x 2 (columns), wave tile 64 x 160
+// (2 x 5 accumulators = 160 VGPRs + 28 fragment registers), 10 MFMAs per phase.  A 320-wide tile covers the UNet's 320 / 640 /
+// 960 / 1280 / 1920 / 2560-channel layers without N padding at 0.93 KB of LDS traffic per MFMA (fragment reads + DMA writes), where
+// the 128 x 160 tile moves 1.69 KB (the GEMM family is bound by LDS traffic, not by the DMA path or the MFMA rate).
+//   * quarters: A = 256 rows x 32 k (2 DMA instructions per wave), B = BN rows x 32 k (BN = 320: 20 pieces, 3 per wave in waves
+//     0-3, 2 in waves 4-7); two buffers x [A-lo | B-lo | A-hi | B-hi] = 128 / 144 KiB;
+//   * phases 0, 1 read the lo quarters, 2, 3 the hi quarters.  A slot is re-staged no earlier than two phases after its last read
+//     (the trailing group's reads), so the issue stream runs  ph1: B-hi(t+1)  ph2: A-hi(t+1)  ph3: B-lo(t+2)  ph0': A-lo(t+2)
+//     (A-lo of tile t+2 is issued in the first phase of tile t+1); every quarter is first read >= 3 phases after its issue, and
+//     "at most the 3 newest quarters outstanding" after each issue is exactly what the next phase needs landed — 2 A + 1 B quarters
+//     after an even phase, 1 A + 2 B after an odd one (instruction counts differ per wave at BN = 320).
+// Requires K % 64 == 0.  Same epilogue code as every other kernel: results are bit-identical to theirs.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int BN, bool GENERAL>
+__global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
+  constexpr int BM = 256, HK = 32;
+  constexpr int WR = BN == 320 ? 4 : 2, WC = 8 / WR;
+  constexpr int WM = BM / WR, WN = BN / WC;                  // 128 x 64 | 64 x 160
+  constexpr int FM = WM / 32, FN = WN / 32;                  // 4 x 2 | 2 x 5
+  constexpr int QA = BM * HK, QB = BN * HK;                  // elements per A / B quarter
+  constexpr int HALF = QA + QB, BUF = 2 * HALF;              // [A | B] of one k half; one buffer = lo half + hi half
+  constexpr int NBP = BN / 16;                               // B pieces per quarter: 16 | 20
+  constexpr int NBJ = (NBP + 7) / 8;                         // per wave: 2 | 3 (the last one only in waves < NBP - 8 * (NBJ - 1))
+  constexpr int NBLAST = NBP - 8 * (NBJ - 1);                // waves that carry NBJ pieces: 8 | 4
+  constexpr int ESTG = 8 * 32 * (WN + 8);                    // epilogue staging: 8 waves x 32 rows
+  static_assert(BN == 256 || BN == 320, "tile width");
+  static_assert(2 * BUF * 2 <= 160 * 1024 && ESTG <= 2 * BUF, "LDS budget");
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wr = wave / WC, wc = wave % WC;
+  int tile_x, tile_y;
+  xcd_tile(tile_x, tile_y, p.group_m);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+
+  const int nkt = p.K / BK;
+  const int bz = blockIdx.z / p.splitk, sz = blockIdx.z - bz * p.splitk;
+  p.A += bz * p.strideA;
+  if (p.A2) p.A2 += bz * p.strideA;
+  p.B += bz * p.strideB;
+  if (p.bias) p.bias += bz * p.strideBias;
+  if (!p.reduce_batch) {
+    if (p.flags & E4T_OUT_F32) p.C = (float*)p.C + bz * p.strideC;
+    else p.C = (bf16_t*)p.C + bz * p.strideC;
+  }
+  const int kt_begin = sz * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nkt) kt_end = nkt;
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFF0000u;
+  // DMA: one wave-instruction = 16 rows x 64 B; wave w feeds A rows 32w + 16j + (lane >> 2), j = 0, 1, and B pieces w + 8j
+  const int drow = lane >> 2, dslot = lane & 3;
+  long long a_base[2];
+  int a_oy[2], a_ox[2], a_kc[2];
+  bool a_ok[2];
+  unsigned b_vo[NBJ];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = wave * 32 + j * 16 + drow;
+    a_kc[j] = (dslot ^ ((r >> 2) & 3)) * 8;
+    const int gr = m0 + r;
+    a_ok[j] = gr < p.M;
+    if (MODE == 0) {
+      a_base[j] = (long long)gr; a_oy[j] = a_ox[j] = 0;
+    } else {
+      const int hw = p.Hout * p.Wout;
+      const int b = gr / hw;
+      const int rem = gr - b * hw;
+      a_oy[j] = rem / p.Wout;
+      a_ox[j] = rem - a_oy[j] * p.Wout;
+      a_base[j] = (long long)b * p.Hin * p.Win;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) {
+    const int r = (wave + 8 * j) * 16 + drow;
+    const int kc = (dslot ^ ((r >> 2) & 3)) * 8;
+    const int gn = n0 + r;
+    b_vo[j] = (r < BN && gn < p.N) ? (unsigned)(((size_t)gn * p.ldb + kc) * 2) : OOB;
+  }
+  unsigned a_vo[2];
+  int a_so = 0, b_so = 0;
+  bool a_second = false;
+  auto place_a = [&](int k0) {
+    if (MODE == 0) {
+      int ld = p.lda, koff = k0;
+      a_second = k0 >= p.K1;
+      if (a_second) { ld = p.lda2; koff = k0 - p.K1; }
+      a_so = koff * 2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) a_vo[j] = a_ok[j] ? (unsigned)((a_base[j] * ld + a_kc[j]) * 2) : OOB;
+    } else {
+      const int tap = k0 / p.Cin;
+      const int ci0 = k0 - tap * p.Cin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      a_so = ci0 * 2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int iy, ix;
+        bool ok = a_ok[j];
+        if (p.mode == E4T_CONV_S1) {
+          iy = a_oy[j] + ky - 1; ix = a_ox[j] + kx - 1;
+          ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        } else if (p.mode == E4T_CONV_S2) {
+          iy = 2 * a_oy[j] + ky - 1; ix = 2 * a_ox[j] + kx - 1;
+          ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        } else if (p.mode == E4T_CONV_UP2) {
+          iy = a_oy[j] + ky - 1; ix = a_ox[j] + kx - 1;
+          ok = ok && iy >= 0 && iy < 2 * p.Hin && ix >= 0 && ix < 2 * p.Win;
+          iy >>= 1; ix >>= 1;
+        } else if (p.mode == E4T_CONV_S2A) {
+          iy = 2 * a_oy[j] + ky; ix = 2 * a_ox[j] + kx;
+          ok = ok && iy < p.Hin && ix < p.Win;
+        } else {
+          const int sy = a_oy[j] + ky - 1, sx = a_ox[j] + kx - 1;
+          ok = ok && sy >= 0 && sx >= 0 && !(sy & 1) && !(sx & 1);
+          iy = sy >> 1; ix = sx >> 1;
+          ok = ok && iy < p.Hin && ix < p.Win;
+        }
+        a_vo[j] = ok ? (unsigned)(((a_base[j] + (long long)iy * p.Win + ix) * p.Cin + a_kc[j]) * 2) : OOB;
+      }
+    }
+  };
+  // the A and B streams are each issued in increasing k: lo(t), hi(t), lo(t+1), ...
+  auto issue_a = [&](int kt, bool hi, bf16_t* dst) {
+    const int k0 = kt * BK;
+    const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
+    if (fresh) place_a(k0);
+    else a_so += HK * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 32 + j * 16) * HK);
+  };
+  auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
+    if (!hi && kt == kt_begin) b_so = kt * BK * 2;
+    else b_so += HK * 2;
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j)
+      if (j < NBJ - 1 || wave < NBLAST) buf_dma16(rs_b, b_vo[j], b_so, dst + ((wave + 8 * j) * 16) * HK);
+  };
+  // at most the 3 newest quarters of this wave outstanding: 2 A + 1 B after an even phase, 1 A + 2 B after an odd one
+  constexpr int NBW_HI = NBJ, NBW_LO = NBJ - 1;
+  auto wait3 = [&](auto ODDc) {
+    constexpr bool ODD = decltype(ODDc)::value;
+    if (NBLAST == 8 || wave < NBLAST) wait_vmcnt<(ODD ? 2 + 2 * NBW_HI : 4 + NBW_HI)>();
+    else wait_vmcnt<(ODD ? 2 + 2 * NBW_LO : 4 + NBW_LO)>();
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fhi = lane >> 5;
+  int a_off[FM][2], b_off[FN][2];     // fragment offsets inside a quarter (elements), [block][k step of the half]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int r = wr * WM + i * 32 + frow;
+      a_off[i][ks] = r * HK + (((ks * 2 + fhi) ^ ((r >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int r = wc * WN + j * 32 + frow;
+      b_off[j][ks] = QA + r * HK + (((ks * 2 + fhi) ^ ((r >> 2) & 3)) * 8);
+    }
+  }
+  // buffer b = smem + b * BUF: [lo: A | B][hi: A | B].  Prologue: lo(t0), hi(t0), B-lo(t0+1), A-lo(t0+1) — the stream position the
+  // first phase expects (its own issue is A-lo(t+2)... of the NEXT tile: see the phase schedule).
+  issue_b(kt_begin, false, smem + QA);
+  issue_a(kt_begin, false, smem);
+  issue_b(kt_begin, true, smem + HALF + QA);
+  issue_a(kt_begin, true, smem + HALF);
+  if (kt_begin + 1 < kt_end) {
+    issue_b(kt_begin + 1, false, smem + BUF + QA);
+    issue_a(kt_begin + 1, false, smem + BUF);
+  }
+  wait_vmcnt<0>();                 // (one-off: the first K-tile and the next one's lo half)
+  __builtin_amdgcn_s_barrier();
+
+  auto phase = [&](auto Bc, auto Pc, int kt) {
+    constexpr int b = decltype(Bc)::value, ph = decltype(Pc)::value;
+    constexpr int kh = ph >> 1, ks = ph & 1;
+    bf16_t* const buf = smem + b * BUF;
+    bf16_t* const other = smem + (b ^ 1) * BUF;
+    const bf16_t* const q = buf + kh * HALF;
+    bf16x8 af[FM], bfr[FN];
+    // ---- L segment ----
+#pragma unroll
+    for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(q + a_off[i][ks]);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) bfr[j] = *(const bf16x8*)(q + b_off[j][ks]);
+    bool staged;
+    if (ph == 0)      { staged = kt + 1 < kt_end && kt > kt_begin; if (staged) issue_a(kt + 1, false, other); }       // A-lo(t+1) (the prologue issued the first one)
+    else if (ph == 1) { staged = kt + 1 < kt_end; if (staged) issue_b(kt + 1, true, other + HALF + QA); }              // B-hi(t+1)
+    else if (ph == 2) { staged = kt + 1 < kt_end; if (staged) issue_a(kt + 1, true, other + HALF); }                   // A-hi(t+1)
+    else              { staged = kt + 2 < kt_end; if (staged) issue_b(kt + 2, false, buf + QA); }                      // B-lo(t+2)
+    if (staged) wait3(std::integral_constant<bool, (ph & 1) != 0>{}); else wait_vmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M segment ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+  if (grp == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier interval behind group 0
+  {
+    int kt = kt_begin;
+    for (; kt + 2 <= kt_end; kt += 2) {
+      phase(I0{}, I0{}, kt); phase(I0{}, I1{}, kt); phase(I0{}, I2{}, kt); phase(I0{}, I3{}, kt);
+      phase(I1{}, I0{}, kt + 1); phase(I1{}, I1{}, kt + 1); phase(I1{}, I2{}, kt + 1); phase(I1{}, I3{}, kt + 1);
+    }
+    if (kt < kt_end) { phase(I0{}, I0{}, kt); phase(I0{}, I1{}, kt); phase(I0{}, I2{}, kt); phase(I0{}, I3{}, kt); }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  __syncthreads();   // every fragment read and every DMA is done before the epilogue reuses the LDS
+  // 32-row slices of the wave tile: the staging of 8 waves x 32 x (WN + 8) fits the operand buffers, the unrolled epilogue stays small
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    if (i) __syncthreads();
+    write_tile<32, WN, 1, FN, GENERAL>(p, *(f32x16(*)[1][FN])(&acc[i][0]), wave_stage<32, WN>(smem, wave), lane, m0 + wr * WM + i * 32, n0 + wc * WN);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 512 x 128 ("tall") ping-pong tile: the same phase machine with the operand roles exchanged, for outputs that are only
 // 128 columns wide (the VAE's 128-channel 3x3 convs at 512^2: M = 4.2 M rows, N = 128 — a 256-wide tile would be half empty
 // and the 128 x 128 tile reaches 680 TF/s there).
@@ -1246,7 +1497,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   static const bool r2_rules = getenv("E4T_GEMM_R2RULES") != nullptr;   // A/B switch: the round-2 choices (before tools/sweep_ps.py, round 3)
   const bool whole_k = p.K % BK == 0 && (!p.A2 || p.K1 % BK == 0);
   const bool ps_ok = allow256 && whole_k && batch == 1 && !p.reduce_batch && splitk_req <= 1;      // what gemm_ps_kernel accepts
-  if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512 && tile != 640 && tile != 1128 && tile != 1160) {
+  if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512 && tile != 640 && tile != 1128 && tile != 1160 && tile != 2256 && tile != 2320) {
     // measured on MI355X (tools/sweep_small.py): 128x128 wins from one full round of the 256 CUs, and already from
     // a quarter round when K is long (3x3 convs at the 16x16 / 8x8 levels) if split-K fills the chip
     const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch;
@@ -1309,6 +1560,8 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   if (tile == 160 && !allow256) tile = 128;
   if (tile == 640 && (!allow256 || p.A2)) tile = 128;
   if ((tile == 1128 || tile == 1160) && !ps_ok) tile = tile == 1160 && p.N % 160 == 0 ? 160 : 128;
+  if ((tile == 2256 || tile == 2320) && !allow256) tile = 128;
+  if (tile == 2320 && general_epi) tile = p.N % 160 == 0 ? 160 : 128;      // the GELU / row-lookup epilogue of the 64 x 160 wave tile spills (256 + 44 VGPRs)
   // The DMA kernels address their operands through buffer resources (32-bit byte offsets): operands beyond 4 GB fall back to
   // the register-staged kernel.  The ping-pong kernels additionally need whole K-tiles.
   bool buf_ok = true;
@@ -1319,21 +1572,23 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     else { ab = ((unsigned long long)(p.M - 1) * p.lda + p.K1) * 2; if (p.A2) a2b = ((unsigned long long)(p.M - 1) * p.lda2 + (p.K - p.K1)) * 2; }
     buf_ok = ab < lim && a2b < lim && bb < lim;
     if (tile == 512 && (!allow256 || !buf_ok || !whole_k)) tile = 128;
+    if ((tile == 2256 || tile == 2320) && (!buf_ok || !whole_k)) tile = 128;
     if (tile == 640 && (!buf_ok || p.K % BK != 0)) tile = 128;
     pl.a_bytes = (unsigned)(buf_ok ? ab : 0); pl.a2_bytes = (unsigned)(buf_ok ? a2b : 0); pl.b_bytes = (unsigned)(buf_ok ? bb : 0);
     if (!buf_ok && tile != 64) { tile = 128; kt32 = false; stages = 2; }      // the register-staged fallback exists as 128x128 and 64x64 only
   }
   // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong, 640 = 512x128 ping-pong, 1128 / 1160 = persistent 256x128 / 256x160
   const int tm = tile == 160 ? 128 : (tile == 512 || tile >= 1000 ? 256 : (tile == 640 ? 512 : tile));
-  const int tn = tile == 256 ? 128 : (tile == 512 ? 256 : (tile == 640 ? 128 : (tile >= 1000 ? tile - 1000 : tile)));
+  const int tn = tile == 256 ? 128 : (tile == 512 ? 256 : (tile == 640 ? 128 : (tile >= 1000 ? tile % 1000 : tile)));
+  const bool pingpong = tile == 512 || tile == 2256 || tile == 2320;      // one 512-thread workgroup per CU
   const int gx = cdiv(p.N, tn), gy = cdiv(p.M, tm);
   // --- split-K: only when the grid underfills the chip and K is long ---
   int splitk = splitk_req;
-  if (tile >= 1000) splitk = 1;
+  if (tile >= 1000 && tile < 2000) splitk = 1;
   if (splitk <= 0) {
     splitk = 1;
     const long long tiles = (long long)gx * gy * batch;
-    if (tile == 512 && (tiles < 256 || !r2_rules)) {
+    if (pingpong && (tiles < 256 || !r2_rules)) {
       if (tiles < 256) {
         splitk = (int)(256 / tiles);                 // one 512-thread workgroup per CU: fill one round
         if (splitk > nkt / 16) splitk = nkt / 16;
@@ -1387,6 +1642,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   p.group_m = gm_env;
   p.fast_epi = !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                (p.strideC % 8 == 0) && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
+  p.fast_f32 = (p.flags & E4T_OUT_F32) && !(p.flags & E4T_ACCUM) && !p.rowbias && (!p.residual || (p.flags & E4T_RES_F32)) &&
+               (!(p.flags & E4T_ACT_GELU) || general_epi);
   if (p.colstats && (p.ws || !p.fast_epi || p.M % 32 != 0 || batch != 1)) p.colstats = nullptr;   // only the bf16 single-pass epilogue produces them
   const int stats_written = p.colstats != nullptr;
   // split-K / batch reduction: the 8-columns-per-thread kernel when C is bf16 and everything it touches is 16-byte aligned
@@ -1410,6 +1667,10 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                       : tile == 256 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>")
                       : nullptr;
     char symbuf[64];
+    if (!sym && tile >= 2000) {
+      snprintf(symbuf, sizeof(symbuf), "gemm_pq_kernel<%d, %d, %s>", conv ? 1 : 0, tile - 2000, general_epi ? "true" : "false");
+      sym = symbuf;
+    }
     if (!sym && tile >= 1000) {
       snprintf(symbuf, sizeof(symbuf), "gemm_ps_kernel<%d, %d, %s>", conv ? 1 : 0, tile - 1000, general_epi ? "true" : "false");
       sym = symbuf;
@@ -1427,7 +1688,20 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                              p.M, p.N, p.reduce_batch ? splitk * batch : splitk, 4.0 * (double)p.M * p.N * splitk * batch + osz * (double)p.M * p.N);
   }
   if (use_dma && buf_ok) {
-    if (tile >= 1000) {
+    if (tile == 2256 || tile == 2320) {
+      block = dim3(512);
+#define E4T_LAUNCH_PQ(BN_)                                                                                                  \
+  do {                                                                                                                     \
+    if (general_epi) { if (conv) hipLaunchKernelGGL((gemm_pq_kernel<1, BN_, true>), grid, block, 0, st, p);                \
+                       else hipLaunchKernelGGL((gemm_pq_kernel<0, BN_, true>), grid, block, 0, st, p); }                   \
+    else { if (conv) hipLaunchKernelGGL((gemm_pq_kernel<1, BN_, false>), grid, block, 0, st, p);                           \
+           else hipLaunchKernelGGL((gemm_pq_kernel<0, BN_, false>), grid, block, 0, st, p); }                              \
+  } while (0)
+      if (tile == 2256) E4T_LAUNCH_PQ(256);
+      else if (conv) hipLaunchKernelGGL((gemm_pq_kernel<1, 320, false>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_pq_kernel<0, 320, false>), grid, block, 0, st, p);
+#undef E4T_LAUNCH_PQ
+    } else if (tile >= 1000) {
       static const bool ps_pre = getenv("E4T_PS_PRE") == nullptr || atoi(getenv("E4T_PS_PRE")) != 0;      // A/B switch
       p.ps_pre = ps_pre && p.fast_epi && nkt >= 2 && (!p.rowbias || p.rows_per_batch % 256 == 0);
       const int rc = e4t_launch_gemm_ps(&p, conv ? 1 : 0, tile - 1000, general_epi ? 1 : 0, device_cu_count(), st);

@@ -35,6 +35,7 @@ struct GemmArgs {
   int group_m;      // row panels per raster group (xcd_tile)
   int reduce_batch; // partials of all (batch, split) pairs are summed into ONE C
   int fast_epi;     // bf16 C, 16-byte aligned rows: LDS-staged vectorised epilogue
+  int fast_f32;     // fp32 C (+ fp32 residual), no accumulate, no row bias: direct line-wide stores from the accumulator layout
   int ps_pre;       // persistent kernel: bias / row bias prefetched into LDS by DMA (write_tile<..., PRE>)
   long long strideA, strideB, strideC, strideBias;
   float* colstats;                       // optional [M/32][N][2] column statistics of the output (fast bf16 epilogue only)
@@ -249,6 +250,38 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][
         }
       }
     }
+    return;
+  }
+  if (!partial && p.fast_f32) {
+    // fp32 C with an optional fp32 residual, no accumulate (the fp32 residual stream of the CLIP-ViT: h = h + proj(...) stays fp32 as
+    // under torch.autocast, [3P] open_clip ResidualAttentionBlock via encoder.py:153-154).  The accumulator layout already holds 32
+    // consecutive columns of a row across lanes 0-31 (and of row + 4 across lanes 32-63): one store instruction writes two full
+    // 128-byte lines.  All loads are unconditional (clamped) and issued per fragment before their first use.
+    const float* Rf = (const float*)p.residual;
+    float* Cf = (float*)p.C;
+    const bool gelu = GENERAL && (p.flags & E4T_ACT_GELU) != 0;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = nw + j * 32 + frow, colc = min(col, p.N - 1);
+        const float bvv = p.bias ? p.bias[colc] : 0.f;
+        float rr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi, p.M - 1);
+          rr[r] = Rf ? Rf[(size_t)row * p.ldr + colc] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+          float v = acc[i][j][r] * p.alpha + bvv;
+          if (gelu) v = gelu_f(v);
+          v += rr[r];
+          if (row < p.M && col < p.N) Cf[(size_t)row * p.ldc + col] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     return;
   }
 #pragma unroll

@@ -637,13 +637,28 @@ constexpr int LN_MAXC = 3;
 // row per wave the bytes in flight per CU (occupancy x one 16-B load per lane) cover only about a third of the HBM
 // latency-bandwidth product — measured 3.0 TB/s algorithmic at M65536 D320 against 5.9 TB/s for the backward of the same
 // tensor, which has three streams in flight.  R rows = R independent load / reduce chains per wave.
-template <int NC, int R>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
+// XF32: the input rows are fp32 (the CLIP-ViT's fp32 residual stream); the output stays bf16 (the next GEMM's operand).
+template <bool XF32>
+struct LnChunk {                  // 8 consecutive elements of a row, as loaded
+  uint4 a, b;
+  __device__ __forceinline__ void load(const void* x, size_t elem) {
+    if (XF32) { const uint4* q = (const uint4*)((const float*)x + elem); a = q[0]; b = q[1]; }
+    else a = *(const uint4*)((const bf16_t*)x + elem);
+  }
+  __device__ __forceinline__ void get(float* v) const {
+    if (XF32) {
+      v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
+      v[4] = __uint_as_float(b.x); v[5] = __uint_as_float(b.y); v[6] = __uint_as_float(b.z); v[7] = __uint_as_float(b.w);
+    } else unpack8(a, v);
+  }
+};
+template <int NC, int R, bool XF32 = false>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, const float* gamma, const float* beta, bf16_t* y,
                                                      float* mean_rstd, int M, int D, float eps) {
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R, lane = threadIdx.x & 63;
   if (row0 >= M) return;
   const int nc = D >> 3;
-  uint4 raw[R][NC];
+  LnChunk<XF32> raw[R][NC];
   float ga[NC][8], be[NC][8];
   int cc[NC], rr[R];
   bool act[NC];
@@ -657,7 +672,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const floa
   for (int r = 0; r < R; ++r) {
     rr[r] = row0 + r < M ? row0 + r : M - 1;          // ragged last wave: re-read the last row, store nothing
 #pragma unroll
-    for (int i = 0; i < NC; ++i) raw[r][i] = *(const uint4*)(x + (size_t)rr[r] * D + cc[i] * 8);
+    for (int i = 0; i < NC; ++i) raw[r][i].load(x, (size_t)rr[r] * D + cc[i] * 8);
   }
 #pragma unroll
   for (int i = 0; i < NC; ++i) { ld8f(gamma + cc[i] * 8, ga[i]); ld8f(beta + cc[i] * 8, be[i]); }
@@ -668,7 +683,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const floa
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       float v[8];
-      unpack8(raw[r][i], v);
+      raw[r][i].get(v);
       if (act[i])
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += v[j];
@@ -683,7 +698,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const floa
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       float v[8];
-      unpack8(raw[r][i], v);
+      raw[r][i].get(v);
       if (act[i])
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float d = v[j] - mean[r]; q += d * d; }
@@ -699,7 +714,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const floa
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       float v[8], o[8];
-      unpack8(raw[r][i], v);
+      raw[r][i].get(v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (v[j] - mean[r]) * rstd[r] * ga[i][j] + be[i][j];
       if (act[i] && live) *(uint4*)(y + (size_t)rr[r] * D + cc[i] * 8) = pack8(o);
@@ -1008,20 +1023,33 @@ extern "C" int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2,
   return 0;
 }
 
-extern "C" int e4t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int M, int D,
-                                 float eps, e4t_stream stream) {
+namespace {
+int launch_ln_fwd(const void* x, bool xf32, const float* gamma, const float* beta, void* y, float* mean_rstd, int M, int D, float eps, e4t_stream stream) {
   E4T_REQUIRE(x && gamma && beta && y && M > 0, "layernorm_fwd: null argument");
   E4T_REQUIRE(D % 8 == 0 && D <= LN_MAXC * 64 * 8, "layernorm: D=%d must be a multiple of 8 and <= 1536", D);
   const int ncl = cdiv(D / 8, 64);      // 16-byte chunks per lane: the kernels are instantiated per count (no dead loads)
   // rows per wave: 4 / 2 / 2 for 1 / 2 / 3 chunks per lane; small M keeps one row per wave (enough blocks to fill the chip first)
-  const int rpw = (long long)M * ncl < 256 * 4 * 8 ? 1 : ncl == 1 ? 4 : 2;
-  E4T_LOG_LAUNCH("ln_fwd_kernel<%d, %d>|M%d D%d|%.0f|0", ncl < 3 ? ncl : 3, rpw, M, D, 4.0 * (double)M * D);
-#define E4T_LN_FWD(NC_, R_) hipLaunchKernelGGL((ln_fwd_kernel<NC_, R_>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean_rstd, M, D, eps)
-  if (rpw == 1) { if (ncl == 1) E4T_LN_FWD(1, 1); else if (ncl == 2) E4T_LN_FWD(2, 1); else E4T_LN_FWD(3, 1); }
-  else if (ncl == 1) E4T_LN_FWD(1, 4); else if (ncl == 2) E4T_LN_FWD(2, 2); else E4T_LN_FWD(3, 2);
+  const int rpw = ((long long)M * ncl < 256 * 4 * 8 || xf32) ? 1 : ncl == 1 ? 4 : 2;
+  E4T_LOG_LAUNCH("ln_fwd_kernel<%d, %d, %s>|M%d D%d|%.0f|0", ncl < 3 ? ncl : 3, rpw, xf32 ? "true" : "false", M, D, (xf32 ? 6.0 : 4.0) * (double)M * D);
+#define E4T_LN_FWD(NC_, R_, F_) hipLaunchKernelGGL((ln_fwd_kernel<NC_, R_, F_>), dim3(cdiv(M, 4 * R_)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y, mean_rstd, M, D, eps)
+  if (xf32) { if (ncl == 1) E4T_LN_FWD(1, 1, true); else if (ncl == 2) E4T_LN_FWD(2, 1, true); else E4T_LN_FWD(3, 1, true); }
+  else if (rpw == 1) { if (ncl == 1) E4T_LN_FWD(1, 1, false); else if (ncl == 2) E4T_LN_FWD(2, 1, false); else E4T_LN_FWD(3, 1, false); }
+  else if (ncl == 1) E4T_LN_FWD(1, 4, false); else if (ncl == 2) E4T_LN_FWD(2, 2, false); else E4T_LN_FWD(3, 2, false);
 #undef E4T_LN_FWD
   E4T_CHECK_LAUNCH("ln_fwd_kernel");
   return 0;
+}
+}  // namespace
+
+extern "C" int e4t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int M, int D, float eps,
+                                 e4t_stream stream) {
+  return launch_ln_fwd(x, false, gamma, beta, y, mean_rstd, M, D, eps, stream);
+}
+
+extern "C" int e4t_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int M, int D, float eps,
+                                     e4t_stream stream) {
+  E4T_REQUIRE(((uintptr_t)x & 15) == 0, "layernorm_fwd_f32: x must be 16-byte aligned");
+  return launch_ln_fwd(x, true, gamma, beta, y, mean_rstd, M, D, eps, stream);
 }
 
 extern "C" int e4t_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* add, void* dx,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "e4t_groupnorm_fwd_cs": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp, sz, vp]),
     "e4t_groupnorm_bwd": (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
     "e4t_layernorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
+    "e4t_layernorm_fwd_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, f32, vp]),
     "e4t_layernorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "e4t_colreduce_splits": (i32, [i32]),
     "e4t_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp, sz, vp]),

@@ -10,7 +10,8 @@ SD_UNET_BASE = dict(sample_size=64, in_channels=4, out_channels=4, block_out_cha
 # CompVis/stable-diffusion-v1-4 (unet/config.json) and stabilityai/stable-diffusion-2-1 at 768 px
 UNET_CONFIGS = {
     "sd14": dict(SD_UNET_BASE, cross_attention_dim=768, attention_head_dim=8),
-    "sd21": dict(SD_UNET_BASE, sample_size=96, cross_attention_dim=1024, attention_head_dim=(5, 10, 20, 20), use_linear_projection=True),
+    "sd21": dict(SD_UNET_BASE, sample_size=96, cross_attention_dim=1024, attention_head_dim=(5, 10, 20, 20), use_linear_projection=True,
+                 upcast_attention=True),
 }
 # text_encoder/config.json of the same checkpoints (CLIP ViT-L/14 text tower; OpenCLIP ViT-H text tower, 23 layers as shipped)
 CLIP_TEXT_L = dict(vocab_size=49408, hidden_size=768, num_layers=12, num_heads=12, intermediate_size=3072, max_len=77, act="quick_gelu")

@@ -106,6 +106,9 @@ def checked_load(module: torch.nn.Module, path: str, may_miss=lambda k: False, w
     """load_state_dict that fails loudly: unexpected keys always raise, missing keys raise unless `may_miss(key)` (the reference's
     load_e4t_unet / load_e4t_encoder contract, e4t/utils.py:119-124,150-154).  A shape mismatch raises inside torch."""
     sd = torch.load(path, map_location="cpu")
+    # transformers < 4.31 saved the (persistent, integer) buffer `*.embeddings.position_ids` with every CLIP state dict; it is an
+    # arange, not a weight, and the module trees here do not carry it: drop it, keep the strict check for every other key
+    sd = {k: v for k, v in sd.items() if not k.endswith(".position_ids")}
     missing, unexpected = module.load_state_dict(sd, strict=False)
     missing = [k for k in missing if not may_miss(k)]
     if missing or unexpected:

@@ -350,6 +350,10 @@ class DeviceLoader:
             while samples[k] is None:
                 samples[k] = self._load(next(self._items), plans_rng[k])
         nbytes = sum((s["image"].size + 15) // 16 * 16 for s in samples)
+        with ops.capture_lock:       # (host decode above ran unlocked) no allocation / copy / event wait while a HIP graph is being captured
+            return self._upload(slot, samples, nbytes)
+
+    def _upload(self, slot, samples, nbytes):
         if slot.event is not None:
             slot.event.synchronize()                     # the consumer's step that used this slot's output has been enqueued and finished
         slot.ensure(nbytes, self.B, self.size)

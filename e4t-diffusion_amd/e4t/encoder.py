@@ -19,6 +19,8 @@ What runs instead of the reference's ops:
 from __future__ import annotations
 
 
+import os
+
 import torch
 from torch import nn
 
@@ -74,13 +76,14 @@ class _ResBlock(nn.Module):
         qkv = Fn.linear(n, self.attn.in_proj_weight, self.attn.in_proj_bias, self._pq)
         dh = w // self.heads
         o = Fn.attention(qkv, None, B, self.heads, T, T, dh, dh ** -0.5)
-        h = Fn.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, self._po, residual=h)
+        f32s = h.dtype == torch.float32 and ops.ACT != torch.float32      # fp32 residual stream (frozen tower): h = h + proj(.) stays fp32
+        h = Fn.linear(o, self.attn.out_proj.weight, self.attn.out_proj.bias, self._po, residual=h, out_f32=f32s)
         n = Fn.layer_norm(h, self.ln_2.weight, self.ln_2.bias, self.ln_2.eps)
         if torch.is_grad_enabled() and (n.requires_grad or self.mlp.c_fc.weight.requires_grad):
             u = Fn.UnaryFn.apply(Fn.linear(n, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self._pf), 2)   # unfused GELU keeps a backward
         else:
             u = Fn.linear(n, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self._pf, gelu=True)
-        return Fn.linear(u, self.mlp.c_proj.weight, self.mlp.c_proj.bias, self._pp, residual=h)
+        return Fn.linear(u, self.mlp.c_proj.weight, self.mlp.c_proj.bias, self._pp, residual=h, out_f32=f32s)
 
 
 class _Transformer(nn.Module):
@@ -104,6 +107,7 @@ class VisionTransformer(nn.Module):
         self.proj = None
         self.output_tokens = True
         self.tokens_after_ln_post = False    # open_clip >= 2.20 behaviour when True
+        self.f32_residual = os.environ.get("E4T_VIT_F32_RESIDUAL", "1") != "0"      # A/B switch
         self._pc = Fn.PreparedLinear(self.conv1.weight)
 
     def forward(self, pixels):
@@ -121,8 +125,21 @@ class VisionTransformer(nn.Module):
         h = torch.cat([cls, x.view(B, g * g, w) + pos[1:][None]], dim=1).reshape(B * (g * g + 1), w).contiguous()
         T = g * g + 1
         h = Fn.layer_norm(h, self.ln_pre.weight, self.ln_pre.bias, self.ln_pre.eps)
+        # The residual stream of the frozen tower is fp32, as under the reference's torch.autocast (LayerNorm outputs and the
+        # `x + ...` adds are fp32 there, only the linears run in bf16): the out-proj / fc2 GEMMs add an fp32 residual and store fp32,
+        # the LayerNorms read fp32 rows.  A trainable tower (--unfreeze_clip_vision) keeps the bf16 stream its backward kernels use.
+        if self.f32_residual and not (torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())):
+            h = h.float()
         for blk in self.transformer.resblocks:
             h = blk(h, B, T)
+        if h.dtype != ops.ACT:
+            w_ = h.shape[1]
+            if self.tokens_after_ln_post:
+                h = Fn.layer_norm(h, self.ln_post.weight, self.ln_post.bias, self.ln_post.eps).view(B, T, w_)
+                return h[:, 0], h[:, 1:]
+            h = h.view(B, T, w_)
+            pooled = Fn.layer_norm(h[:, 0].contiguous(), self.ln_post.weight, self.ln_post.bias, self.ln_post.eps)
+            return pooled, h[:, 1:].to(ops.ACT)
         if self.tokens_after_ln_post:
             h = Fn.layer_norm(h, self.ln_post.weight, self.ln_post.bias, self.ln_post.eps).view(B, T, w)
             return h[:, 0], h[:, 1:]

@@ -54,7 +54,16 @@ class CrossAttention(nn.Module):
         self.inner_dim = dim_head * heads
         self.is_self = cross_attention_dim is None
         cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
-        self.upcast_attention, self.upcast_softmax = upcast_attention, upcast_softmax  # softmax is fp32 in the kernel regardless
+        # upcast_attention / upcast_softmax (cross_attention.py:224-226,245-246; `stable-diffusion-2-1` @768 ships upcast_attention):
+        # accepted and HONOURED BY CONSTRUCTION, not by a switch.  In the reference they are `.float()` casts in front of
+        # torch.baddbmm / softmax of the math path; under the recipe this path replaces (`--mixed_precision bf16` = torch.autocast)
+        # baddbmm is on autocast's cast-to-bf16 list, so the upcast query / key are cast straight back and Q.K^T runs with bf16
+        # operands either way (checked: baddbmm(fp32, fp32) under autocast(bf16) returns bf16), and the SDPA / xFormers processors
+        # (cross_attention.py:473-481,521-531) never look at the flags.  The kernel (csrc/attention.hip) contracts bf16 operands into
+        # an fp32 accumulator, keeps the scores and the whole softmax in fp32 registers and never rounds S to bf16 — at least the
+        # precision of either setting under autocast.  tests/test_configs_gpu.py::full_sd21 builds the UNet with upcast_attention=True
+        # and holds it to the fp32 oracle.
+        self.upcast_attention, self.upcast_softmax = upcast_attention, upcast_softmax
         self.scale = dim_head ** -0.5
         self.heads = heads
         self.to_q = nn.Linear(query_dim, self.inner_dim, bias=False)

@@ -8,8 +8,11 @@ never installs another backend: with no GPU / no built library every call raises
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import gc
 import os
+import threading
 from dataclasses import dataclass, field
 from typing import List, Optional
 
@@ -25,6 +28,30 @@ f32 = torch.float32
 ACT = bf16
 
 _WEIGHTS_EPOCH = 0
+
+# Held while a HIP graph is being captured (CLIP text encoder, sampling loop).  Stream capture runs in "global" error mode: a
+# device allocation, a pinned-memory allocation, an event synchronisation or a host-to-device copy issued by ANOTHER host thread
+# while the capture is open invalidates it (hipErrorStreamCaptureUnsupported / ...Invalidated).  The only other thread of a rank that
+# talks to the GPU is the data loader's prefetch worker (data.py DeviceLoader._produce): it takes this lock around its GPU section,
+# so a capture simply pauses it for the few hundred milliseconds it takes.
+capture_lock = threading.RLock()
+
+
+@contextlib.contextmanager
+def capture_guard():
+    """Everything a HIP graph capture needs from the rest of the process: the loader's prefetch worker paused (capture_lock) and the
+    garbage collector off — a cycle holding an OLD graph (a re-captured shape, a previous model) that is collected while a capture
+    is open runs ~CUDAGraph -> hipGraphDestroy -> "operation not permitted when stream is capturing" inside a destructor, i.e. a
+    process abort (seen when a second trainer was built in one process).  Collects first."""
+    was_on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with capture_lock:
+            yield
+    finally:
+        if was_on:
+            gc.enable()
 
 
 def weights_epoch() -> int:
@@ -351,12 +378,14 @@ class HipBackend:
         return dx1, dx2, dgamma, dbeta
 
     def layernorm_fwd(self, x, gamma, beta, eps, need_stats=True):
+        """x: bf16, or fp32 rows of an fp32 residual stream (CLIP-ViT); y is bf16 either way"""
         M, D = x.shape
         assert x.is_contiguous()
-        y = torch.empty_like(x)
+        y = torch.empty((M, D), dtype=bf16, device=x.device)
         stats = torch.empty((M, 2), dtype=f32, device=x.device) if need_stats else None
-        self._timed("ln_fwd", 0.0, lambda: _C.check(self.lib.e4t_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), M, D, float(eps),
-                                                                           _stream()), "e4t_layernorm_fwd"), 4.0 * M * D)
+        fn, what = (self.lib.e4t_layernorm_fwd_f32, "e4t_layernorm_fwd_f32") if x.dtype == f32 else (self.lib.e4t_layernorm_fwd, "e4t_layernorm_fwd")
+        self._timed("ln_fwd", 0.0, lambda: _C.check(fn(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), M, D, float(eps), _stream()), what),
+                    (x.element_size() + 2.0) * M * D)
         return y, stats
 
     def layernorm_bwd(self, x, dy, gamma, stats, want_param_grads=False, add=None):

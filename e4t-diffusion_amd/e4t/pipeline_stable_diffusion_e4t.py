@@ -273,7 +273,7 @@ class StableDiffusionE4TPipeline:
             latents.copy_(keep)
         torch.cuda.current_stream(latents.device).wait_stream(coefs_stream)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=coefs_stream):
+        with ops.capture_guard(), torch.cuda.graph(graph, stream=coefs_stream):
             fn()
         latents.copy_(keep)               # capture does not execute: the first replay starts from the same state
         return graph

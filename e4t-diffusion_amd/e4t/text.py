@@ -78,14 +78,37 @@ class CLIPTextModel(_CLIPTextTree):
         hit = self._graphs.get(sig)
         if hit is None or hit[0] != self._fused[0]:
             sample = torch.zeros_like(inputs_embeds).requires_grad_(True)
+            be = ops.backend()
+            ws_before = set(getattr(be, "_ws", {}))
             try:
-                fn = torch.cuda.make_graphed_callables(lambda e: self._encode(e, False), (sample,))
+                # ops.capture_guard: the data loader's prefetch worker is paused (an allocation, copy or event wait from another host
+                # thread invalidates a capture in global error mode) and the garbage collector is off (destroying an old graph during
+                # a capture aborts the process).  Call `prepare_graphs` before the training loop to keep the pause out of the first step.
+                with ops.capture_guard():
+                    torch.cuda.synchronize()
+                    fn = torch.cuda.make_graphed_callables(lambda e: self._encode(e, False), (sample,))
+                # scratch buffers the warm-up / capture streams made the backend allocate (64 MB each, keyed by stream): the graph's
+                # own copy lives in its memory pool, the host-side handles are dead weight
+                for k in [k for k in getattr(be, "_ws", {}) if k not in ws_before]:
+                    del be._ws[k]
             except Exception as ex:          # capture unsupported in this process: run the launches from the host as before
                 warnings.warn(f"CLIP text encoder: HIP graph capture failed ({type(ex).__name__}: {ex}); running eagerly")
                 self._graph_ok = False
                 return self._encode(inputs_embeds, False)
             hit = self._graphs[sig] = (self._fused[0], fn)
         return hit[1](inputs_embeds).clone()
+
+    def prepare_graphs(self, batch_size, device, requires_grad=True):
+        """Capture the frozen stack's graphs for (batch_size, max_len, width) inputs NOW — before the training loop and its loader
+        thread start — instead of inside the first step.  No-op when graphs are off, the weights train, or on the CPU."""
+        dev = torch.device(device)
+        if not (self._graph_ok and dev.type == "cuda") or any(p.requires_grad for p in self.text_model.encoder.parameters()):
+            return False
+        cfg = self.config
+        e = torch.zeros((batch_size, cfg["max_len"], cfg["hidden_size"]), device=dev, requires_grad=requires_grad)
+        with torch.enable_grad():
+            self._replay(e)
+        return self._graph_ok
 
     def _encode(self, inputs_embeds, trainable):
         tm = self.text_model

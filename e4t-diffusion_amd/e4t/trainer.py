@@ -170,6 +170,13 @@ class E4TTrainer:
                                "or a non-deterministic gradient path)")
         return True
 
+    def prepare(self, batch_size):
+        """One-off work that should not land inside the first training step: the frozen text encoder's HIP graphs for this batch size
+        are captured here, before the caller starts its data-loader thread (a capture and another thread's allocations do not mix)."""
+        te = self.text_encoder
+        if hasattr(te, "prepare_graphs") and not self.text_trainable:
+            te.prepare_graphs(batch_size, self.device)
+
     def _refresh_text_constants(self):
         with torch.no_grad():
             emb = self.text_encoder.get_input_embeddings()

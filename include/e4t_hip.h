@@ -167,6 +167,10 @@ int e4t_groupnorm_bwd(const void* x1, int C1, const void* x2, int C2, const void
 /* LayerNorm over the last dim (attention.py:259,268,273; open_clip ViT ln_*). */
 int e4t_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd /* [M][2] or NULL */,
                       int M, int D, float eps, e4t_stream stream);
+/* The same with fp32 input rows (y stays bf16): LayerNorm of an fp32 residual stream — under torch.autocast the CLIP-ViT's
+ * ResidualAttentionBlock keeps x = x + attn(ln_1(x)) in fp32 ([3P] open_clip via encoder.py:153-154). */
+int e4t_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int M, int D, float eps,
+                          e4t_stream stream);
 /* dx = LN'(dy) (+ add): `add` (bf16 [M][D] or NULL) is the gradient that reaches x through the residual branch of a
  * pre-LN block, fused here instead of a separate elementwise add. */
 int e4t_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean_rstd, const void* add, void* dx,

@@ -397,7 +397,7 @@ SD14_UNET_CONFIG = dict(
     up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
 )
 SD21_UNET_CONFIG = dict(SD14_UNET_CONFIG, sample_size=96, cross_attention_dim=1024,
-                        attention_head_dim=(5, 10, 20, 20), use_linear_projection=True)
+                        attention_head_dim=(5, 10, 20, 20), use_linear_projection=True, upcast_attention=True)   # stable-diffusion-2-1 @768
 
 
 class UNet2DConditionModel(nn.Module):

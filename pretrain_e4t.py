@@ -138,6 +138,7 @@ def setup(args, dev, world=1, rank=0):
             lr, args.gradient_accumulation_steps, world, args.train_batch_size, args.learning_rate))
     tr = E4TTrainer(unet, enc, text, vae, lr=lr, domain_embed_scale=args.domain_embed_scale, reg_lambda=args.reg_lambda,
                     prediction_type=args.prediction_type, class_token_id=class_token_id, empty_prompt_ids=empty_ids.to(dev), device=dev)
+    tr.prepare(args.train_batch_size)        # graph captures happen here, before any loader thread exists
     rng = random.Random((args.seed or 0) + (rank if args.per_rank_seed else 0)) if args.seed is not None else random.Random()
 
     def prompts(bsz):                                                                                      # :607-615

@@ -61,6 +61,10 @@ def check_gemm(hip, emu, dev):
         (300, 480, 128, 1160, 1), (2048, 128, 64, 1128, 1), (256, 160, 64, 1160, 1), (66000, 100, 64, 1128, 1), (4112, 1280, 1280, 1160, 1),
         (1000, 256, 328, 1128, 1),                                   # K % 64 != 0: falls back to the 128 x 128 tile
         (900, 384, 512, 5256, 1), (5000, 640, 320, 5256, 1),         # experimental: 256 x 128, 32-wide K-tiles
+        # k-step-phased ping-pong tiles (gemm_pq_kernel): 256 x 256 and 256 x 320 (wave tile 64 x 160); ragged M / N, one K-tile, split-K
+        (512, 512, 512, 2256, 1), (700, 520, 256, 2256, 1), (300, 256, 64, 2256, 1), (513, 1000, 1152, 2256, 2), (2048, 1280, 1920, 2256, 0),
+        (1000, 320, 320, 2320, 1), (700, 640, 256, 2320, 1), (300, 200, 64, 2320, 1), (4096, 1280, 2560, 2320, 0), (513, 1000, 1152, 2320, 2),
+        (65536, 320, 320, 2320, 1), (16384, 640, 640, 2320, 0),
     ]
     for i, (M, N, K, tile, sk) in enumerate(cases):
         g = gen(10 + i, dev)
@@ -86,7 +90,8 @@ def check_gemm(hip, emu, dev):
     out.append(("gemm_tn into a column slice", rel(wide, wide2), TOLF * 50))
     # column statistics left by the epilogue for the consuming GroupNorm (all tile variants; with / without residual)
     for i, (M, N, K, tile) in enumerate([(256, 128, 128, 0), (4096, 320, 320, 160), (1024, 640, 1280, 128), (2048, 512, 2304, 512), (192, 72, 64, 64),
-                                         (4096, 320, 320, 1160), (8192, 256, 128, 1128), (66560, 640, 192, 1160), (34816, 128, 64, 1128)]):
+                                         (4096, 320, 320, 1160), (8192, 256, 128, 1128), (66560, 640, 192, 1160), (34816, 128, 64, 1128),
+                                         (4096, 320, 320, 2320), (2048, 512, 2304, 2256), (8192, 640, 640, 2320)]):
         g = gen(60 + i, dev)
         a, b = rnd(g, M, K, dev=dev), rnd(g, N, K, scale=K ** -0.5, dev=dev)
         res = rnd(g, M, N, dev=dev) if i % 2 == 0 else None
@@ -104,7 +109,7 @@ def check_gemm(hip, emu, dev):
     out.append(("gemm gelu fp32-out t512", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32, tile=512),
                                                 emu.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32)), TOLF * 50))
     out.append(("gemm gelu", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
-    for t in (512, 1128, 1160):      # the GENERAL epilogue instantiations of the ping-pong / persistent kernels
+    for t in (512, 1128, 1160, 2256):      # the GENERAL epilogue instantiations of the ping-pong / persistent kernels
         out.append((f"gemm gelu t{t}", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True, tile=t), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
         out.append((f"gemm two-source A t{t}", rel(hip.gemm(a1, b, a2=a2, tile=t), emu.gemm(a1, b, a2=a2)), TOL1))
     c0 = rnd(g, M, N, dtype=f32, dev=dev)
@@ -112,6 +117,13 @@ def check_gemm(hip, emu, dev):
     hip.gemm(a1, b[:, :K1].contiguous(), out=c1, accum=True, alpha=0.5)
     emu.gemm(a1, b[:, :K1].contiguous(), out=c2, accum=True, alpha=0.5)
     out.append(("gemm fp32 out + accumulate + alpha", rel(c1, c2), TOLF * 50))
+    # fp32 C + fp32 residual (the CLIP-ViT's fp32 residual stream): the line-wide direct-store epilogue, every kernel family
+    gv = gen(33, dev)
+    for (Mv, Nv, Kv, t) in [(4112, 1280, 1280, 0), (4112, 1280, 5120, 0), (1000, 1280, 320, 160), (700, 512, 256, 512), (513, 200, 64, 64), (2048, 256, 128, 1128), (900, 384, 96, 5256)]:
+        av, bw = rnd(gv, Mv, Kv, dev=dev), rnd(gv, Nv, Kv, scale=Kv ** -0.5, dev=dev)
+        r32, bi = rnd(gv, Mv, Nv, dtype=f32, dev=dev), rnd(gv, Nv, dtype=f32, dev=dev)
+        out.append((f"gemm {Mv}x{Nv}x{Kv} t{t} fp32 out + fp32 residual", rel(hip.gemm(av, bw, bias=bi, residual=r32, out_dtype=f32, tile=t),
+                                                                            emu.gemm(av, bw, bias=bi, residual=r32, out_dtype=f32)), TOLF * 50))
     rb = rnd(g, M // 96, N, dtype=f32, dev=dev)
     out.append(("gemm rowbias", rel(hip.gemm(a1, b[:, :K1].contiguous(), rowbias=rb, rows_per_batch=96),
                                     emu.gemm(a1, b[:, :K1].contiguous(), rowbias=rb, rows_per_batch=96)), TOL1))
@@ -152,6 +164,9 @@ def check_conv(hip, emu, dev):
         (3, 24, 24, 64, 192, CONV_S1, 24, 24, 1128, 1), (3, 16, 16, 64, 128, CONV_S2, 8, 8, 1128, 1), (2, 8, 8, 64, 160, CONV_UP2, 16, 16, 1160, 1),
         (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 1128, 1), (1, 64, 64, 128, 128, 5, 32, 32, 1128, 1), (18, 64, 64, 128, 128, CONV_S1, 64, 64, 1128, 1),
         (2, 48, 40, 64, 320, CONV_S1, 48, 40, 5256, 1),
+        (4, 32, 32, 320, 320, CONV_S1, 32, 32, 2320, 1), (2, 32, 32, 128, 256, CONV_S1, 32, 32, 2256, 1), (2, 16, 16, 256, 640, CONV_S1, 16, 16, 2320, 2),
+        (3, 16, 16, 64, 320, CONV_S2, 8, 8, 2320, 1), (2, 8, 8, 64, 320, CONV_UP2, 16, 16, 2320, 1), (2, 8, 8, 128, 256, CONV_S2T, 16, 16, 2256, 1),
+        (16, 64, 64, 64, 320, CONV_S1, 64, 64, 2320, 1),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
         g = gen(50 + i, dev)
@@ -287,6 +302,11 @@ def check_norms(hip, emu, dev):
         out.append((f"layernorm {M}x{D} bwd dx", rel(dx, ex), TOL1))
         out.append((f"layernorm {M}x{D} bwd dgamma", rel(dga, ega), 1e-3))
         out.append((f"layernorm {M}x{D} bwd dbeta", rel(dbe, ebe), 1e-3))
+        x32 = (rnd(g, M, D, dtype=f32, dev=dev) + 0.5) * 3.0            # fp32 rows (ViT residual stream) -> bf16 y
+        y32, st32 = hip.layernorm_fwd(x32, gamma, beta, 1e-5)
+        yr32, str32 = emu.layernorm_fwd(x32, gamma, beta, 1e-5)
+        out.append((f"layernorm {M}x{D} fwd, fp32 input", rel(y32, yr32), TOL1))
+        out.append((f"layernorm {M}x{D} stats, fp32 input", rel(st32, str32), 1e-4))
         skip = rnd(g, M, D, dev=dev)
         out.append((f"layernorm {M}x{D} bwd dx + residual grad", rel(hip.layernorm_bwd(x, dy, gamma, str_, add=skip)[0],
                                                                      emu.layernorm_bwd(x, dy, gamma, str_, add=skip)[0]), TOL1))
@@ -455,10 +475,12 @@ def check_gemm_races(hip, emu, dev):
         want = emu.gemm(a, w)
         ref = hip.gemm(a, w, tile=128)
         out.append((f"race-check reference {M}x{N}x{K}", rel(ref, want), TOL1))
-        for code in (64, 3064, 4064, 128, 3128, 4128, 160, 3160, 4160, 1128, 1160, 5256, 512):
+        for code in (64, 3064, 4064, 128, 3128, 4128, 160, 3160, 4160, 1128, 1160, 5256, 512, 2256, 2320):
             if code % 1000 == 160 and N % 160:
                 continue
-            if code == 512 and N % 256:
+            if code in (512, 2256) and N % 256:
+                continue
+            if code == 2320 and N % 320:
                 continue
             differing = 0
             for _ in range(12):
@@ -466,8 +488,9 @@ def check_gemm_races(hip, emu, dev):
             out.append((f"gemm {M}x{N}x{K} tile code {code}: launches (of 12) differing from the reference", float(differing), 0.0))
     x, w = rnd(g, 16 * 32 * 32, 640, dev=dev), rnd(g, 640, 9 * 640, dev=dev)
     ref = hip.conv3x3(x, w, 16, 32, 32, 32, 32, CONV_S1, tile=128)
-    for code in (128, 3128, 160, 4160, 64, 3064, 1128, 1160):
-        differing = sum(int((hip.conv3x3(x, w, 16, 32, 32, 32, 32, CONV_S1, tile=code) != ref).sum() > 0) for _ in range(6))
+    for code in (128, 3128, 160, 4160, 64, 3064, 1128, 1160, 2320):
+        sk = 1 if code == 2320 else 0          # (its automatic split-K would change the summation order, not a race)
+        differing = sum(int((hip.conv3x3(x, w, 16, 32, 32, 32, 32, CONV_S1, tile=code, splitk=sk) != ref).sum() > 0) for _ in range(6))
         out.append((f"conv 32x32 640->640 tile code {code}: launches (of 6) differing", float(differing), 0.0))
     dy, xx = rnd(g, 16384, 640, dev=dev), rnd(g, 16384, 1280, dev=dev)
     ref = hip.gemm_tn(dy, xx)

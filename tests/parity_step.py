@@ -476,7 +476,8 @@ def batch_consistency(case_name, dev, B=16, verbose=True):
     grids).  Every per-sample quantity of the B-step (VAE latents, 13 encoder maps, e_hat) is compared with the B = 1 run of that
     sample, and the gradient of every trainable tensor with the sum over the B single-sample backward passes of
     loss_diff_i / B + loss_reg_i  (= the B-step's loss, pretrain_e4t.py:645-647).  Both sides are bf16 realisations of the same
-    arithmetic, so the bounds are absolute: a mis-indexed tile or a wrong split-K reduction is an O(1) error.
+    arithmetic, so the bounds are absolute: a mis-indexed tile or a wrong split-K reduction is an O(1) error.  (Forward bound 3e-2:
+    the deepest encoder map is 1.4e-2 from the ORACLE in either realisation, measured 1.6e-2 between the two; UNet gradients pooled 1.2e-3.)
     The E4T head's gradients see the LeakyReLU kink lottery between the two realisations (module docstring) and get a loose bound;
     UNet-side gradients do not pass through the head's backward and get the tight one."""
     import dataclasses
@@ -541,7 +542,7 @@ def batch_consistency(case_name, dev, B=16, verbose=True):
     pooled = {part: rel(torch.cat([tr.flat.view(i, g_full).reshape(-1) for i, p in enumerate(tr.flat.params) if names[id(p)].startswith(part)]),
                         torch.cat([tr.flat.view(i, g_sum).reshape(-1) for i, p in enumerate(tr.flat.params) if names[id(p)].startswith(part)]))
               for part in ("unet.", "e4t_encoder.")}
-    BOUND = dict(forward=1.5e-2, loss=2e-3, unet_grad=6e-2, unet_pooled=2e-2, head_grad=0.5, head_pooled=0.25)
+    BOUND = dict(forward=3e-2, loss=2e-3, unet_grad=6e-2, unet_pooled=2e-2, head_grad=0.5, head_pooled=0.25)
     bad = [(k, e) for k, e in rows if e > (BOUND["loss"] if k.startswith("loss") else BOUND["forward"])]
     bad += [(k, e) for k, e in grads if e > (BOUND["unet_grad"] if k.startswith("grad/unet.") else BOUND["head_grad"])]
     if pooled["unet."] > BOUND["unet_pooled"]:

@@ -168,3 +168,18 @@ def test_trainable_text_encoder_trains_natively(emu_fp32):
     assert any("token_embedding" in n for n in moved) and any("position_embedding" in n for n in moved)
     tr.train_step(px, ids, pidx, latents=lat)
     assert not torch.equal(tr.ctx_for_e4t, ctx_before)                                             # re-evaluated with the updated weights
+
+
+def test_checked_load_ignores_legacy_position_ids_but_nothing_else(tmp_path):
+    """CLIPTextModel state dicts written by transformers < 4.31 carry the persistent buffer `...embeddings.position_ids`
+    (an arange): real SD text-encoder dumps must load; any other unexpected key still raises."""
+    from e4t import cli_common as cc
+    lin = torch.nn.Linear(4, 3)
+    sd = dict(lin.state_dict())
+    sd["text_model.embeddings.position_ids"] = torch.arange(77)[None]
+    torch.save(sd, tmp_path / "ok.pt")
+    cc.checked_load(torch.nn.Linear(4, 3), str(tmp_path / "ok.pt"))
+    sd["text_model.embeddings.something_else"] = torch.zeros(1)
+    torch.save(sd, tmp_path / "bad.pt")
+    with pytest.raises(RuntimeError, match="something_else"):
+        cc.checked_load(torch.nn.Linear(4, 3), str(tmp_path / "bad.pt"))

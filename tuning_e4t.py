@@ -98,6 +98,7 @@ def setup(args, dev):
     tr = E4TTrainer(unet, enc, text, vae, lr=lr, domain_embed_scale=args.domain_embed_scale, reg_lambda=args.reg_lambda,
                     prediction_type=getattr(pretrained_args, "prediction_type", None) or "epsilon", class_token_id=class_token_id,
                     empty_prompt_ids=empty_ids.to(dev), device=dev, tuning=True, max_grad_norm=args.max_grad_norm)
+    tr.prepare(args.train_batch_size)
     print(f"Number of Trainable Parameters: {tr.flat.numel * 1.e-6:.2f} M")
     import random
     rng = random.Random(args.seed)
