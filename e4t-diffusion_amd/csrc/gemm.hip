@@ -772,7 +772,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 256 x BN ping-pong, BN = 256 | 320, phases = (k half) x (16-wide k step)      [round 3]
+// 256 x 320 ping-pong, phases = (k half) x (16-wide k step)      [round 3; the template also builds BN = 256, measured = gemm_pp_kernel]
 //
 // The same machine as gemm_pp_kernel — two groups of four waves alternating an LDS/DMA segment with an MFMA segment, operand
 // quarters of 32 k moved by LDS-DMA, counted vmcnt — with the K-tile cut along K instead of along the wave tile's rows: a phase is
@@ -1015,10 +1015,20 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
   if (grp == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();   // every fragment read and every DMA is done before the epilogue reuses the LDS
   // 32-row slices of the wave tile: the staging of 8 waves x 32 x (WN + 8) fits the operand buffers, the unrolled epilogue stays small
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    if (i) __syncthreads();
+  // (compile-time row index: a runtime-indexed accumulator array is placed in scratch memory — 704 bytes per lane written and read back
+  // through HBM cost ~55 us per tile in the first version of this kernel)
+  auto slice = [&](auto Ic) {
+    constexpr int i = decltype(Ic)::value;
     write_tile<32, WN, 1, FN, GENERAL>(p, *(f32x16(*)[1][FN])(&acc[i][0]), wave_stage<32, WN>(smem, wave), lane, m0 + wr * WM + i * 32, n0 + wc * WN);
+  };
+  slice(I0{});
+  __syncthreads();
+  slice(I1{});
+  if constexpr (FM == 4) {
+    __syncthreads();
+    slice(I2{});
+    __syncthreads();
+    slice(I3{});
   }
 }
 
@@ -1497,7 +1507,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   static const bool r2_rules = getenv("E4T_GEMM_R2RULES") != nullptr;   // A/B switch: the round-2 choices (before tools/sweep_ps.py, round 3)
   const bool whole_k = p.K % BK == 0 && (!p.A2 || p.K1 % BK == 0);
   const bool ps_ok = allow256 && whole_k && batch == 1 && !p.reduce_batch && splitk_req <= 1;      // what gemm_ps_kernel accepts
-  if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512 && tile != 640 && tile != 1128 && tile != 1160 && tile != 2256 && tile != 2320) {
+  if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512 && tile != 640 && tile != 1128 && tile != 1160 && tile != 2320) {
     // measured on MI355X (tools/sweep_small.py): 128x128 wins from one full round of the 256 CUs, and already from
     // a quarter round when K is long (3x3 convs at the 16x16 / 8x8 levels) if split-K fills the chip
     const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch;
@@ -1539,6 +1549,21 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     //    padding of K to 64), GEMM M65536 N2560 K320 162 vs 185, M65536 N1280 K320 76 vs 81 us.
     if (!r2_rules && allow256 && tile == 128 && !general && (p.N % 128 == 0 || p.N < 128) &&
         (long long)cdiv(p.M, 256) * cdiv(p.N, 128) * batch >= 768) { tile = 256; kt32 = true; stages = 3; }
+    //  * the 256 x 320 ping-pong tile (gemm_pq_kernel, code 2320) wherever N is a multiple of 320 and its rounds of one workgroup per
+    //    CU come out full: 0.93 KB of LDS traffic per MFMA against 1.69 KB for the 128 x 160 tile.  Cold-operand sweep
+    //    (profiles/r03_sweep_tiles_c.txt): conv 320->320 @64^2 105 vs 127 us (1154 TF/s), 640->640 @64^2 374 vs 458, 1280->1280
+    //    M16384 354 vs 439 (1366 TF/s), nearest-x2 + conv 1280->1280 339 vs 472 (1424 TF/s); GEMM M65536 N320 K2560 103 vs 135,
+    //    K1280 57 vs 73, K320 26 vs 28; M4096 N10240 K1280 100 vs 112 (ping-pong 256 x 256).  It loses below one round (M16384
+    //    N640: 128 tiles) and on the K = 320 GEMMs wider than 320 (epilogue-bound: 83 vs 72 us at N1280).
+    static const bool no_pq = getenv("E4T_GEMM_NOPQ") != nullptr;      // A/B switch
+    if (!r2_rules && !no_pq && allow256 && batch == 1 && !general && whole_k && p.N % 320 == 0) {
+      const long long t320 = (long long)cdiv(p.M, 256) * (p.N / 320);
+      const int ncu = device_cu_count();
+      const double eff = (double)t320 / (double)(cdivl(t320, ncu) * ncu);
+      if (t320 >= ncu && ((nkt >= 20 && eff >= 0.75) || (nkt >= 10 && eff >= 0.99) || (nkt >= 5 && p.N == 320 && eff >= 0.99))) {
+        tile = 2320; kt32 = false; stages = 2;
+      }
+    }
     // The persistent 256 x 160 / 256 x 128 streaming kernel (gemm_ps.hip).  NOT chosen automatically: correct, but slower than the
     // tiles above on every shape of the step (its ping-pong phases are bound by the DMA-issue / fragment-read segment).
     // E4T_GEMM_PS=1 turns the automatic choice on for experiments.
@@ -1560,7 +1585,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   if (tile == 160 && !allow256) tile = 128;
   if (tile == 640 && (!allow256 || p.A2)) tile = 128;
   if ((tile == 1128 || tile == 1160) && !ps_ok) tile = tile == 1160 && p.N % 160 == 0 ? 160 : 128;
-  if ((tile == 2256 || tile == 2320) && !allow256) tile = 128;
+  if (tile == 2320 && !allow256) tile = 128;
   if (tile == 2320 && general_epi) tile = p.N % 160 == 0 ? 160 : 128;      // the GELU / row-lookup epilogue of the 64 x 160 wave tile spills (256 + 44 VGPRs)
   // The DMA kernels address their operands through buffer resources (32-bit byte offsets): operands beyond 4 GB fall back to
   // the register-staged kernel.  The ping-pong kernels additionally need whole K-tiles.
@@ -1572,7 +1597,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     else { ab = ((unsigned long long)(p.M - 1) * p.lda + p.K1) * 2; if (p.A2) a2b = ((unsigned long long)(p.M - 1) * p.lda2 + (p.K - p.K1)) * 2; }
     buf_ok = ab < lim && a2b < lim && bb < lim;
     if (tile == 512 && (!allow256 || !buf_ok || !whole_k)) tile = 128;
-    if ((tile == 2256 || tile == 2320) && (!buf_ok || !whole_k)) tile = 128;
+    if (tile == 2320 && (!buf_ok || !whole_k)) tile = 128;
     if (tile == 640 && (!buf_ok || p.K % BK != 0)) tile = 128;
     pl.a_bytes = (unsigned)(buf_ok ? ab : 0); pl.a2_bytes = (unsigned)(buf_ok ? a2b : 0); pl.b_bytes = (unsigned)(buf_ok ? bb : 0);
     if (!buf_ok && tile != 64) { tile = 128; kt32 = false; stages = 2; }      // the register-staged fallback exists as 128x128 and 64x64 only
@@ -1580,7 +1605,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   // 256 = 256x128, 160 = 128x160, 512 = 256x256 ping-pong, 640 = 512x128 ping-pong, 1128 / 1160 = persistent 256x128 / 256x160
   const int tm = tile == 160 ? 128 : (tile == 512 || tile >= 1000 ? 256 : (tile == 640 ? 512 : tile));
   const int tn = tile == 256 ? 128 : (tile == 512 ? 256 : (tile == 640 ? 128 : (tile >= 1000 ? tile % 1000 : tile)));
-  const bool pingpong = tile == 512 || tile == 2256 || tile == 2320;      // one 512-thread workgroup per CU
+  const bool pingpong = tile == 512 || tile == 2320;      // one 512-thread workgroup per CU
   const int gx = cdiv(p.N, tn), gy = cdiv(p.M, tm);
   // --- split-K: only when the grid underfills the chip and K is long ---
   int splitk = splitk_req;
@@ -1688,19 +1713,10 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                              p.M, p.N, p.reduce_batch ? splitk * batch : splitk, 4.0 * (double)p.M * p.N * splitk * batch + osz * (double)p.M * p.N);
   }
   if (use_dma && buf_ok) {
-    if (tile == 2256 || tile == 2320) {
+    if (tile == 2320) {
       block = dim3(512);
-#define E4T_LAUNCH_PQ(BN_)                                                                                                  \
-  do {                                                                                                                     \
-    if (general_epi) { if (conv) hipLaunchKernelGGL((gemm_pq_kernel<1, BN_, true>), grid, block, 0, st, p);                \
-                       else hipLaunchKernelGGL((gemm_pq_kernel<0, BN_, true>), grid, block, 0, st, p); }                   \
-    else { if (conv) hipLaunchKernelGGL((gemm_pq_kernel<1, BN_, false>), grid, block, 0, st, p);                           \
-           else hipLaunchKernelGGL((gemm_pq_kernel<0, BN_, false>), grid, block, 0, st, p); }                              \
-  } while (0)
-      if (tile == 2256) E4T_LAUNCH_PQ(256);
-      else if (conv) hipLaunchKernelGGL((gemm_pq_kernel<1, 320, false>), grid, block, 0, st, p);
+      if (conv) hipLaunchKernelGGL((gemm_pq_kernel<1, 320, false>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_pq_kernel<0, 320, false>), grid, block, 0, st, p);
-#undef E4T_LAUNCH_PQ
     } else if (tile >= 1000) {
       static const bool ps_pre = getenv("E4T_PS_PRE") == nullptr || atoi(getenv("E4T_PS_PRE")) != 0;      // A/B switch
       p.ps_pre = ps_pre && p.fast_epi && nkt >= 2 && (!p.rowbias || p.rows_per_batch % 256 == 0);

@@ -61,8 +61,7 @@ def check_gemm(hip, emu, dev):
         (300, 480, 128, 1160, 1), (2048, 128, 64, 1128, 1), (256, 160, 64, 1160, 1), (66000, 100, 64, 1128, 1), (4112, 1280, 1280, 1160, 1),
         (1000, 256, 328, 1128, 1),                                   # K % 64 != 0: falls back to the 128 x 128 tile
         (900, 384, 512, 5256, 1), (5000, 640, 320, 5256, 1),         # experimental: 256 x 128, 32-wide K-tiles
-        # k-step-phased ping-pong tiles (gemm_pq_kernel): 256 x 256 and 256 x 320 (wave tile 64 x 160); ragged M / N, one K-tile, split-K
-        (512, 512, 512, 2256, 1), (700, 520, 256, 2256, 1), (300, 256, 64, 2256, 1), (513, 1000, 1152, 2256, 2), (2048, 1280, 1920, 2256, 0),
+        # k-step-phased ping-pong tile (gemm_pq_kernel): 256 x 320 (wave tile 64 x 160); ragged M / N, one K-tile, split-K
         (1000, 320, 320, 2320, 1), (700, 640, 256, 2320, 1), (300, 200, 64, 2320, 1), (4096, 1280, 2560, 2320, 0), (513, 1000, 1152, 2320, 2),
         (65536, 320, 320, 2320, 1), (16384, 640, 640, 2320, 0),
     ]
@@ -91,7 +90,7 @@ def check_gemm(hip, emu, dev):
     # column statistics left by the epilogue for the consuming GroupNorm (all tile variants; with / without residual)
     for i, (M, N, K, tile) in enumerate([(256, 128, 128, 0), (4096, 320, 320, 160), (1024, 640, 1280, 128), (2048, 512, 2304, 512), (192, 72, 64, 64),
                                          (4096, 320, 320, 1160), (8192, 256, 128, 1128), (66560, 640, 192, 1160), (34816, 128, 64, 1128),
-                                         (4096, 320, 320, 2320), (2048, 512, 2304, 2256), (8192, 640, 640, 2320)]):
+                                         (4096, 320, 320, 2320), (8192, 640, 640, 2320)]):
         g = gen(60 + i, dev)
         a, b = rnd(g, M, K, dev=dev), rnd(g, N, K, scale=K ** -0.5, dev=dev)
         res = rnd(g, M, N, dev=dev) if i % 2 == 0 else None
@@ -109,7 +108,7 @@ def check_gemm(hip, emu, dev):
     out.append(("gemm gelu fp32-out t512", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32, tile=512),
                                                 emu.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32)), TOLF * 50))
     out.append(("gemm gelu", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
-    for t in (512, 1128, 1160, 2256):      # the GENERAL epilogue instantiations of the ping-pong / persistent kernels
+    for t in (512, 1128, 1160):      # the GENERAL epilogue instantiations of the ping-pong / persistent kernels
         out.append((f"gemm gelu t{t}", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True, tile=t), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
         out.append((f"gemm two-source A t{t}", rel(hip.gemm(a1, b, a2=a2, tile=t), emu.gemm(a1, b, a2=a2)), TOL1))
     c0 = rnd(g, M, N, dtype=f32, dev=dev)
@@ -164,8 +163,8 @@ def check_conv(hip, emu, dev):
         (3, 24, 24, 64, 192, CONV_S1, 24, 24, 1128, 1), (3, 16, 16, 64, 128, CONV_S2, 8, 8, 1128, 1), (2, 8, 8, 64, 160, CONV_UP2, 16, 16, 1160, 1),
         (2, 8, 8, 128, 64, CONV_S2T, 16, 16, 1128, 1), (1, 64, 64, 128, 128, 5, 32, 32, 1128, 1), (18, 64, 64, 128, 128, CONV_S1, 64, 64, 1128, 1),
         (2, 48, 40, 64, 320, CONV_S1, 48, 40, 5256, 1),
-        (4, 32, 32, 320, 320, CONV_S1, 32, 32, 2320, 1), (2, 32, 32, 128, 256, CONV_S1, 32, 32, 2256, 1), (2, 16, 16, 256, 640, CONV_S1, 16, 16, 2320, 2),
-        (3, 16, 16, 64, 320, CONV_S2, 8, 8, 2320, 1), (2, 8, 8, 64, 320, CONV_UP2, 16, 16, 2320, 1), (2, 8, 8, 128, 256, CONV_S2T, 16, 16, 2256, 1),
+        (4, 32, 32, 320, 320, CONV_S1, 32, 32, 2320, 1), (2, 16, 16, 256, 640, CONV_S1, 16, 16, 2320, 2), (2, 8, 8, 128, 320, CONV_S2T, 16, 16, 2320, 1),
+        (3, 16, 16, 64, 320, CONV_S2, 8, 8, 2320, 1), (2, 8, 8, 64, 320, CONV_UP2, 16, 16, 2320, 1),
         (16, 64, 64, 64, 320, CONV_S1, 64, 64, 2320, 1),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
@@ -475,10 +474,10 @@ def check_gemm_races(hip, emu, dev):
         want = emu.gemm(a, w)
         ref = hip.gemm(a, w, tile=128)
         out.append((f"race-check reference {M}x{N}x{K}", rel(ref, want), TOL1))
-        for code in (64, 3064, 4064, 128, 3128, 4128, 160, 3160, 4160, 1128, 1160, 5256, 512, 2256, 2320):
+        for code in (64, 3064, 4064, 128, 3128, 4128, 160, 3160, 4160, 1128, 1160, 5256, 512, 2320):
             if code % 1000 == 160 and N % 160:
                 continue
-            if code in (512, 2256) and N % 256:
+            if code == 512 and N % 256:
                 continue
             if code == 2320 and N % 320:
                 continue

@@ -46,7 +46,7 @@ for x in rows:
     if x[1] not in seen and "flags9" not in x[1]:
         seen.add(x[1]); todo.append(x)
 todo = todo[:top]
-CODES = ((0, 0), (128, 0), (160, 0), (512, 0), (512, 1), (5256, 0), (2256, 0), (2256, 1), (2320, 0), (2320, 1), (2320, 2))
+CODES = ((0, 0), (128, 0), (160, 0), (512, 0), (512, 1), (5256, 0), (2320, 0), (2320, 1))
 tot = {c: 0.0 for c in CODES}
 tot_best = tot_bestps = 0.0
 for x in todo:
@@ -77,7 +77,7 @@ for x in todo:
             continue
         if tile == 2320 and (N % 320 or K % 64):
             continue
-        if tile in (512, 2256) and (N % 256 or K % 64):
+        if tile == 512 and (N % 256 or K % 64):
             continue
         if tile in (1128, 5256) and N % 128 and N > 128:
             continue
