@@ -27,6 +27,8 @@ import torch.distributed as dist  # noqa: E402
 HOT_FLOP_PER_IMAGE = {"sd14": 2.72e12, "sd21": 7.13e12}
 STEP_FLOP_PER_IMAGE = {"sd14": 3.86e12, "sd21": 9.83e12}   # incl. frozen VAE encode + text encoder
 MFMA_PEAK = 2.5e15                                         # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
+# the newest round whose counter pass (tools/profile_round.sh) is committed under profiles/
+PROFILE_ROUND = next((r for r in ("r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_pmc_traffic.csv"))), "r03")
 HBM_PEAK = 8.0e12                                          # HBM3E spec (6.3e12 achievable), same guide
 
 
@@ -226,13 +228,13 @@ def main():
                  "geglu_fwd": "geglu_fwd_kernel", "geglu_bwd": "geglu_bwd_kernel", "adamw": "adamw_kernel"}
         # HBM bytes per launch of each kernel symbol from the TCC counters: collected offline with tools/profile_round.sh on this
         # very command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 as
-        # MI355X_MICROARCH.md prescribes; check: adamw_kernel = 28 B x parameters) -> profiles/r02_pmc_traffic.csv, whose header
-        # line names the commit it was collected at; profiles/r02_roofline_per_shape.csv breaks it down per shape.
+        # MI355X_MICROARCH.md prescribes; check: adamw_kernel = 28 B x parameters) -> profiles/rNN_pmc_traffic.csv, whose header
+        # line names the commit it was collected at; profiles/rNN_roofline_per_shape.csv breaks it down per shape.
         traffic_tab, traffic_src = {}, None
-        csv_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.csv")
+        csv_path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_traffic.csv")
         if os.path.exists(csv_path) and args.model == "sd14" and args.batch == 16:
             lines = open(csv_path).read().splitlines()
-            traffic_src = "profiles/r02_pmc_traffic.csv" + (" " + lines[0].lstrip("# ") if lines and lines[0].startswith("#") else "")
+            traffic_src = "profiles/" + PROFILE_ROUND + "_pmc_traffic.csv" + (" " + lines[0].lstrip("# ") if lines and lines[0].startswith("#") else "")
             for line in lines:
                 if line.startswith("#") or line.startswith("kernel,"):
                     continue
@@ -272,7 +274,7 @@ def main():
         dom = max(agg, key=lambda k: agg[k][2])
         roof = entry(dom)
         roof["traffic_source"] = traffic_src
-        roof["configuration"] = "in-step (ViT side stream on), events on the launch stream; same command as profiles/r02_step_kernel_stats.csv"
+        roof["configuration"] = "in-step (ViT side stream on), events on the launch stream; same command as profiles/" + PROFILE_ROUND + "_step_kernel_stats.csv"
         roof["per_kernel"] = {k: dict(tflops=v[0] / v[2] / 1e12, gbps=v[1] / v[2] / 1e9, ms_per_step=v[2] * 1e3, launches=v[3],
                                       intensity=(v[0] / v[1] if v[1] else 0.0)) for k, v in sorted(agg.items())}
         roof["step_mfma_frac_necessary"] = ips * HOT_FLOP_PER_IMAGE[args.model] / (world * MFMA_PEAK)
