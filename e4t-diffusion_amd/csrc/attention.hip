@@ -44,7 +44,26 @@ struct AttnArgs {
   float scale2;                // scale * log2(e)
   float scale;
   int causal;                  // key index > query index is masked
+  int xcd_raster;              // re-deal workgroups so one XCD owns whole (batch, head) pairs (xcd_block)
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin by linear id (x fastest), so the row blocks of one (batch, head) — which all
+// stream the SAME K and V (dK/dV kernel: the same Q and dO) — land in 8 different L2s and every operand is fetched 8 times from
+// HBM/MALL (measured r03: 3.5-4.5 x the algorithmic bytes per launch at T = 4096).  Re-deal so that each XCD owns a contiguous
+// chunk of the (block, head, batch) raster: its ~128 resident workgroups then cover ~4 whole heads whose K/V (0.66 MB a head at
+// T = 4096, dh = 40) stay in its 4 MB L2.
+struct Blk { int x, h, b; };
+__device__ __forceinline__ Blk xcd_block(int on) {
+  Blk o{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  if (!on) return o;
+  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+  const int lin = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, v = lin & 7;
+  const int lin2 = (v < r ? v * (q + 1) : r * (q + 1) + (v - r) * q) + (lin >> 3);
+  const int t = lin2 / gx;
+  o.x = lin2 - t * gx; o.b = t / gy; o.h = t - o.b * gy;
+  return o;
+}
 
 template <int DH>
 struct Cfg {
@@ -209,10 +228,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::LDE];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * C::LDE];
   const FragOff<DH> fo;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const Blk blk = xcd_block(p.xcd_raster);
+  const int b = blk.b, h = blk.h;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, hi = lane >> 5;
-  const int q = blockIdx.x * 128 + wave * 32 + li;
+  const int q = blk.x * 128 + wave * 32 + li;
   const bf16_t* Qb = p.Q + b * p.bq + h * DH;
   const bf16_t* Kb = p.K + b * p.bk + h * DH;
   const bf16_t* Vb = p.V + b * p.bv + h * DH;
@@ -345,10 +365,11 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * C::LDE];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * C::LDE];
   const FragOff<DH> fo;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const Blk blk = xcd_block(p.xcd_raster);
+  const int b = blk.b, h = blk.h;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, hi = lane >> 5;
-  const int q = blockIdx.x * 128 + wave * 32 + li;
+  const int q = blk.x * 128 + wave * 32 + li;
   const bf16_t* Kb = p.K + b * p.bk + h * DH;
   const bf16_t* Vb = p.V + b * p.bv + h * DH;
 
@@ -426,10 +447,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * C::LDE];
   const FragOff<DH> fo;
   __shared__ __attribute__((aligned(16))) float Ls[64], Dls[64];
-  const int b = blockIdx.z, h = blockIdx.y;
+  const Blk blk = xcd_block(p.xcd_raster);
+  const int b = blk.b, h = blk.h;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, hi = lane >> 5;
-  const int key = blockIdx.x * 128 + wave * 32 + li;
+  const int key = blk.x * 128 + wave * 32 + li;
   const bf16_t* Qb = p.Q + b * p.bq + h * DH;
   const bf16_t* dOb = p.dO + b * p.bo + h * DH;
 
@@ -524,6 +546,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
   store_T_acc<DH>(dkt, p.scale, p.dK + b * p.bk + h * DH, p.ldk, key, p.S, hi);
 }
 
+inline int xcd_raster_on() {                      // A/B switch: E4T_ATTN_NOXCD=1 restores the hardware's round-robin deal
+  static const int on = [] { const char* e = getenv("E4T_ATTN_NOXCD"); return (e && e[0] == '1') ? 0 : 1; }();
+  return on;
+}
+
 template <int DH>
 int launch_fwd(const AttnArgs& p, int Bn, hipStream_t st) {
   // algorithmic bytes: Q, K, V read once, O written once (bf16) + the fp32 log-sum-exp
@@ -582,7 +609,7 @@ extern "C" int e4t_attention_fwd(const void* Q, const void* K, const void* V, vo
   memset(&p, 0, sizeof(p));
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.Out = (bf16_t*)O; p.L = lse;
   p.T = T; p.S = S; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.bq = bq; p.bk = bk; p.bv = bv; p.bo = bo;
-  p.scale = scale; p.scale2 = scale * 1.4426950408889634f; p.causal = causal;
+  p.scale = scale; p.scale2 = scale * 1.4426950408889634f; p.causal = causal; p.xcd_raster = xcd_raster_on();
   hipStream_t st = (hipStream_t)stream;
   switch (DH) {
     case 32: return launch_fwd<32>(p, Bn, st);
@@ -604,7 +631,7 @@ extern "C" int e4t_attention_bwd(const void* Q, const void* K, const void* V, co
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (const bf16_t*)O; p.dO = (const bf16_t*)dO;
   p.L = (float*)lse; p.Delta = delta_ws; p.dQ = (bf16_t*)dQ; p.dK = (bf16_t*)dK; p.dV = (bf16_t*)dV;
   p.T = T; p.S = S; p.H = H; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.bq = bq; p.bk = bk; p.bv = bv; p.bo = bo;
-  p.scale = scale; p.scale2 = scale * 1.4426950408889634f; p.causal = causal;
+  p.scale = scale; p.scale2 = scale * 1.4426950408889634f; p.causal = causal; p.xcd_raster = xcd_raster_on();
   hipStream_t st = (hipStream_t)stream;
   switch (DH) {
     case 32: return launch_bwd<32>(p, Bn, st);

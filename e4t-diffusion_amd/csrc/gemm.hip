@@ -217,7 +217,7 @@ __device__ unsigned long long g_dma_trace[128 * 16];
 // (48 KiB) instead of 1 (32 KiB) in flight per workgroup.  The cycle-stamp trace (tools/dma_trace.sh) shows the K loop of every
 // shape waiting ~1700-2500 cycles per 64-wide tile for a DMA issued one iteration earlier against ~500 cycles of MFMA work.
 template <int BM, int BN, int WGM, int WGN, int MODE, int NSTAGE, bool GENERAL = false, int KT = 64>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : 1) void gemm_dma_kernel(GemmArgs p) {
 #ifdef DMA_TRACE
   const int dt_lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int dt_wg = dt_lin >> 3;
@@ -267,7 +267,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
   // (dense), the ragged last tile — plus a wave-uniform SGPR offset that walks K (+128 B per K-tile).  Issuing a tile costs
   // no VALU at all (a per-tile 64-bit address recomputation cost ~1.2k issue cycles per wave, carried 64-bit pointers still
   // 3 VALU each), and out-of-range rows / conv padding / K tails carry an out-of-range offset: the hardware returns zeros.
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  const bool cm = MODE != 0 && p.chan_major;          // channel-chunk-major K order (gemm_common.h, cm_step)
+  const __amdgpu_buffer_rsrc_t rs_a = cm ? cm_rsrc(p) : __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFF0000u;          // >= every extent the launcher accepts
@@ -361,10 +362,29 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma_kernel(GemmArgs p) {
       b_vo[i] = ok ? b_row[i] : OOB;
     }
   };
-  auto issue_tile = [&](int kt, bf16_t* buf) {
+  if (cm) {                        // a_vo = the output position's own pixel (all taps), a_oy = 9-bit tap validity mask
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      a_vo[i] = cm_center(p, a_base[i], a_oy[i], a_ox[i], a_kc[i]);
+      a_oy[i] = cm_mask(p, a_ok[i], a_oy[i], a_ox[i]);
+    }
+  }
+  auto issue_tile = [&](int kt, bf16_t* buf) __attribute__((always_inline)) {
     const int k0 = kt * KT;
     bf16_t* As = buf;
     bf16_t* Bs = buf + BM * KT;
+    if (cm) {                      // whole K-tiles only (Cin % KT == 0): no ragged tile
+      const CmStep s = cm_step(p, kt, KT, 0);
+      if (kt == kt_begin) place_b(k0);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        buf_dma16(rs_a, ((a_oy[i] >> s.tap) & 1) ? a_vo[i] : OOB, s.a_so, As + (wave * NA + i) * 512);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if ((BN / RPP) % NW == 0 || wave * NB + i < BN / RPP)
+          buf_dma16(rs_b, b_vo[i], s.b_so, Bs + (wave * NB + i) * 512);
+      return;
+    }
     const bool ragged = k0 + KT > p.K;                                      // wave-uniform conditions
     const bool fresh_a = kt == kt_begin || ragged || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0);
     if (fresh_a) place_a(k0);
@@ -567,7 +587,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   // when the conv tap / concat source changes, plus a wave-uniform SGPR offset that walks K (+64 B per quarter).  Issuing a
   // quarter costs no VALU at all, and out-of-range rows / conv padding simply carry an out-of-range offset (the hardware
   // returns zeros) instead of a redirected pointer.
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  const bool cm = MODE != 0 && p.chan_major;          // channel-chunk-major K order (gemm_common.h, cm_step)
+  const __amdgpu_buffer_rsrc_t rs_a = cm ? cm_rsrc(p) : __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFF0000u;          // >= every extent the launcher accepts
@@ -598,6 +619,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     b_vo[j] = gn < p.N ? (unsigned)(((size_t)gn * p.ldb + kc) * 2) : OOB;
   }
   unsigned a_vo[2];
+  if (cm) {                        // a_vo = the output position's own pixel (all taps), a_oy = 9-bit tap validity mask
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      a_vo[j] = cm_center(p, a_base[j], a_oy[j], a_ox[j], a_kc[j]);
+      a_oy[j] = cm_mask(p, a_ok[j], a_oy[j], a_ox[j]);
+    }
+  }
   int a_so = 0, b_so = 0;          // wave-uniform byte offsets along K
   bool a_second = false;           // reading the second concat source
   auto place_a = [&](int k0) {
@@ -641,7 +669,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     }
   };
   // The A and B streams are each issued in increasing k (lo(t), hi(t), lo(t+1), ...): +64 bytes on the scalar offset per quarter.
-  auto issue_a = [&](int kt, bool hi, bf16_t* dst) {
+  auto issue_a = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
+    if (cm) {
+      const CmStep s = cm_step(p, kt, BK, hi ? HK : 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        buf_dma16(rs_a, ((a_oy[j] >> s.tap) & 1) ? a_vo[j] : OOB, s.a_so, dst + (wave * 32 + j * 16) * HK);
+      return;
+    }
     const int k0 = kt * BK;
     const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
     if (fresh) place_a(k0);
@@ -650,8 +685,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     for (int j = 0; j < 2; ++j)
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 32 + j * 16) * HK);
   };
-  auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
-    if (!hi && kt == kt_begin) b_so = kt * BK * 2;
+  auto issue_b = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
+    if (cm) b_so = cm_step(p, kt, BK, hi ? HK : 0).b_so;
+    else if (!hi && kt == kt_begin) b_so = kt * BK * 2;
     else b_so += HK * 2;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -829,7 +865,8 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nkt) kt_end = nkt;
 
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  const bool cm = MODE != 0 && p.chan_major;          // channel-chunk-major K order (gemm_common.h, cm_step)
+  const __amdgpu_buffer_rsrc_t rs_a = cm ? cm_rsrc(p) : __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFF0000u;
@@ -864,6 +901,13 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
     b_vo[j] = (r < BN && gn < p.N) ? (unsigned)(((size_t)gn * p.ldb + kc) * 2) : OOB;
   }
   unsigned a_vo[2];
+  if (cm) {                        // a_vo = the output position's own pixel (all taps), a_oy = 9-bit tap validity mask
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      a_vo[j] = cm_center(p, a_base[j], a_oy[j], a_ox[j], a_kc[j]);
+      a_oy[j] = cm_mask(p, a_ok[j], a_oy[j], a_ox[j]);
+    }
+  }
   int a_so = 0, b_so = 0;
   bool a_second = false;
   auto place_a = [&](int k0) {
@@ -907,7 +951,14 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
     }
   };
   // the A and B streams are each issued in increasing k: lo(t), hi(t), lo(t+1), ...
-  auto issue_a = [&](int kt, bool hi, bf16_t* dst) {
+  auto issue_a = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
+    if (cm) {
+      const CmStep s = cm_step(p, kt, BK, hi ? HK : 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        buf_dma16(rs_a, ((a_oy[j] >> s.tap) & 1) ? a_vo[j] : OOB, s.a_so, dst + (wave * 32 + j * 16) * HK);
+      return;
+    }
     const int k0 = kt * BK;
     const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
     if (fresh) place_a(k0);
@@ -916,8 +967,9 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
     for (int j = 0; j < 2; ++j)
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 32 + j * 16) * HK);
   };
-  auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
-    if (!hi && kt == kt_begin) b_so = kt * BK * 2;
+  auto issue_b = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
+    if (cm) b_so = cm_step(p, kt, BK, hi ? HK : 0).b_so;
+    else if (!hi && kt == kt_begin) b_so = kt * BK * 2;
     else b_so += HK * 2;
 #pragma unroll
     for (int j = 0; j < NBJ; ++j)
@@ -1149,7 +1201,7 @@ __global__ __launch_bounds__(512) void gemm_pt_kernel(GemmArgs p) {
       }
     }
   };
-  auto issue_a = [&](int kt, bool hi, bf16_t* dst) {
+  auto issue_a = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
     const int k0 = kt * BK;
     const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
     if (fresh) place_a(k0);
@@ -1158,7 +1210,7 @@ __global__ __launch_bounds__(512) void gemm_pt_kernel(GemmArgs p) {
     for (int j = 0; j < 4; ++j)
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 64 + j * 16) * HK);
   };
-  auto issue_b = [&](int kt, bool hi, bf16_t* dst) {
+  auto issue_b = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
     if (!hi && kt == kt_begin) b_so = kt * BK * 2;
     else b_so += HK * 2;
     buf_dma16(rs_b, b_vo, b_so, dst + (wave * 16) * HK);
@@ -1323,7 +1375,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
     b_col[i] = b_col_ok ? (unsigned)(((size_t)r * p.ldb + n0 + lchunk * 8) * 2) : OOB;
   }
   int a_so = 0, b_so = 0;
-  auto issue_tile = [&](int kt, bf16_t* buf) {
+  auto issue_tile = [&](int kt, bf16_t* buf) __attribute__((always_inline)) {
     if (kt == kt_begin || (kt + 1) * BK > p.K) {          // first tile, or the ragged last one: mask the rows beyond K
       a_so = kt * BK * p.lda * 2; b_so = kt * BK * p.ldb * 2;
 #pragma unroll
@@ -1651,6 +1703,10 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   int splitk = pl.splitk;
   p.ktiles_per_split = pl.ktiles_per_split;
   p.a_bytes = pl.a_bytes; p.a2_bytes = pl.a2_bytes; p.b_bytes = pl.b_bytes;
+  // stride-1 3x3 convs walk K channel-chunk-major (gemm_common.h, cm_step) in every DMA kernel; A/B switch: E4T_CONV_TAPMAJOR=1
+  static const bool tap_major = getenv("E4T_CONV_TAPMAJOR") != nullptr && getenv("E4T_CONV_TAPMAJOR")[0] == '1';
+  p.chan_major = conv && !tap_major && buf_ok && p.mode == E4T_CONV_S1 && p.Cin % BK == 0 && p.K == 9 * p.Cin && batch == 1 &&
+                 (unsigned long long)p.a_bytes + (unsigned long long)(p.Win + 1) * p.Cin * 2 < 0xFFFF0000ull;
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   (void)allow256;
   const bool need_ws = splitk > 1 || p.reduce_batch;

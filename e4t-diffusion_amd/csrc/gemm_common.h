@@ -37,6 +37,7 @@ struct GemmArgs {
   int fast_epi;     // bf16 C, 16-byte aligned rows: LDS-staged vectorised epilogue
   int fast_f32;     // fp32 C (+ fp32 residual), no accumulate, no row bias: direct line-wide stores from the accumulator layout
   int ps_pre;       // persistent kernel: bias / row bias prefetched into LDS by DMA (write_tile<..., PRE>)
+  int chan_major;   // stride-1 3x3 conv: K walked channel-chunk-major (cm_step) instead of tap-major
   long long strideA, strideB, strideC, strideBias;
   float* colstats;                       // optional [M/32][N][2] column statistics of the output (fast bf16 epilogue only)
   unsigned a_bytes, a2_bytes, b_bytes;   // operand extents from the (batch-adjusted) base pointers, for buffer resources (pp kernel)
@@ -320,6 +321,47 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int GM) {
   const int first = grp * GM, gsz = min(gy - first, GM);
   bx = l / gsz;
   by = first + (l - bx * gsz);
+}
+
+// ---- channel-chunk-major K order for stride-1 3x3 convolutions (GemmArgs::chan_major) ---------------------------------------
+// K = 9 taps x Cin.  Walked tap-major, every input pixel is read 9 times at a reuse distance of one whole tap panel per resident
+// workgroup (256 rows x Cin x 2 B x 32 workgroups per XCD = 5-10 MB against a 4 MB L2): measured (profiles/r03_roofline_per_shape
+// .csv) the 3x3 convs fetched 3.6-5.2 x their algorithmic bytes from beyond L2.  Walked channel-chunk-major — K-tile kt = (chunk
+// kt / 9, tap kt % 9) — the 9 shifted reads of one chunk are adjacent in time (reuse distance: one K-tile per workgroup).  B is
+// addressed by the same (tap, chunk), so the product only changes its fp32 summation order.  For stride 1 the tap shift is
+// wave-uniform ((ky * Win + kx) * Cin elements from the pixel up-left of the output position) and goes into the SCALAR offset:
+// the buffer base is lowered by one image row + one pixel (those bytes are never touched: lanes whose tap falls into the padding
+// carry the out-of-range offset), the per-lane offset is the output position's own pixel for all 9 taps, and the only per-lane
+// work per K-tile is picking that offset or the out-of-range one from a 9-bit validity mask.
+struct CmStep { int a_so, b_so, tap; };
+__device__ __forceinline__ CmStep cm_step(const GemmArgs& p, int kt, int ktw, int sub) {      // kt counts ktw-wide K-tiles
+  const int c = kt / 9, tap = kt - 9 * c;
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  const int ch = c * ktw + sub;
+  CmStep o;
+  o.tap = tap;
+  o.a_so = ((ky * p.Win + kx) * p.Cin + ch) * 2;
+  o.b_so = (tap * p.Cin + ch) * 2;
+  return o;
+}
+__device__ __forceinline__ int cm_mask(const GemmArgs& p, bool ok, int oy, int ox) {
+  int m = 0;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = oy + ky - 1, ix = ox + kx - 1;
+      if (ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) m |= 1 << (ky * 3 + kx);
+    }
+  return m;
+}
+__device__ __forceinline__ unsigned cm_center(const GemmArgs& p, long long img_px, int oy, int ox, int kc) {
+  return (unsigned)(((img_px + (long long)oy * p.Win + ox) * p.Cin + kc) * 2);
+}
+__device__ __forceinline__ unsigned cm_shift_bytes(const GemmArgs& p) { return (unsigned)((p.Win + 1) * p.Cin * 2); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cm_rsrc(const GemmArgs& p) {
+  const unsigned sh = cm_shift_bytes(p);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - sh), 0, (int)(p.a_bytes + sh), 0x00020000);
 }
 
 template <int N>
