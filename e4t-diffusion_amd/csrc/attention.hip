@@ -25,6 +25,7 @@
 #include "common.h"
 #include "../../include/e4t_hip.h"
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -86,7 +87,60 @@ union Frag {
   uint32_t w[4];
 };
 
+// max / sum of a value with its partner lane in the other half of the wave (lane ^ 32) as ONE VALU lane swap (gfx950
+// v_permlane32_swap) instead of a ds_bpermute round trip through the LDS crossbar: the softmax row max sits at the head of the
+// per-sub-tile dependency chain, and a bpermute there also drains every LDS read issued before it (lgkmcnt is in-order), which
+// would defeat the fragment prefetch below.  (The clang builtin folds away its second result, hence inline asm; the s_nops
+// cover the VALU-write -> permlane-read and permlane-write -> VALU-read hazards the compiler cannot see inside the asm.)
+#ifndef ATTN_FWD_PREFETCH
+#define ATTN_FWD_PREFETCH 0      // measured neutral (667 -> 658 us at dh 40): the SIMD serialises instruction cycles, not latency
+#endif
+#ifndef ATTN_PERMLANE
+#define ATTN_PERMLANE 1
+#endif
+__device__ __forceinline__ float xhalf_max(float v) {
+  if (!ATTN_PERMLANE) return fmaxf(v, __shfl_xor(v, 32, 64));
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+  return a;
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  if (!ATTN_PERMLANE) return v + __shfl_xor(v, 32, 64);
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_add_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+  return a;
+}
+
+// tools/probe/attn_probe.hip compiles timing variants of the forward kernel (results are wrong in every variant but 0):
+//   1 v_exp_f32 replaced by the plain fma   2 no softmax VALU at all   3 MFMAs replaced by one VALU add   4 no tile staging
+//   5 no LDS fragment reads (operands made up in registers)   6 = 4 + 5   7 = 5 + 2   8 = 5 + 3
+#ifndef ATTN_PROBE
+#define ATTN_PROBE 0
+#endif
+__device__ __forceinline__ f32x16 probe_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if (ATTN_PROBE == 3 || ATTN_PROBE == 8) {
+    Frag fa, fb;
+    fa.v = a; fb.v = b;
+    c[0] += __builtin_bit_cast(float, fa.w[0] ^ fb.w[1]);
+    return c;
+  }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// The softmax arithmetic of two adjacent score elements per instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32): the kernels
+// are bound by VALU issue slots, and a wave64 VALU instruction costs its SIMD ~4.5 clk packed or not (tools/probe/mfma_rate.hip).
+// Same IEEE operations as the scalar form (s * scale2 - m contracts to one fma either way): results are bit-identical.
+#ifndef ATTN_DKV_FOLD
+#define ATTN_DKV_FOLD 1
+#endif
+#ifndef ATTN_PACKED
+#define ATTN_PACKED 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // element offset of the logical 16-byte slot L of tile row r in a swizzled LDS image (see Cfg)
 template <int LDE>
@@ -185,10 +239,12 @@ struct FragOff {
 };
 template <int DH>
 __device__ __forceinline__ bf16x8 load_row_frag(const bf16_t* img, const FragOff<DH>& f, int sub, int ks) {
+  if (ATTN_PROBE >= 5) { Frag t; t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0x3C003C00u + threadIdx.x + sub + ks; return t.v; }
   return *(const bf16x8*)(img + sub * 32 * Cfg<DH>::LDE + f.row[ks]);
 }
 template <int DH>
 __device__ __forceinline__ bf16x8 load_T_frag(const bf16_t* img, const FragOff<DH>& f, int dt, int sub, int k2) {
+  if (ATTN_PROBE >= 5) { Frag t; t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0x3C003C00u + threadIdx.x + sub + k2 + dt; return t.v; }
   const bf16_t* b = img + (sub * 32 + k2 * 16) * Cfg<DH>::LDE;
   return tr_frag(b + f.tr_lo[dt], b + f.tr_hi[dt]);
 }
@@ -246,6 +302,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m = -INFINITY, l = 0.f;
+  constexpr bool PREFETCH = DH <= 48 && ATTN_FWD_PREFETCH;      // (dh 64 would spill at four workgroups per CU)
   constexpr bool SUM_BY_MFMA = C::DV > DH && DH % 8 == 0;      // a spare O^T row (d = DH) exists: it accumulates sum_k p
 
   TileRegs<DH> kr, vr;
@@ -259,6 +316,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
     if (threadIdx.x < 64) *(uint4*)(Vs + img_off<C::LDE>(threadIdx.x, C::NCH)) = make_uint4(0x3F80u, 0, 0, 0);
   }
   for (int kv0 = 0; kv0 < p.S; kv0 += 64) {
+    if ((ATTN_PROBE != 4 && ATTN_PROBE != 6) || kv0 == 0) {
     __syncthreads();                       // everyone finished reading the previous tile
     kr.store_rows(Ks);
     vr.store_rows(Vs);
@@ -267,14 +325,38 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
       kr.load(rsK, kv0 + 64);
       vr.load(rsV, kv0 + 64);
     }
+    }
     const int nsub = (p.S - kv0 > 32) ? 2 : 1;
-    for (int sub = 0; sub < nsub; ++sub) {
+    // PREFETCH (dh <= 48): every LDS fragment is requested one phase before the MFMA that consumes it — this sub-tile's V^T
+    // fragments and the next sub-tile's K fragments are issued in front of the softmax VALU block and land underneath it
+    // (measured with tools/probe/attn_probe.hip: with the fragment reads taken out the dh = 40 forward drops 667 -> 464 us, i.e.
+    // a third of the kernel was exposed LDS latency — the compiler had sunk each ds_read to just above its MFMA).
+    bf16x8 kfr[C::NKS];
+    if (PREFETCH) {
+#pragma unroll
+      for (int ks = 0; ks < C::NKS; ++ks) kfr[ks] = load_row_frag<DH>(Ks, fo, 0, ks);
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      if (sub >= nsub) break;
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < C::NKS; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(Ks, fo, sub, ks), qf[ks], s, 0, 0, 0);
+        s = probe_mfma(PREFETCH ? kfr[ks] : load_row_frag<DH>(Ks, fo, sub, ks), qf[ks], s);
+      }
+      bf16x8 vfr[C::NDT][2];
+      if (PREFETCH) {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int dt = 0; dt < C::NDT; ++dt) vfr[dt][k2] = load_T_frag<DH>(Vs, fo, dt, sub, k2);
+        if (sub == 0 && nsub > 1) {
+#pragma unroll
+          for (int ks = 0; ks < C::NKS; ++ks) kfr[ks] = load_row_frag<DH>(Ks, fo, 1, ks);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       // Softmax bookkeeping is VALU work on a VALU-bound kernel (PMC: ~18 VALU instructions per MFMA), so it is kept minimal:
       //  * the row max is taken on the raw scores and the scale folded into the exp argument (one fma per element);
@@ -293,10 +375,12 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
           s[r] = (key < p.S && (!p.causal || key <= q)) ? s[r] : -INFINITY;
         }
       }
+      if (ATTN_PROBE != 2 && ATTN_PROBE != 7) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale2;         // scale2 > 0
-      if (__builtin_amdgcn_ballot_w64(mx > m + 8.f) != 0) {
+      mx = xhalf_max(mx) * p.scale2;         // scale2 > 0
+      }
+      if (ATTN_PROBE != 2 && ATTN_PROBE != 7 && __builtin_amdgcn_ballot_w64(mx > m + 8.f) != 0) {
         const float mn = fmaxf(m, mx);
         const float alpha = fast_exp2(m - mn);
         m = mn;
@@ -307,18 +391,34 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pr[r] = fast_exp2(s[r] * p.scale2 - m);
+      for (int r = 0; r < 16; r += 2) {
+        if (ATTN_PACKED && ATTN_PROBE == 0) {
+          const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-m, -m});
+          pr[r] = fast_exp2(t.x); pr[r + 1] = fast_exp2(t.y);
+        } else {
+#pragma unroll
+          for (int e = r; e < r + 2; ++e) pr[e] = (ATTN_PROBE == 2 || ATTN_PROBE == 7) ? s[e] : ATTN_PROBE == 1 ? s[e] * p.scale2 - m : fast_exp2(s[e] * p.scale2 - m);
+        }
+      }
       if (!SUM_BY_MFMA) {
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) rs += pr[r];
-        l += rs + __shfl_xor(rs, 32, 64);
+        l += xhalf_sum(rs);
       }
       const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);
+      if (PREFETCH) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int dt = 0; dt < C::NDT; ++dt) {
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Vs, fo, dt, sub, 0), pf0, o[dt], 0, 0, 0);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Vs, fo, dt, sub, 1), pf1, o[dt], 0, 0, 0);
+        for (int k2 = 0; k2 < 2; ++k2)             // k-step outer: neighbouring MFMAs accumulate into different O^T blocks
+#pragma unroll
+          for (int dt = 0; dt < C::NDT; ++dt) o[dt] = probe_mfma(vfr[dt][k2], k2 ? pf1 : pf0, o[dt]);
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) {
+          o[dt] = probe_mfma(load_T_frag<DH>(Vs, fo, dt, sub, 0), pf0, o[dt]);
+          o[dt] = probe_mfma(load_T_frag<DH>(Vs, fo, dt, sub, 1), pf1, o[dt]);
+        }
       }
     }
   }
@@ -403,7 +503,10 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
       vr.load(rsV, kv0 + 64);
     }
     const int nsub = (p.S - kv0 > 32) ? 2 : 1;
-    for (int sub = 0; sub < nsub; ++sub) {
+    // one 32-row sub-tile; at dh <= 48 the two sub-tiles are separate instantiations (fragment addresses become immediates,
+    // no per-read address VALU), larger head dims keep the runtime loop (the unrolled form would spill)
+    auto sub_tile = [&](auto sub_) __attribute__((always_inline)) {
+      const int sub = sub_;
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -422,7 +525,17 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(s[r] * p.scale2 - Lq) * (dp[r] - Dq);
+        for (int r = 0; r < 16; r += 2) {
+          if (ATTN_PACKED && DH <= 48) {      // (dh 64 would spill)
+            const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-Lq, -Lq});
+            const f32x2 d = pk_fma(f32x2{Dq, Dq}, f32x2{-1.f, -1.f}, f32x2{dp[r], dp[r + 1]});      // dp - Dq, kept packed
+            const f32x2 o2 = f32x2{fast_exp2(t.x), fast_exp2(t.y)} * d;
+            ds[r] = o2.x; ds[r + 1] = o2.y;
+          } else {
+            ds[r] = fast_exp2(s[r] * p.scale2 - Lq) * (dp[r] - Dq);
+            ds[r + 1] = fast_exp2(s[r + 1] * p.scale2 - Lq) * (dp[r + 1] - Dq);
+          }
+        }
       }
       const bf16x8 f0 = pack_acc(ds, 0), f1 = pack_acc(ds, 1);
 #pragma unroll
@@ -430,6 +543,13 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Ks, fo, dt, sub, 0), f0, acc[dt], 0, 0, 0);
         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Ks, fo, dt, sub, 1), f1, acc[dt], 0, 0, 0);
       }
+    };
+    if constexpr (DH <= 48) {
+      sub_tile(std::integral_constant<int, 0>{});
+      if (nsub > 1) sub_tile(std::integral_constant<int, 1>{});
+    } else {
+#pragma unroll 1
+      for (int sub = 0; sub < nsub; ++sub) sub_tile(sub);
     }
   }
   store_T_acc<DH>(acc, p.scale, p.dQ + b * p.bq + h * DH, p.ldq, q, p.T, hi);
@@ -458,6 +578,19 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
   bf16x8 kf[C::NKS], vf[C::NKS];
   load_row_frags<DH>(p.K + b * p.bk + h * DH, p.ldk, key, p.S, hi, kf);
   load_row_frags<DH>(p.V + b * p.bv + h * DH, p.ldv, key, p.S, hi, vf);
+  // FOLD (head dims with >= 3 spare contraction slots: 40 -> 48): the per-query terms ride in the padding of the two score
+  // GEMMs.  The Q image carries -L/scale2 split into three bf16 pieces (24 bits) in columns DH..DH+2 and the K fragment holds
+  // ones there, so S'^T = K.Q^T - L/scale2 comes out of the MFMA and p = exp2(scale2 * S'); likewise dO carries -Delta against
+  // ones in the V fragment, so the MFMA yields dP - Delta.  That removes 8 ds_read_b128 of L / Delta (1 KB of VGPR return each,
+  // broadcast or not) and 16 subtractions per 32 x 32 sub-tile from a kernel bound by VALU issue + LDS return bandwidth
+  // (tools/probe/mfma_rate.hip, attn_probe.hip).  The transposed reads of those image columns land in accumulator rows
+  // d = DH..DH+2 of dK^T / dV^T, which are never stored.
+  constexpr bool FOLD = ATTN_DKV_FOLD && C::DK - DH >= 3 && DH % 8 == 0;
+  if (FOLD && hi == (DH % 16) / 8) {
+    Frag t;
+    t.v = kf[DH / 16]; t.w[0] = 0x3F803F80u; t.w[1] = 0x00003F80u; kf[DH / 16] = t.v;
+    t.v = vf[DH / 16]; t.w[0] = 0x3F803F80u; t.w[1] = 0x00003F80u; vf[DH / 16] = t.v;
+  }
 
   f32x16 dvt[C::NDT], dkt[C::NDT];
 #pragma unroll
@@ -485,6 +618,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
   zero_pad_cols<DH>(Qs);
   zero_pad_cols<DH>(dOs);
+  const float inv_scale2 = 1.f / p.scale2;
   for (int q0 = 0; q0 < p.T; q0 += 64) {
     if (!PF) {
       qr.load(rsQ, q0);
@@ -494,7 +628,22 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
     __syncthreads();
     qr.store_rows(Qs);
     dor.store_rows(dOs);
-    if (threadIdx.x < 64) { Ls[threadIdx.x] = l_next; Dls[threadIdx.x] = d_next; }
+    if (threadIdx.x < 64) {
+      if (FOLD) {
+        auto split3 = [](float x) {          // x ~ hi + mid + lo, each a bf16
+          const bf16_t h0 = f2bf(x);
+          const float r1 = x - bf2f(h0);
+          const bf16_t h1 = f2bf(r1);
+          const bf16_t h2 = f2bf(r1 - bf2f(h1));
+          return make_uint4((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2, 0u, 0u);
+        };
+        // a query row beyond T has L = +inf: a large finite value keeps the pieces finite and still gives p = exp2(-huge) = 0
+        *(uint4*)(Qs + img_off<C::LDE>(threadIdx.x, C::NCH)) = split3(fmaxf(-l_next * inv_scale2, -1e30f));
+        *(uint4*)(dOs + img_off<C::LDE>(threadIdx.x, C::NCH)) = split3(-d_next);
+      } else {
+        Ls[threadIdx.x] = l_next; Dls[threadIdx.x] = d_next;
+      }
+    }
     __syncthreads();
     if (PF && q0 + 64 < p.T) {
       qr.load(rsQ, q0 + 64);
@@ -502,28 +651,51 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
       load_stats(q0 + 64);
     }
     const int nsub = (p.T - q0 > 32) ? 2 : 1;
-    for (int sub = 0; sub < nsub; ++sub) {
+    // one 32-row sub-tile; at dh <= 48 the two sub-tiles are separate instantiations (fragment addresses become immediates,
+    // no per-read address VALU), larger head dims keep the runtime loop (the unrolled form would spill)
+    auto sub_tile = [&](auto sub_) __attribute__((always_inline)) {
+      const int sub = sub_;
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < C::NKS; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(Qs, fo, sub, ks), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_row_frag<DH>(dOs, fo, sub, ks), vf[ks], dp, 0, 0, 0);
+        s = probe_mfma(load_row_frag<DH>(Qs, fo, sub, ks), kf[ks], s);
+        dp = probe_mfma(load_row_frag<DH>(dOs, fo, sub, ks), vf[ks], dp);
       }
       // No masks: a query row beyond T carries L = +inf (-> p = 0 exactly, dO row = 0 keeps dp finite), and a key lane
       // beyond S only pollutes its own accumulator column, which is never stored.
       float pr[16], ds[16];
+      if (FOLD && ATTN_PROBE == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 t = f32x2{s[r], s[r + 1]} * f32x2{p.scale2, p.scale2};
+          const f32x2 e2 = f32x2{fast_exp2(t.x), fast_exp2(t.y)};
+          const f32x2 o2 = e2 * f32x2{dp[r], dp[r + 1]};
+          pr[r] = e2.x; pr[r + 1] = e2.y; ds[r] = o2.x; ds[r + 1] = o2.y;
+        }
+      } else
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 l4 = *(const float4*)(Ls + sub * 32 + 8 * g + 4 * hi);     // acc rows 4g..4g+3 = 4 consecutive queries
         const float4 d4 = *(const float4*)(Dls + sub * 32 + 8 * g + 4 * hi);
         const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; j += 2) {
           const int r = 4 * g + j;
-          pr[r] = fast_exp2(s[r] * p.scale2 - lq[j]);
-          ds[r] = pr[r] * (dp[r] - dq[j]);
+          if (ATTN_PACKED && ATTN_PROBE == 0) {
+            const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-lq[j], -lq[j + 1]});
+            const f32x2 d = pk_fma(f32x2{dq[j], dq[j + 1]}, f32x2{-1.f, -1.f}, f32x2{dp[r], dp[r + 1]});      // dp - dq, kept packed
+            const f32x2 e2 = f32x2{fast_exp2(t.x), fast_exp2(t.y)};
+            const f32x2 o2 = e2 * d;
+            pr[r] = e2.x; pr[r + 1] = e2.y; ds[r] = o2.x; ds[r + 1] = o2.y;
+          } else {
+#pragma unroll
+            for (int e = r; e < r + 2; ++e) {
+              pr[e] = (ATTN_PROBE == 2 || ATTN_PROBE == 7) ? s[e] : ATTN_PROBE == 1 ? s[e] * p.scale2 - lq[e - 4 * g] : fast_exp2(s[e] * p.scale2 - lq[e - 4 * g]);
+              ds[e] = (ATTN_PROBE == 2 || ATTN_PROBE == 7) ? dp[e] : pr[e] * (dp[e] - dq[e - 4 * g]);
+            }
+          }
         }
       }
       if (p.causal) {                      // (CLIP text encoder only; kept out of the unmasked loop above)
@@ -535,11 +707,18 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
       const bf16x8 sf0 = pack_acc(ds, 0), sf1 = pack_acc(ds, 1);
 #pragma unroll
       for (int dt = 0; dt < C::NDT; ++dt) {
-        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(dOs, fo, dt, sub, 0), pf0, dvt[dt], 0, 0, 0);
-        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(dOs, fo, dt, sub, 1), pf1, dvt[dt], 0, 0, 0);
-        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Qs, fo, dt, sub, 0), sf0, dkt[dt], 0, 0, 0);
-        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_T_frag<DH>(Qs, fo, dt, sub, 1), sf1, dkt[dt], 0, 0, 0);
+        dvt[dt] = probe_mfma(load_T_frag<DH>(dOs, fo, dt, sub, 0), pf0, dvt[dt]);
+        dvt[dt] = probe_mfma(load_T_frag<DH>(dOs, fo, dt, sub, 1), pf1, dvt[dt]);
+        dkt[dt] = probe_mfma(load_T_frag<DH>(Qs, fo, dt, sub, 0), sf0, dkt[dt]);
+        dkt[dt] = probe_mfma(load_T_frag<DH>(Qs, fo, dt, sub, 1), sf1, dkt[dt]);
       }
+    };
+    if constexpr (DH <= 48) {
+      sub_tile(std::integral_constant<int, 0>{});
+      if (nsub > 1) sub_tile(std::integral_constant<int, 1>{});
+    } else {
+#pragma unroll 1
+      for (int sub = 0; sub < nsub; ++sub) sub_tile(sub);
     }
   }
   store_T_acc<DH>(dvt, 1.f, p.dV + b * p.bv + h * DH, p.ldv, key, p.S, hi);
@@ -556,7 +735,8 @@ int launch_fwd(const AttnArgs& p, int Bn, hipStream_t st) {
   // algorithmic bytes: Q, K, V read once, O written once (bf16) + the fp32 log-sum-exp
   E4T_LOG_LAUNCH("attn_fwd_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
                  2.0 * Bn * p.H * DH * (2.0 * p.T + 2.0 * p.S) + 4.0 * Bn * p.H * p.T, 4.0 * Bn * p.H * (double)p.T * p.S * DH);
-  hipLaunchKernelGGL((attn_fwd_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
+  static const int probe_lds = (ATTN_PROBE >= 0 && getenv("E4T_ATTN_PROBE_LDS")) ? atoi(getenv("E4T_ATTN_PROBE_LDS")) : 0;   // occupancy probe: extra dynamic LDS bytes
+  hipLaunchKernelGGL((attn_fwd_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), probe_lds, st, p);
   E4T_CHECK_LAUNCH("attn_fwd_kernel");
   return 0;
 }
