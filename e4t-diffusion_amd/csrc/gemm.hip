@@ -362,27 +362,31 @@ __global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : 1) vo
       b_vo[i] = ok ? b_row[i] : OOB;
     }
   };
-  if (cm) {                        // a_vo = the output position's own pixel (all taps), a_oy = 9-bit tap validity mask
+  if (cm) {                        // a_vo = the output position's own pixel (all taps), a_oy = inverted 9-bit tap validity mask
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       a_vo[i] = cm_center(p, a_base[i], a_oy[i], a_ox[i], a_kc[i]);
-      a_oy[i] = cm_mask(p, a_ok[i], a_oy[i], a_ox[i]);
+      a_oy[i] = cm_inv_mask(p, a_ok[i], a_oy[i], a_ox[i]);
     }
   }
+  CmWalk wk;                       // cm: (tap, chunk) of the next K-tile to issue
+  wk.init(kt_begin, KT);
+  const int cm_table = cm ? cm_tap_table(p, lane) : 0;
   auto issue_tile = [&](int kt, bf16_t* buf) __attribute__((always_inline)) {
     const int k0 = kt * KT;
     bf16_t* As = buf;
     bf16_t* Bs = buf + BM * KT;
-    if (cm) {                      // whole K-tiles only (Cin % KT == 0): no ragged tile
-      const CmStep s = cm_step(p, kt, KT, 0);
+    if (cm) {                      // whole K-tiles only (Cin % KT == 0): no ragged tile; tiles are issued in increasing kt
       if (kt == kt_begin) place_b(k0);
+      const int aso = cm_a_so(cm_table, wk), bso = cm_b_so(p, wk);
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        buf_dma16(rs_a, ((a_oy[i] >> s.tap) & 1) ? a_vo[i] : OOB, s.a_so, As + (wave * NA + i) * 512);
+        buf_dma16(rs_a, cm_row_off(a_vo[i], a_oy[i], wk), aso, As + (wave * NA + i) * 512);
 #pragma unroll
       for (int i = 0; i < NB; ++i)
         if ((BN / RPP) % NW == 0 || wave * NB + i < BN / RPP)
-          buf_dma16(rs_b, b_vo[i], s.b_so, Bs + (wave * NB + i) * 512);
+          buf_dma16(rs_b, b_vo[i], bso, Bs + (wave * NB + i) * 512);
+      wk.next(KT);
       return;
     }
     const bool ragged = k0 + KT > p.K;                                      // wave-uniform conditions
@@ -619,13 +623,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     b_vo[j] = gn < p.N ? (unsigned)(((size_t)gn * p.ldb + kc) * 2) : OOB;
   }
   unsigned a_vo[2];
-  if (cm) {                        // a_vo = the output position's own pixel (all taps), a_oy = 9-bit tap validity mask
+  if (cm) {                        // a_vo = the output position's own pixel (all taps), a_oy = inverted 9-bit tap validity mask
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       a_vo[j] = cm_center(p, a_base[j], a_oy[j], a_ox[j], a_kc[j]);
-      a_oy[j] = cm_mask(p, a_ok[j], a_oy[j], a_ox[j]);
+      a_oy[j] = cm_inv_mask(p, a_ok[j], a_oy[j], a_ox[j]);
     }
   }
+  unsigned a_eff[2] = {0u, 0u};    // cm: the offsets of the K-tile whose quarters are being issued
+  CmWalk wa, wb;                   // cm: one walker per operand stream (A and B are issued at different times)
+  wa.init(kt_begin, BK); wb = wa;
+  const int cm_table = cm ? cm_tap_table(p, lane) : 0;
   int a_so = 0, b_so = 0;          // wave-uniform byte offsets along K
   bool a_second = false;           // reading the second concat source
   auto place_a = [&](int k0) {
@@ -670,11 +678,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   };
   // The A and B streams are each issued in increasing k (lo(t), hi(t), lo(t+1), ...): +64 bytes on the scalar offset per quarter.
   auto issue_a = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
-    if (cm) {
-      const CmStep s = cm_step(p, kt, BK, hi ? HK : 0);
+    if (cm) {                        // lo(t), hi(t), lo(t+1), ...: the walker advances after each hi
+      if (!hi) {
+        a_so = cm_a_so(cm_table, wa);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        buf_dma16(rs_a, ((a_oy[j] >> s.tap) & 1) ? a_vo[j] : OOB, s.a_so, dst + (wave * 32 + j * 16) * HK);
+        for (int j = 0; j < 2; ++j) a_eff[j] = cm_row_off(a_vo[j], a_oy[j], wa);
+      } else {
+        a_so += HK * 2;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) buf_dma16(rs_a, a_eff[j], a_so, dst + (wave * 32 + j * 16) * HK);
+      if (hi) wa.next(BK);
       return;
     }
     const int k0 = kt * BK;
@@ -686,12 +700,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 32 + j * 16) * HK);
   };
   auto issue_b = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
-    if (cm) b_so = cm_step(p, kt, BK, hi ? HK : 0).b_so;
-    else if (!hi && kt == kt_begin) b_so = kt * BK * 2;
+    if (cm && !hi) b_so = cm_b_so(p, wb);
+    else if (!cm && !hi && kt == kt_begin) b_so = kt * BK * 2;
     else b_so += HK * 2;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       buf_dma16(rs_b, b_vo[j], b_so, dst + (wave * 32 + j * 16) * HK);
+    if (cm && hi) wb.next(BK);
   };
 
   f32x16 acc[4][2];
@@ -901,13 +916,17 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
     b_vo[j] = (r < BN && gn < p.N) ? (unsigned)(((size_t)gn * p.ldb + kc) * 2) : OOB;
   }
   unsigned a_vo[2];
-  if (cm) {                        // a_vo = the output position's own pixel (all taps), a_oy = 9-bit tap validity mask
+  if (cm) {                        // a_vo = the output position's own pixel (all taps), a_oy = inverted 9-bit tap validity mask
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       a_vo[j] = cm_center(p, a_base[j], a_oy[j], a_ox[j], a_kc[j]);
-      a_oy[j] = cm_mask(p, a_ok[j], a_oy[j], a_ox[j]);
+      a_oy[j] = cm_inv_mask(p, a_ok[j], a_oy[j], a_ox[j]);
     }
   }
+  unsigned a_eff[2] = {0u, 0u};    // cm: the offsets of the K-tile whose quarters are being issued
+  CmWalk wa, wb;                   // cm: one walker per operand stream (A and B are issued at different times)
+  wa.init(kt_begin, BK); wb = wa;
+  const int cm_table = cm ? cm_tap_table(p, lane) : 0;
   int a_so = 0, b_so = 0;
   bool a_second = false;
   auto place_a = [&](int k0) {
@@ -952,11 +971,17 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
   };
   // the A and B streams are each issued in increasing k: lo(t), hi(t), lo(t+1), ...
   auto issue_a = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
-    if (cm) {
-      const CmStep s = cm_step(p, kt, BK, hi ? HK : 0);
+    if (cm) {                        // lo(t), hi(t), lo(t+1), ...: the walker advances after each hi
+      if (!hi) {
+        a_so = cm_a_so(cm_table, wa);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        buf_dma16(rs_a, ((a_oy[j] >> s.tap) & 1) ? a_vo[j] : OOB, s.a_so, dst + (wave * 32 + j * 16) * HK);
+        for (int j = 0; j < 2; ++j) a_eff[j] = cm_row_off(a_vo[j], a_oy[j], wa);
+      } else {
+        a_so += HK * 2;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) buf_dma16(rs_a, a_eff[j], a_so, dst + (wave * 32 + j * 16) * HK);
+      if (hi) wa.next(BK);
       return;
     }
     const int k0 = kt * BK;
@@ -968,12 +993,13 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 32 + j * 16) * HK);
   };
   auto issue_b = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
-    if (cm) b_so = cm_step(p, kt, BK, hi ? HK : 0).b_so;
-    else if (!hi && kt == kt_begin) b_so = kt * BK * 2;
+    if (cm && !hi) b_so = cm_b_so(p, wb);
+    else if (!cm && !hi && kt == kt_begin) b_so = kt * BK * 2;
     else b_so += HK * 2;
 #pragma unroll
     for (int j = 0; j < NBJ; ++j)
       if (j < NBJ - 1 || wave < NBLAST) buf_dma16(rs_b, b_vo[j], b_so, dst + ((wave + 8 * j) * 16) * HK);
+    if (cm && hi) wb.next(BK);
   };
   // at most the 3 newest quarters of this wave outstanding: 2 A + 1 B after an even phase, 1 A + 2 B after an odd one
   constexpr int NBW_HI = NBJ, NBW_LO = NBJ - 1;

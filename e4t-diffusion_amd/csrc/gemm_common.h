@@ -332,19 +332,33 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int GM) {
 // wave-uniform ((ky * Win + kx) * Cin elements from the pixel up-left of the output position) and goes into the SCALAR offset:
 // the buffer base is lowered by one image row + one pixel (those bytes are never touched: lanes whose tap falls into the padding
 // carry the out-of-range offset), the per-lane offset is the output position's own pixel for all 9 taps, and the only per-lane
-// work per K-tile is picking that offset or the out-of-range one from a 9-bit validity mask.
-struct CmStep { int a_so, b_so, tap; };
-__device__ __forceinline__ CmStep cm_step(const GemmArgs& p, int kt, int ktw, int sub) {      // kt counts ktw-wide K-tiles
-  const int c = kt / 9, tap = kt - 9 * c;
-  const int ky = tap / 3, kx = tap - 3 * ky;
-  const int ch = c * ktw + sub;
-  CmStep o;
-  o.tap = tap;
-  o.a_so = ((ky * p.Win + kx) * p.Cin + ch) * 2;
-  o.b_so = (tap * p.Cin + ch) * 2;
-  return o;
+// work per K-tile is picking that offset or an out-of-range one from a 9-bit validity mask.
+// The walk is INCREMENTAL: every SIMD retires one instruction at a time whatever its kind (SQ counters, profiles/r03_gemm_pmc.txt:
+// MFMA 32 cycles + ~4 per scalar / vector / LDS instruction add up to the kernel time), so decoding (chunk, tap) from the K-tile
+// index with a division per issue (~20 SALU) cost the ping-pong kernels a scalar instruction per MFMA.  One walker per operand
+// stream: tap and chunk offset live in SGPRs, the A-side tap shift comes from lane `tap` of a VGPR table (one v_readlane), the
+// B-side one is tap * Cin * 2.
+struct CmWalk {
+  int tap, ch;                        // current tap (0..8); byte offset of the current channel chunk
+  __device__ __forceinline__ void init(int kt, int ktw) { const int c = kt / 9; tap = kt - 9 * c; ch = c * ktw * 2; }
+  __device__ __forceinline__ void next(int ktw) {
+    ++tap;
+    if (tap == 9) { tap = 0; ch += ktw * 2; }
+  }
+};
+// lane t < 9 holds the A-side byte shift of tap t
+__device__ __forceinline__ int cm_tap_table(const GemmArgs& p, int lane) {
+  const int t = lane < 9 ? lane : 0;
+  return ((t / 3) * p.Win + (t % 3)) * p.Cin * 2;
 }
-__device__ __forceinline__ int cm_mask(const GemmArgs& p, bool ok, int oy, int ox) {
+__device__ __forceinline__ int cm_a_so(int table, const CmWalk& w) { return __builtin_amdgcn_readlane(table, w.tap) + w.ch; }
+__device__ __forceinline__ int cm_b_so(const GemmArgs& p, const CmWalk& w) { return w.tap * (p.Cin * 2) + w.ch; }
+// per-lane offset of one row for the walker's tap: the row's own pixel, or all-ones (out of range) when the INVERTED validity
+// mask has the tap's bit set — two VALU instructions (v_bfe_i32 with the scalar tap, v_or)
+__device__ __forceinline__ unsigned cm_row_off(unsigned center, int inv_mask, const CmWalk& w) {
+  return center | (unsigned)__builtin_amdgcn_sbfe(inv_mask, (unsigned)w.tap, 1u);
+}
+__device__ __forceinline__ int cm_inv_mask(const GemmArgs& p, bool ok, int oy, int ox) {
   int m = 0;
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
@@ -353,7 +367,7 @@ __device__ __forceinline__ int cm_mask(const GemmArgs& p, bool ok, int oy, int o
       const int iy = oy + ky - 1, ix = ox + kx - 1;
       if (ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) m |= 1 << (ky * 3 + kx);
     }
-  return m;
+  return ~m;                          // inverted: bit t set = tap t of this row reads padding (cm_row_off)
 }
 __device__ __forceinline__ unsigned cm_center(const GemmArgs& p, long long img_px, int oy, int ox, int kc) {
   return (unsigned)(((img_px + (long long)oy * p.Win + ox) * p.Cin + kc) * 2);
