@@ -316,7 +316,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : 1) vo
       int ld = p.lda, koff = k0;
       a_second = k0 >= p.K1;
       if (a_second) { ld = p.lda2; koff = k0 - p.K1; }
-      a_so = koff * 2;
+      a_so = __builtin_amdgcn_readfirstlane(koff * 2);          // (wave-uniform by construction; keeps the offset in an SGPR for the compiler)
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const bool ok = a_ok[i] && (k0 + a_kc[i] < p.K);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : 1) vo
       const int tap = k0 / p.Cin;
       const int ci0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
-      a_so = ci0 * 2;
+      a_so = __builtin_amdgcn_readfirstlane(ci0 * 2);
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         int iy, ix;
@@ -641,14 +641,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
       int ld = p.lda, koff = k0;
       a_second = k0 >= p.K1;
       if (a_second) { ld = p.lda2; koff = k0 - p.K1; }
-      a_so = koff * 2;
+      a_so = __builtin_amdgcn_readfirstlane(koff * 2);          // (wave-uniform by construction; keeps the offset in an SGPR for the compiler)
 #pragma unroll
       for (int j = 0; j < 2; ++j) a_vo[j] = a_ok[j] ? (unsigned)((a_base[j] * ld + a_kc[j]) * 2) : OOB;
     } else {
       const int tap = k0 / p.Cin;
       const int ci0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
-      a_so = ci0 * 2;
+      a_so = __builtin_amdgcn_readfirstlane(ci0 * 2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int iy, ix;
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) a_eff[j] = cm_row_off(a_vo[j], a_oy[j], wa);
       } else {
-        a_so += HK * 2;
+        a_so = __builtin_amdgcn_readfirstlane(a_so + HK * 2);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) buf_dma16(rs_a, a_eff[j], a_so, dst + (wave * 32 + j * 16) * HK);
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
     const int k0 = kt * BK;
     const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
     if (fresh) place_a(k0);
-    else a_so += HK * 2;
+    else a_so = __builtin_amdgcn_readfirstlane(a_so + HK * 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 32 + j * 16) * HK);
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   auto issue_b = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
     if (cm && !hi) b_so = cm_b_so(p, wb);
     else if (!cm && !hi && kt == kt_begin) b_so = kt * BK * 2;
-    else b_so += HK * 2;
+    else b_so = __builtin_amdgcn_readfirstlane(b_so + HK * 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       buf_dma16(rs_b, b_vo[j], b_so, dst + (wave * 32 + j * 16) * HK);
@@ -934,14 +934,14 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
       int ld = p.lda, koff = k0;
       a_second = k0 >= p.K1;
       if (a_second) { ld = p.lda2; koff = k0 - p.K1; }
-      a_so = koff * 2;
+      a_so = __builtin_amdgcn_readfirstlane(koff * 2);          // (wave-uniform by construction; keeps the offset in an SGPR for the compiler)
 #pragma unroll
       for (int j = 0; j < 2; ++j) a_vo[j] = a_ok[j] ? (unsigned)((a_base[j] * ld + a_kc[j]) * 2) : OOB;
     } else {
       const int tap = k0 / p.Cin;
       const int ci0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
-      a_so = ci0 * 2;
+      a_so = __builtin_amdgcn_readfirstlane(ci0 * 2);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int iy, ix;
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) a_eff[j] = cm_row_off(a_vo[j], a_oy[j], wa);
       } else {
-        a_so += HK * 2;
+        a_so = __builtin_amdgcn_readfirstlane(a_so + HK * 2);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) buf_dma16(rs_a, a_eff[j], a_so, dst + (wave * 32 + j * 16) * HK);
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
     const int k0 = kt * BK;
     const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
     if (fresh) place_a(k0);
-    else a_so += HK * 2;
+    else a_so = __builtin_amdgcn_readfirstlane(a_so + HK * 2);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 32 + j * 16) * HK);
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
   auto issue_b = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
     if (cm && !hi) b_so = cm_b_so(p, wb);
     else if (!cm && !hi && kt == kt_begin) b_so = kt * BK * 2;
-    else b_so += HK * 2;
+    else b_so = __builtin_amdgcn_readfirstlane(b_so + HK * 2);
 #pragma unroll
     for (int j = 0; j < NBJ; ++j)
       if (j < NBJ - 1 || wave < NBLAST) buf_dma16(rs_b, b_vo[j], b_so, dst + ((wave + 8 * j) * 16) * HK);
@@ -1192,14 +1192,14 @@ __global__ __launch_bounds__(512) void gemm_pt_kernel(GemmArgs p) {
       int ld = p.lda, koff = k0;
       a_second = k0 >= p.K1;
       if (a_second) { ld = p.lda2; koff = k0 - p.K1; }
-      a_so = koff * 2;
+      a_so = __builtin_amdgcn_readfirstlane(koff * 2);          // (wave-uniform by construction; keeps the offset in an SGPR for the compiler)
 #pragma unroll
       for (int j = 0; j < 4; ++j) a_vo[j] = a_ok[j] ? (unsigned)((a_base[j] * ld + a_kc[j]) * 2) : OOB;
     } else {
       const int tap = k0 / p.Cin;
       const int ci0 = k0 - tap * p.Cin;
       const int ky = tap / 3, kx = tap - ky * 3;
-      a_so = ci0 * 2;
+      a_so = __builtin_amdgcn_readfirstlane(ci0 * 2);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int iy, ix;
@@ -1231,14 +1231,14 @@ __global__ __launch_bounds__(512) void gemm_pt_kernel(GemmArgs p) {
     const int k0 = kt * BK;
     const bool fresh = !hi && (kt == kt_begin || (MODE == 0 ? k0 == p.K1 : (k0 % p.Cin) == 0));
     if (fresh) place_a(k0);
-    else a_so += HK * 2;
+    else a_so = __builtin_amdgcn_readfirstlane(a_so + HK * 2);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       buf_dma16(a_second ? rs_a2 : rs_a, a_vo[j], a_so, dst + (wave * 64 + j * 16) * HK);
   };
   auto issue_b = [&](int kt, bool hi, bf16_t* dst) __attribute__((always_inline)) {
     if (!hi && kt == kt_begin) b_so = kt * BK * 2;
-    else b_so += HK * 2;
+    else b_so = __builtin_amdgcn_readfirstlane(b_so + HK * 2);
     buf_dma16(rs_b, b_vo, b_so, dst + (wave * 16) * HK);
   };
 

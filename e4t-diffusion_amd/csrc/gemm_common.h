@@ -351,8 +351,10 @@ __device__ __forceinline__ int cm_tap_table(const GemmArgs& p, int lane) {
   const int t = lane < 9 ? lane : 0;
   return ((t / 3) * p.Win + (t % 3)) * p.Cin * 2;
 }
-__device__ __forceinline__ int cm_a_so(int table, const CmWalk& w) { return __builtin_amdgcn_readlane(table, w.tap) + w.ch; }
-__device__ __forceinline__ int cm_b_so(const GemmArgs& p, const CmWalk& w) { return w.tap * (p.Cin * 2) + w.ch; }
+// (readfirstlane: both offsets are wave-uniform by construction; saying so keeps them in SGPRs — where the compiler had moved
+// the B-side multiply to the VALU it wrapped every buffer_load ... lds in a waterfall loop over the "divergent" scalar offset)
+__device__ __forceinline__ int cm_a_so(int table, const CmWalk& w) { return __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(table, w.tap) + w.ch); }
+__device__ __forceinline__ int cm_b_so(const GemmArgs& p, const CmWalk& w) { return __builtin_amdgcn_readfirstlane(w.tap * (p.Cin * 2) + w.ch); }
 // per-lane offset of one row for the walker's tap: the row's own pixel, or all-ones (out of range) when the INVERTED validity
 // mask has the tap's bit set — two VALU instructions (v_bfe_i32 with the scalar tap, v_or)
 __device__ __forceinline__ unsigned cm_row_off(unsigned center, int inv_mask, const CmWalk& w) {
