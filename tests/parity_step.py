@@ -39,12 +39,15 @@ import torch
 import os
 
 FLOOR = 3e-3
-# An oracle LeakyReLU input counts as AMBIGUOUS (may take the compared leg's branch) when |x| <= KINK_TOL x median|x|.  With the
-# fp32 residual stream in the frozen CLIP-ViT (round 3) the native forward error at those inputs is ~5e-3 of the typical magnitude
-# (it was 1.2e-2 with a bf16 stream, and the band 5e-2), so a 1e-2 band is two standard deviations of it — the same
-# band the autocast calibration legs get.  Every report still counts the elements the band re-branched (`kink_elements_aligned`,
-# `kink_elements_within_1e-2`); E4T_KINK_TOL overrides the band for experiments.
-KINK_TOL = float(os.environ.get("E4T_KINK_TOL", "1e-2"))
+# An oracle LeakyReLU input counts as AMBIGUOUS (may take the compared leg's branch) when |x| <= KINK_TOL x median|x|.  An element
+# flips whenever its value is inside the native forward error there, so the band is a few standard deviations of that error.
+# Measured on MI355X (round 3): with the fp32 residual stream in the frozen CLIP-ViT the pretrain cases pass with a 1e-2 band
+# (full_sd14: native forward error of the encoder output 4.7e-3, 3 elements re-branched, all inside 1e-2), but the tuning case
+# `tuning_real_width` does not — 6 elements inside 1e-2 are re-branched and at least one more flips between 1e-2 and 5e-2 of the
+# median (262 encoder-gradient quantities at 3.6e-2 against 1.4e-2 for stock autocast, which re-branches 15 elements itself).  So
+# the band stays at 5e-2 for every case; each report counts the elements it re-branched and how many of them a 1e-2 band would
+# have (`kink_elements_aligned`, `kink_elements_within_1e-2`), and E4T_KINK_TOL overrides the band for experiments.
+KINK_TOL = float(os.environ.get("E4T_KINK_TOL", "5e-2"))
 KINK_TIGHT = 1e-2
 ADAM = dict(lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)      # the optimiser step both legs take (torch.optim.AdamW defaults, pretrain_e4t.py:387-392)
 
