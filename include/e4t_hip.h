@@ -64,7 +64,9 @@ typedef struct {
                           1128 / 1160 (= persistent streaming 256x128 / 256x160, gemm_ps.hip; needs K % 64 == 0, batch 1, no split-K);
                           + 3000 / 4000 forces 3 / 4 LDS stages on the 64 / 128 / 160 tiles (e.g. 3128); 5064 / 5128 / 5256 = the 64 / 128 /
                           256x128 tiles with 32-wide K-tiles (5256: three 24-KiB stages, two workgroups per CU — the automatic choice
-                          for tall outputs with N % 128 == 0) */
+                          for tall outputs with N % 128 == 0); 2320 = 256x320 ping-pong with k-step phases (gemm_pq_kernel: N % 320 == 0,
+                          K % 64 == 0, plain bias / row-bias / residual epilogue — the automatic choice where its rounds are full).
+                          An unsupported code for the shape falls back to the nearest tile that fits; e4t_gemm_plan reports the choice. */
   int splitk;          /* 0 = auto, >= 1 forced */
   int batch;           /* >= 1; operand base pointers advance by the strides below (elements) */
   long long strideA, strideB, strideC, strideBias;
