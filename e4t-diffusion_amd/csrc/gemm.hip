@@ -1675,7 +1675,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     else { ab = ((unsigned long long)(p.M - 1) * p.lda + p.K1) * 2; if (p.A2) a2b = ((unsigned long long)(p.M - 1) * p.lda2 + (p.K - p.K1)) * 2; }
     buf_ok = ab < lim && a2b < lim && bb < lim;
     if (tile == 512 && (!allow256 || !buf_ok || !whole_k)) tile = 128;
-    if (tile == 2320 && (!buf_ok || !whole_k)) tile = 128;
+    if (tile == 2320 && (!buf_ok || !whole_k || p.N % 320 != 0)) tile = 128;      // (ragged N is only exercised for the narrower tiles)
     if (tile == 640 && (!buf_ok || p.K % BK != 0)) tile = 128;
     pl.a_bytes = (unsigned)(buf_ok ? ab : 0); pl.a2_bytes = (unsigned)(buf_ok ? a2b : 0); pl.b_bytes = (unsigned)(buf_ok ? bb : 0);
     if (!buf_ok && tile != 64) { tile = 128; kt32 = false; stages = 2; }      // the register-staged fallback exists as 128x128 and 64x64 only

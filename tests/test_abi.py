@@ -55,7 +55,7 @@ def test_descriptor_structs_match_the_header(tmp_path):
     if shutil.which("gcc") is None:
         import pytest
         pytest.skip("gcc not available")
-    structs = {"e4t_gemm_desc": _C.GemmDesc, "e4t_conv_desc": _C.ConvDesc, "e4t_wo_desc": _C.WODesc}
+    structs = {"e4t_gemm_desc": _C.GemmDesc, "e4t_conv_desc": _C.ConvDesc, "e4t_wo_desc": _C.WODesc, "e4t_gemm_plan_t": _C.GemmPlan}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "e4t_hip.h")}"', "int main(void) {"]
     for cname, cls in structs.items():
         lines.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')

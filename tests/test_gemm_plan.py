@@ -1,0 +1,93 @@
+"""The tile planner behind e4t_gemm_plan / e4t_conv3x3_plan / e4t_gemm_tn_plan (csrc/gemm.hip: plan_gemm) on the training step's own
+shapes.  Pure host logic of the library (no launch, no GPU: the CU count defaults to the MI355X's 256), so the rules DESIGN.md §2.1
+states — which kernel family takes which shape, when split-K is used, how much workspace a caller must bring — are pinned on CPU.
+The timings that justify the rules are GPU measurements (profiles/r03_sweep_tiles_c.txt); this test keeps the rules from drifting."""
+import ctypes as C
+import os
+
+import pytest
+
+from e4t import _C
+
+lib = _C.load()
+
+
+def gemm_plan(M, N, K, flags=0, tile=0, splitk=0, batch=1, rowbias=False, rows_per_batch=0):
+    d = _C.GemmDesc(M=M, N=N, K=K, K1=K, lda=K, ldb=K, ldc=N, batch=batch, alpha=1.0, flags=flags, tile=tile, splitk=splitk,
+                    rows_per_batch=rows_per_batch, rowbias=(1 << 20) if rowbias else None)      # planner only tests pointers for NULL
+    pl = _C.GemmPlan()
+    assert lib.e4t_gemm_plan(C.byref(d), C.byref(pl)) == 0, lib.e4t_last_error()
+    return pl
+
+
+def conv_plan(B, H, W, Cin, Cout, mode=_C.CONV_S1, Hout=None, Wout=None, tile=0, splitk=0):
+    d = _C.ConvDesc(B=B, Hin=H, Win=W, Cin=Cin, Hout=Hout or H, Wout=Wout or W, Cout=Cout, mode=mode, tile=tile, splitk=splitk)
+    pl = _C.GemmPlan()
+    assert lib.e4t_conv3x3_plan(C.byref(d), C.byref(pl)) == 0, lib.e4t_last_error()
+    return pl
+
+
+@pytest.mark.parametrize("shape, tile, dims", [
+    # SD-1.4, B = 16 (profiles/r03_roofline_per_shape.csv)
+    ((65536, 320, 2560), 2320, (256, 320)),      # ff.net.2 at the 64x64 level: 256 x 320 ping-pong, full rounds
+    ((65536, 320, 1280), 2320, (256, 320)),
+    ((4096, 10240, 1280), 2320, (256, 320)),     # GEGLU projection at the 16x16 level
+    ((16384, 5120, 640), 2320, (256, 320)),
+    ((65536, 2560, 320), 5256, (256, 128)),      # K = 320: too short for the ping-pong prologue, N % 128 == 0
+    ((4096, 1280, 1280), 128, (128, 128)),       # 320 tiles: no wider tile has a full round
+    ((16384, 640, 640), 160, (128, 160)),
+    ((4112, 3840, 1280), 512, (256, 256)),       # ViT qkv
+])
+def test_step_gemms_get_the_documented_tile(shape, tile, dims):
+    pl = gemm_plan(*shape)
+    assert (pl.tile, pl.tile_m, pl.tile_n) == (tile, *dims), (shape, pl.tile, pl.tile_m, pl.tile_n)
+    assert pl.splitk == 1 and pl.workspace_bytes == 0
+
+
+def test_deep_k_small_grid_uses_ping_pong_with_split_k_and_reports_the_workspace():
+    M, N, K = 4096, 1280, 10240                  # 80 tiles of 256 x 256 on 256 CUs, 160 K-tiles
+    pl = gemm_plan(M, N, K)
+    assert pl.tile == 512 and pl.splitk == 3
+    assert pl.workspace_bytes == pl.splitk * M * N * 4       # fp32 partials, one per split
+
+
+@pytest.mark.parametrize("args, tile", [
+    ((16, 512, 512, 128, 128), 5256),            # VAE 128-channel convs: N = 128
+    ((16, 256, 256, 256, 256), 512),             # VAE / UNet convs with N % 256 == 0 and many tiles: 256 x 256 ping-pong
+    ((16, 128, 128, 512, 512), 512),
+    ((16, 64, 64, 320, 320), 2320),              # every 320-multiple width with full rounds
+    ((16, 64, 64, 640, 320), 2320),
+    ((16, 32, 32, 640, 640), 160),               # 64 x 2 tiles of 256 x 320 would leave half the chip idle
+])
+def test_step_convs_get_the_documented_tile(args, tile):
+    assert conv_plan(*args).tile == tile, (args, conv_plan(*args).tile)
+
+
+def test_small_map_convs_split_k():
+    pl = conv_plan(16, 16, 16, 1280, 1280)       # 16 x 16 level: 80 ping-pong tiles, K = 11520
+    assert pl.tile == 512 and pl.splitk == 3 and pl.workspace_bytes == 3 * 4096 * 1280 * 4
+    pl = conv_plan(16, 8, 8, 1280, 1280)         # 8 x 8 level: 128 x 128 tiles, split 6 ways
+    assert pl.tile == 128 and pl.splitk == 6
+
+
+def test_general_epilogue_demotes_the_wide_tiles():
+    # exact GELU and the per-row row-bias lookup exist as 64 / 128 / 160 instantiations only (gemm_common.h, GENERAL)
+    assert gemm_plan(4112, 5120, 1280, flags=_C.ACT_GELU).tile == 128
+    assert gemm_plan(65536, 320, 2560, flags=_C.ACT_GELU).tile in (128, 160)
+    assert gemm_plan(65536, 320, 2560, rowbias=True, rows_per_batch=4097).tile in (128, 160)      # rows_per_batch % 32 != 0
+    assert gemm_plan(65536, 320, 2560, rowbias=True, rows_per_batch=4096).tile == 2320
+
+
+def test_a_forced_tile_and_split_are_honoured_or_replaced_by_one_that_fits():
+    assert gemm_plan(65536, 320, 2560, tile=128).tile == 128
+    assert gemm_plan(65536, 320, 2560, tile=160).tile == 160
+    pl = gemm_plan(4096, 1280, 10240, tile=128, splitk=4)
+    assert pl.tile == 128 and pl.splitk == 4 and pl.workspace_bytes == 4 * 4096 * 1280 * 4
+    assert gemm_plan(4096, 1000, 1280, tile=2320).tile != 2320        # N % 320 != 0: the code does not fit the shape
+
+
+def test_tn_plan_reports_split_k_over_the_rows():
+    d = _C.GemmDesc(M=320, N=320, K=65536, K1=65536, lda=320, ldb=320, ldc=320, batch=1, alpha=1.0, flags=_C.OUT_F32)
+    pl = _C.GemmPlan()
+    assert lib.e4t_gemm_tn_plan(C.byref(d), C.byref(pl)) == 0, lib.e4t_last_error()
+    assert pl.splitk > 1 and pl.workspace_bytes == pl.splitk * 320 * 320 * 4
