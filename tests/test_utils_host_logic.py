@@ -65,3 +65,42 @@ def test_image_helpers(tmp_path):
     assert np.abs(np.asarray(sq).astype(float) - want).max() <= 1.0
     g = image_grid([sq] * 6, rows=2, cols=3)
     assert g.size == (144, 96)
+
+
+def test_capture_guard_pauses_the_loader_and_the_garbage_collector():
+    """ops.capture_guard() is what every HIP-graph capture runs under (text encoder, sampling step): while it is open the loader's
+    upload path (which takes ops.capture_lock) must block, the garbage collector must be off (a collected old graph would call
+    hipGraphDestroy inside the capture), and both must be restored afterwards — also when the capture raises, and when nested."""
+    import gc
+    import threading
+    import time
+
+    from e4t import ops
+
+    assert gc.isenabled()
+    entered = []
+
+    def upload():                       # what data.DeviceLoader._upload does around its GPU work
+        with ops.capture_lock:
+            entered.append(time.monotonic())
+
+    with ops.capture_guard():
+        assert not gc.isenabled()
+        t = threading.Thread(target=upload)
+        t.start()
+        time.sleep(0.2)
+        assert not entered, "the loader's upload ran during a capture"
+        with ops.capture_guard():       # re-entrant (a pipeline capture that triggers a text-encoder capture)
+            assert not gc.isenabled()
+        assert not gc.isenabled(), "the inner guard re-enabled the collector while the outer capture is still open"
+        released = time.monotonic()
+    t.join(5)
+    assert entered and entered[0] >= released
+    assert gc.isenabled()
+    try:
+        with ops.capture_guard():
+            raise RuntimeError("capture failed")
+    except RuntimeError:
+        pass
+    assert gc.isenabled() and ops.capture_lock.acquire(blocking=False)
+    ops.capture_lock.release()
