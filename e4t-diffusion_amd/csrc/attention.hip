@@ -46,6 +46,10 @@ struct AttnArgs {
   float scale;
   int causal;                  // key index > query index is masked
   int xcd_raster;              // re-deal workgroups so one XCD owns whole (batch, head) pairs (xcd_block)
+  // dK/dV kernel with few keys (cross-attention, S = 77): the query range is cut into `tsplit` chunks of `tchunk` queries, one
+  // workgroup each, writing fp32 partials part[tsplit][B][H][2 (dV, dK)][S][DH]; attn_dkv_reduce_kernel sums them in split order
+  float* part;
+  int tsplit, tchunk;
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin by linear id (x fastest), so the row blocks of one (batch, head) — which all
@@ -272,6 +276,19 @@ __device__ __forceinline__ void store_T_acc(const f32x16* acc, float mul, bf16_t
         for (int j = 0; j < 4; ++j) f[j] = acc[dt][rg * 4 + j] * mul;
         *(uint2*)(g + (long long)row * ld + d) = pack4(f);
       }
+    }
+}
+
+// the same accumulator as fp32 rows of a dense [R][DH] partial (16-byte stores)
+template <int DH>
+__device__ __forceinline__ void store_T_acc_f32(const f32x16* acc, float* g, int row, int R, int hi) {
+  if (row >= R) return;
+#pragma unroll
+  for (int dt = 0; dt < Cfg<DH>::NDT; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int d = dt * 32 + 8 * rg + 4 * hi;
+      if (d < DH) *(float4*)(g + (size_t)row * DH + d) = make_float4(acc[dt][rg * 4], acc[dt][rg * 4 + 1], acc[dt][rg * 4 + 2], acc[dt][rg * 4 + 3]);
     }
 }
 
@@ -571,7 +588,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
   const int b = blk.b, h = blk.h;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, hi = lane >> 5;
-  const int key = blk.x * 128 + wave * 32 + li;
+  // blk.x = split * (key blocks) + key block; one split (the default) covers all queries
+  const int nkb = (p.S + 127) >> 7;
+  const int ts = p.tsplit > 1 ? blk.x / nkb : 0;
+  const int key = (blk.x - ts * nkb) * 128 + wave * 32 + li;
+  const int t_begin = ts * p.tchunk, t_end = p.tsplit > 1 ? min(p.T, t_begin + p.tchunk) : p.T;
   const bf16_t* Qb = p.Q + b * p.bq + h * DH;
   const bf16_t* dOb = p.dO + b * p.bo + h * DH;
 
@@ -612,14 +633,14 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
   const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(dOb, (unsigned)(((long long)(p.T - 1) * p.ldo + DH) * 2));
   qr.init(p.ldq); dor.init(p.ldo);
   if (PF) {
-    qr.load(rsQ, 0);
-    dor.load(rsdO, 0);
-    load_stats(0);
+    qr.load(rsQ, t_begin);
+    dor.load(rsdO, t_begin);
+    load_stats(t_begin);
   }
   zero_pad_cols<DH>(Qs);
   zero_pad_cols<DH>(dOs);
   const float inv_scale2 = 1.f / p.scale2;
-  for (int q0 = 0; q0 < p.T; q0 += 64) {
+  for (int q0 = t_begin; q0 < t_end; q0 += 64) {
     if (!PF) {
       qr.load(rsQ, q0);
       dor.load(rsdO, q0);
@@ -645,12 +666,12 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
       }
     }
     __syncthreads();
-    if (PF && q0 + 64 < p.T) {
+    if (PF && q0 + 64 < t_end) {
       qr.load(rsQ, q0 + 64);
       dor.load(rsdO, q0 + 64);
       load_stats(q0 + 64);
     }
-    const int nsub = (p.T - q0 > 32) ? 2 : 1;
+    const int nsub = (t_end - q0 > 32) ? 2 : 1;      // (chunks are multiples of 64 queries: only the last tile of T is ragged)
     // one 32-row sub-tile; at dh <= 48 the two sub-tiles are separate instantiations (fragment addresses become immediates,
     // no per-read address VALU), larger head dims keep the runtime loop (the unrolled form would spill)
     auto sub_tile = [&](auto sub_) __attribute__((always_inline)) {
@@ -721,13 +742,61 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
       for (int sub = 0; sub < nsub; ++sub) sub_tile(sub);
     }
   }
+  if (p.tsplit > 1) {        // fp32 partials of this query chunk; the reduce kernel scales dK and rounds once
+    float* base = p.part + ((((size_t)ts * gridDim.z + b) * p.H + h) * 2) * (size_t)p.S * DH;
+    store_T_acc_f32<DH>(dvt, base, key, p.S, hi);
+    store_T_acc_f32<DH>(dkt, base + (size_t)p.S * DH, key, p.S, hi);
+    return;
+  }
   store_T_acc<DH>(dvt, 1.f, p.dV + b * p.bv + h * DH, p.ldv, key, p.S, hi);
   store_T_acc<DH>(dkt, p.scale, p.dK + b * p.bk + h * DH, p.ldk, key, p.S, hi);
+}
+
+// dV / dK = sum over the query chunks' partials (fixed order: deterministic), dK scaled, one bf16 rounding
+template <int DH>
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs p, int Bn) {
+  constexpr int D4 = DH / 4;
+  const long long per = (long long)p.S * D4, total = (long long)Bn * p.H * 2 * per;
+  const size_t slab = (size_t)Bn * p.H * 2 * p.S * DH;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long bh2 = i / per;
+    const int rem = (int)(i - bh2 * per), key = rem / D4, d = (rem - key * D4) * 4;
+    const int which = (int)(bh2 & 1), h = (int)((bh2 >> 1) % p.H), b = (int)((bh2 >> 1) / p.H);
+    const float* src = p.part + (size_t)bh2 * p.S * DH + (size_t)key * DH + d;
+    float4 a = *(const float4*)src;
+    for (int t = 1; t < p.tsplit; ++t) {
+      const float4 v = *(const float4*)(src + (size_t)t * slab);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    const float mul = which ? p.scale : 1.f;
+    const float f[4] = {a.x * mul, a.y * mul, a.z * mul, a.w * mul};
+    bf16_t* dst = which ? p.dK + b * p.bk + (long long)key * p.ldk + h * DH + d : p.dV + b * p.bv + (long long)key * p.ldv + h * DH + d;
+    *(uint2*)dst = pack4(f);
+  }
 }
 
 inline int xcd_raster_on() {                      // A/B switch: E4T_ATTN_NOXCD=1 restores the hardware's round-robin deal
   static const int on = [] { const char* e = getenv("E4T_ATTN_NOXCD"); return (e && e[0] == '1') ? 0 : 1; }();
   return on;
+}
+
+// Query chunks of the dK/dV kernel.  It parallelises over (key block, head, batch) and walks the queries serially: with S = 77
+// (cross-attention: ONE key block) that is B * H = 128 workgroups — half the chip — each making 64 trips of 64 queries at the
+// 64 x 64 level, 120 us of pure loop latency per launch (0.095 of the HBM roof, profiles/r03_roofline_per_shape.csv).  Cutting T
+// so that ~1024 workgroups exist turns it into ~8 trips each; the partials are tiny (S x DH per head).  Long key ranges
+// (self-attention) already fill the chip: never split.
+inline void dkv_tsplit(int Bn, int H, int T, int S, int* tsplit, int* tchunk) {
+  static const bool off = getenv("E4T_ATTN_NOTSPLIT") != nullptr;      // A/B switch
+  const long long wgs = (long long)cdiv(S, 128) * H * Bn;
+  int n = 1;
+  if (!off && wgs < 512 && T >= 512) {
+    n = (int)((1024 + wgs - 1) / wgs);
+    if (n > T / 256) n = T / 256;
+    if (n < 1) n = 1;
+  }
+  const int chunk = cdiv(cdiv(T, n), 64) * 64;
+  *tchunk = chunk;
+  *tsplit = cdiv(T, chunk);
 }
 
 template <int DH>
@@ -741,8 +810,14 @@ int launch_fwd(const AttnArgs& p, int Bn, hipStream_t st) {
   return 0;
 }
 template <int DH>
-int launch_bwd(const AttnArgs& p, int Bn, hipStream_t st) {
+int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
   const long long total = (long long)Bn * p.H * p.T;
+  dkv_tsplit(Bn, p.H, p.T, p.S, &p.tsplit, &p.tchunk);
+  if (p.tsplit > 1) {
+    const size_t need = (size_t)total + (size_t)p.tsplit * Bn * p.H * 2 * p.S * DH;
+    if (ws_floats >= need) p.part = p.Delta + (((size_t)total + 3) & ~(size_t)3);     // 16-byte aligned behind Delta
+    if (ws_floats < need + 3) { p.tsplit = 1; p.part = nullptr; }                     // caller sized the workspace for Delta only
+  }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   static const int dkv_env = getenv("E4T_ATTN_DKV_OCC") ? atoi(getenv("E4T_ATTN_DKV_OCC")) : 0;    // A/B switch (tools/ab_dkv.py)
@@ -759,13 +834,21 @@ int launch_bwd(const AttnArgs& p, int Bn, hipStream_t st) {
   }
   hipLaunchKernelGGL((attn_delta_kernel<DH>), dim3(blocks), dim3(256), 0, st, p, Bn);
   E4T_CHECK_LAUNCH("attn_delta_kernel");
+  const dim3 gdkv(cdiv(p.S, 128) * p.tsplit, p.H, Bn);
   if constexpr (DH <= 64) {
-    if (dkv_occ == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 3>), dim3(cdiv(p.S, 128), p.H, Bn), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, DKV_WAVES>), dim3(cdiv(p.S, 128), p.H, Bn), dim3(256), 0, st, p);
+    if (dkv_occ == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 3>), gdkv, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, DKV_WAVES>), gdkv, dim3(256), 0, st, p);
   } else {
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 1>), dim3(cdiv(p.S, 128), p.H, Bn), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 1>), gdkv, dim3(256), 0, st, p);
   }
   E4T_CHECK_LAUNCH("attn_bwd_dkv_kernel");
+  if (p.tsplit > 1) {
+    const long long items = (long long)Bn * p.H * 2 * p.S * (DH / 4);
+    int rb = (int)((items + 255) / 256);
+    if (rb > 2048) rb = 2048;
+    hipLaunchKernelGGL((attn_dkv_reduce_kernel<DH>), dim3(rb), dim3(256), 0, st, p, Bn);
+    E4T_CHECK_LAUNCH("attn_dkv_reduce_kernel");
+  }
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
   E4T_CHECK_LAUNCH("attn_bwd_dq_kernel");
   return 0;
@@ -800,12 +883,30 @@ extern "C" int e4t_attention_fwd(const void* Q, const void* K, const void* V, vo
   }
 }
 
+extern "C" size_t e4t_attention_bwd_workspace_floats(int Bn, int H, int T, int S, int DH) {
+  if (Bn <= 0 || H <= 0 || T <= 0 || S <= 0 || DH <= 0) return 0;
+  int tsplit, tchunk;
+  dkv_tsplit(Bn, H, T, S, &tsplit, &tchunk);
+  const size_t delta = (size_t)Bn * H * T;
+  return tsplit > 1 ? delta + 4 + (size_t)tsplit * Bn * H * 2 * S * DH : delta;
+}
+
 extern "C" int e4t_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                                  float* delta_ws, void* dQ, void* dK, void* dV, int Bn, int H, int T, int S, int DH, int ldq,
                                  int ldk, int ldv, int ldo, long long bq, long long bk, long long bv, long long bo, float scale,
                                  int causal, e4t_stream stream) {
+  return e4t_attention_bwd_ws(Q, K, V, O, dO, lse, delta_ws, (size_t)(Bn > 0 && H > 0 && T > 0 ? (size_t)Bn * H * T : 0), dQ, dK, dV, Bn, H, T, S, DH,
+                              ldq, ldk, ldv, ldo, bq, bk, bv, bo, scale, causal, stream);
+}
+
+extern "C" int e4t_attention_bwd_ws(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                                    float* delta_ws, size_t ws_floats, void* dQ, void* dK, void* dV, int Bn, int H, int T, int S, int DH,
+                                    int ldq, int ldk, int ldv, int ldo, long long bq, long long bk, long long bv, long long bo, float scale,
+                                    int causal, e4t_stream stream) {
   if (int e = check_common(Bn, H, T, S, DH, ldq, ldk, ldv, ldo)) return e;
   E4T_REQUIRE(Q && K && V && O && dO && lse && delta_ws && dQ && dK && dV, "attention_bwd: null operand");
+  E4T_REQUIRE(ws_floats >= (size_t)Bn * H * T, "attention_bwd: workspace of %zu floats is smaller than B*H*T", ws_floats);
+  E4T_REQUIRE(((uintptr_t)delta_ws & 15) == 0, "attention_bwd: workspace must be 16-byte aligned");
   AttnArgs p;
   memset(&p, 0, sizeof(p));
   p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.V = (const bf16_t*)V; p.O = (const bf16_t*)O; p.dO = (const bf16_t*)dO;
@@ -814,10 +915,10 @@ extern "C" int e4t_attention_bwd(const void* Q, const void* K, const void* V, co
   p.scale = scale; p.scale2 = scale * 1.4426950408889634f; p.causal = causal; p.xcd_raster = xcd_raster_on();
   hipStream_t st = (hipStream_t)stream;
   switch (DH) {
-    case 32: return launch_bwd<32>(p, Bn, st);
-    case 40: return launch_bwd<40>(p, Bn, st);
-    case 64: return launch_bwd<64>(p, Bn, st);
-    case 80: return launch_bwd<80>(p, Bn, st);
-    default: return launch_bwd<160>(p, Bn, st);
+    case 32: return launch_bwd<32>(p, Bn, ws_floats, st);
+    case 40: return launch_bwd<40>(p, Bn, ws_floats, st);
+    case 64: return launch_bwd<64>(p, Bn, ws_floats, st);
+    case 80: return launch_bwd<80>(p, Bn, ws_floats, st);
+    default: return launch_bwd<160>(p, Bn, ws_floats, st);
   }
 }

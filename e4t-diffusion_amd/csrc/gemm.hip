@@ -1373,12 +1373,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(GemmArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
-  int tile_x, tile_y;
-  xcd_tile(tile_x, tile_y, p.group_m);
+  int tile_x, tile_y, sz = blockIdx.z;           // sz: split index (no batching in this variant)
+  if (p.xcd3) { xcd_tile3(tile_x, tile_y, sz); p.zslab = sz; }
+  else xcd_tile(tile_x, tile_y, p.group_m);
   const int m0 = tile_y * BM, n0 = tile_x * BN;
 
   const int nkt = (p.K + BK - 1) / BK;
-  const int sz = blockIdx.z;                     // split index (no batching in this variant)
   const int kt_begin = sz * p.ktiles_per_split;
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nkt) kt_end = nkt;
@@ -1886,6 +1886,7 @@ namespace {
 
 void fill_gemm_args(const e4t_gemm_desc* d, GemmArgs& p) {
   memset(&p, 0, sizeof(p));
+  p.zslab = -1;
   p.A = (const bf16_t*)d->A; p.A2 = (const bf16_t*)d->A2; p.K1 = d->A2 ? d->K1 : d->K; p.lda = d->lda; p.lda2 = d->lda2;
   p.B = (const bf16_t*)d->B; p.ldb = d->ldb; p.C = d->C; p.ldc = d->ldc; p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr;
   p.rowbias = d->rowbias; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1; p.ldrb = d->ldrb > 0 ? d->ldrb : d->N;
@@ -1898,6 +1899,7 @@ void fill_gemm_args(const e4t_gemm_desc* d, GemmArgs& p) {
 void fill_conv_args(const e4t_conv_desc* d, GemmArgs& p) {
   const int Cin = d->Cin, Cout = d->Cout;
   memset(&p, 0, sizeof(p));
+  p.zslab = -1;
   p.A = (const bf16_t*)d->X; p.K1 = 9 * Cin; p.Hin = d->Hin; p.Win = d->Win; p.Cin = Cin; p.Hout = d->Hout; p.Wout = d->Wout;
   p.mode = d->mode; p.B = (const bf16_t*)d->W; p.ldb = 9 * Cin; p.C = d->Y; p.ldc = Cout; p.bias = d->bias;
   p.residual = d->residual; p.ldr = Cout; p.rowbias = d->rowbias; p.rows_per_batch = d->Hout * d->Wout; p.ldrb = d->ldrb > 0 ? d->ldrb : Cout;
@@ -1978,6 +1980,7 @@ extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
               "gemm_tn: M, N, lda, ldb must be multiples of 8 and the operands 16-byte aligned");
   GemmArgs p;
   memset(&p, 0, sizeof(p));
+  p.zslab = -1;
   p.A = (const bf16_t*)d->A; p.lda = d->lda; p.B = (const bf16_t*)d->B; p.ldb = d->ldb;
   p.C = d->C; p.ldc = d->ldc; p.bias = d->bias; p.residual = d->residual; p.ldr = d->ldr;
   p.M = d->M; p.N = d->N; p.K = d->K; p.K1 = d->K; p.alpha = d->alpha; p.flags = d->flags & ~E4T_REDUCE_BATCH;
@@ -2000,6 +2003,8 @@ extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
   if (splitk <= 1) p.ws = nullptr;
   p.splitk = splitk;
   p.group_m = 8;
+  static const bool no_xcd3 = getenv("E4T_TN_NOXCD3") != nullptr;      // A/B switch
+  p.xcd3 = splitk > 1 && !no_xcd3;
   p.fast_epi = !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
   hipStream_t st = (hipStream_t)stream;

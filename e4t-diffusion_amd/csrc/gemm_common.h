@@ -38,6 +38,8 @@ struct GemmArgs {
   int fast_f32;     // fp32 C (+ fp32 residual), no accumulate, no row bias: direct line-wide stores from the accumulator layout
   int ps_pre;       // persistent kernel: bias / row bias prefetched into LDS by DMA (write_tile<..., PRE>)
   int chan_major;   // stride-1 3x3 conv: K walked channel-chunk-major (cm_step) instead of tap-major
+  int xcd3;         // TN kernel with split-K: workgroups re-dealt over (split, tile) so one XCD owns whole K-slices (xcd_tile3)
+  int zslab;        // partial-slab index of this workgroup when it is not blockIdx.z (set in-kernel by a re-dealing kernel; host: -1)
   long long strideA, strideB, strideC, strideBias;
   float* colstats;                       // optional [M/32][N][2] column statistics of the output (fast bf16 epilogue only)
   unsigned a_bytes, a2_bytes, b_bytes;   // operand extents from the (batch-adjusted) base pointers, for buffer resources (pp kernel)
@@ -295,7 +297,7 @@ __device__ __forceinline__ void write_tile(const GemmArgs& p, f32x16 (&acc)[FM][
       for (int r = 0; r < 16; ++r) {
         const int row = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
         if (row >= p.M) continue;
-        if (partial) p.ws[((size_t)blockIdx.z * p.M + row) * p.N + col] = acc[i][j][r];  // z = batch*splitk + split
+        if (partial) p.ws[((size_t)(p.zslab >= 0 ? p.zslab : (int)blockIdx.z) * p.M + row) * p.N + col] = acc[i][j][r];  // z = batch*splitk + split
         else epilogue_store(p, acc[i][j][r], row, col);
       }
     }
@@ -321,6 +323,22 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by, int GM) {
   const int first = grp * GM, gsz = min(gy - first, GM);
   bx = l / gsz;
   by = first + (l - bx * gsz);
+}
+
+// The same re-deal over a 3-D grid whose z index is a split-K slice (gemm_tn_kernel).  The dispatcher deals by LINEAR workgroup id
+// (x fastest, then y, then z), so with the 2-D mapping above the tiles of one K-slice — which all stream the SAME rows of A and B,
+// each reading its own 128-column stripe — sit in 8 different L2s and every 128-byte row segment is fetched by several of them:
+// measured (profiles/r03_roofline_per_shape.csv) 3.2 x the algorithmic bytes on the K = 65536 weight gradients of the 64 x 64
+// level, which at 6.8 TB/s of actual traffic are HBM-bound on exactly that waste.  Split-major chunks: one XCD owns whole slices.
+__device__ __forceinline__ void xcd_tile3(int& bx, int& by, int& bz) {
+  const int gx = gridDim.x, gy = gridDim.y, per = gx * gy, nwg = per * gridDim.z;
+  const int lin = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, v = lin & 7;
+  const int lin2 = (v < r ? v * (q + 1) : r * (q + 1) + (v - r) * q) + (lin >> 3);
+  bz = lin2 / per;
+  const int t = lin2 - bz * per;
+  by = t / gx;
+  bx = t - by * gx;
 }
 
 // ---- channel-chunk-major K order for stride-1 3x3 convolutions (GemmArgs::chan_major) ---------------------------------------

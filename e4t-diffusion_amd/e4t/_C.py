@@ -63,6 +63,8 @@ SIGNATURES = {
     "e4t_conv3x3_plan": (i32, [C.POINTER(ConvDesc), C.POINTER(GemmPlan)]),
     "e4t_attention_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i64, f32, i32, vp]),
     "e4t_attention_bwd": (i32, [vp] * 10 + [i32] * 9 + [i64] * 4 + [f32, i32, vp]),
+    "e4t_attention_bwd_workspace_floats": (sz, [i32] * 5),
+    "e4t_attention_bwd_ws": (i32, [vp] * 7 + [sz] + [vp] * 3 + [i32] * 9 + [i64] * 4 + [f32, i32, vp]),
     "e4t_groupnorm_num_chunks": (i32, [i32, i32]),
     "e4t_groupnorm_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "e4t_groupnorm_stats": (i32, [vp, i32, vp, i32, i32, i32, i32, f32, vp, vp, sz, vp]),

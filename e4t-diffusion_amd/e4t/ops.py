@@ -311,12 +311,14 @@ class HipBackend:
         """dq/dk/dv are pre-allocated views with the SAME strides as q/k/v; do has the strides of o."""
         ldq, ldk, ldv, ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
         assert dq.stride(0) == ldq and dk.stride(0) == ldk and dv.stride(0) == ldv and do.stride(0) == ldo
-        delta = torch.empty((B, H, T), dtype=f32, device=q.device)
+        # Delta [B][H][T] + (few keys only) the fp32 partials of the query-chunked dK/dV kernel: the library states the size
+        nws = self.lib.e4t_attention_bwd_workspace_floats(B, H, T, S, DH)
+        ws = torch.empty(nws, dtype=f32, device=q.device)
         st = _stream()
-        self._timed(f"attn_bwd{DH}", 10.0 * B * H * T * S * DH, lambda: _C.check(self.lib.e4t_attention_bwd(
-            _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk),
+        self._timed(f"attn_bwd{DH}", 10.0 * B * H * T * S * DH, lambda: _C.check(self.lib.e4t_attention_bwd_ws(
+            _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(ws), nws, _ptr(dq), _ptr(dk),
             _ptr(dv), B, H, T, S, DH, ldq, ldk, ldv, ldo, T * ldq, S * ldk, S * ldv, T * ldo,
-            float(scale), int(causal), st), "e4t_attention_bwd"), 2.0 * B * H * DH * (4 * T + 4 * S) + 8.0 * B * H * T)
+            float(scale), int(causal), st), "e4t_attention_bwd_ws"), 2.0 * B * H * DH * (4 * T + 4 * S) + 8.0 * B * H * T)
 
     # ------------------------------------------------------------------ norms
     def groupnorm_fwd(self, x1, x2, gamma, beta, B, HW, G, eps, silu):

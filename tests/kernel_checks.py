@@ -197,6 +197,9 @@ def check_attention(hip, emu, dev):
         (3, 5, 300, 300, 40), (2, 8, 4096, 4096, 40),        # 45 workgroups (XCD re-deal with a remainder); the step's own 64 x 64 self-attention
         (1, 2, 300, 2100, 40), (1, 1, 2050, 2050, 64),       # S >= 2048: the dK/dV kernel's three-workgroups-per-CU instantiation, ragged tiles
         (3, 12, 77, 77, 64, True), (2, 3, 200, 200, 40, True), (1, 2, 128, 128, 80, True),      # causal: CLIP text encoder
+        # few key blocks, long query range: the dK/dV kernel cuts T into chunks + fp32 partial reduce (round 4) — the step's own
+        # cross-attention shape at a smaller batch, a ragged T (3 chunks of 384 / 384 / 232), dh 80 / 64, a short self-attention
+        (2, 8, 4096, 77, 40), (1, 2, 1000, 77, 40), (2, 2, 1024, 77, 80), (1, 2, 600, 33, 64), (1, 4, 1024, 1024, 40),
     ]
     for i, case in enumerate(cases):
         (B, H, T, S, DH), causal = case[:5], (len(case) > 5 and case[5])
