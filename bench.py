@@ -163,6 +163,7 @@ def main():
     # tokenizer("") of CLIP: BOS + EOS padding (pretrain_e4t.py:565-583); class token "art" = one id of the table
     empty_ids = torch.tensor([[49406] + [49407] * 76], device=dev)
     tr = E4TTrainer(unet, enc, text, vae, lr=1e-6 * args.batch * world, class_token_id=1125, empty_prompt_ids=empty_ids, device=dev)
+    tr_prefetch = (tr.prefetch_mode, tr.prefetch_at)
 
     B = args.batch
     res = 512 if args.model == "sd14" else 768
@@ -183,11 +184,17 @@ def main():
     # synthetic input batches are generated up front and sit in HBM when the timed region starts (a pool of distinct
     # batches, cycled): the timed region is the training step, not torch's RNG
     pool = [batch(s) for s in range(min(4, args.warmup + args.steps))]
+    # Next-batch prefetch (E4TTrainer.prefetch): every step is told which images come next — as a training loop that holds its
+    # loader's look-ahead batch does — and starts the frozen CLIP-ViT (E4T_PREFETCH=vit+vae: and the VAE encoder) for THEM under its
+    # own backward.  Each of the K timed steps therefore still runs one ViT (+ VAE) pass (for the batch after it; the first one
+    # consumes what the last warm-up step started, the last one prefetches a batch that is never used): same work per step.
     for s in range(args.warmup):
+        tr.prefetch(pool[(s + 1) % len(pool)][0])
         tr.train_step(*pool[s % len(pool)])
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
+        tr.prefetch(pool[(args.warmup + s + 1) % len(pool)][0])
         loss, _, _ = tr.train_step(*pool[(args.warmup + s) % len(pool)])
     sync()
     dt = time.perf_counter() - t0
@@ -206,6 +213,7 @@ def main():
         if rank == 0:
             hip.prof = []
         tr.comm_timing = {} if world > 1 else None      # per-region all-reduce enqueue times + exposed wait of this step (N > 1)
+        tr.prefetch(pool[0][0])                         # same configuration as the timed steps: the next batch's ViT runs under this backward
         tr.train_step(*batch(10_000))
         torch.cuda.synchronize()
     comm = tr.comm_report() if (world > 1 and not args.no_kernel_roofline) else None
@@ -302,6 +310,7 @@ def main():
                    config=dict(workload=("SD-1.4 UNet + ViT-H-14 E4T encoder pretrain step, 512px" if args.model == "sd14"
                                          else "SD-2.x UNet (ctx 1024, linear proj) + ViT-H-14 E4T encoder pretrain step, 768px"),
                                per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}", trainable="weight offsets + E4T head (ViT frozen)",
+                               next_batch_prefetch=f"{tr_prefetch[0]} at {tr_prefetch[1]} (E4TTrainer.prefetch: frozen front ends of batch i+1 run under step i's backward)",
                                frozen_on_stock_torch="none (CLIP text encoder and VAE encoder run on the HIP kernels; only embedding lookups / loss glue are torch ops)", last_loss=float(loss)),
                    roofline=roof, roofline_hbm=roof_hbm, cpu_baseline=cpu, parity=parity, secondary=secondary, comm=comm)
         print(json.dumps(out), flush=True)

@@ -83,6 +83,14 @@ class E4TTrainer:
         self.share_prefix = True     # compute the context-independent UNet prefix once for the step's two passes
         self.overlap_vision = os.environ.get("E4T_OVERLAP_VISION", "1") != "0"
         self._side, self._vision = None, None
+        # Next-batch prefetch of the step's FROZEN, weight-independent front ends (prefetch()): "vit" = CLIP-ViT tokens, "vit+vae" = also
+        # the VAE latents; started on the side stream where E4T_PREFETCH_AT says ("bwd": when the current step's backward begins,
+        # "start": at the start of the current step).  "0" = off: both run inside their own step (round 3 behaviour).
+        self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit")
+        self.prefetch_at = os.environ.get("E4T_PREFETCH_AT", "bwd")
+        self._next_px, self._pref = None, None
+        self._main_prio = int(os.environ["E4T_MAIN_PRIORITY"]) if os.environ.get("E4T_MAIN_PRIORITY") else None
+        self._main_stream = None
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         # E4T_FORCE_COMM=1: run the collective path even in a 1-rank group (exercises the RCCL calls / stream ordering on one GPU)
@@ -203,13 +211,15 @@ class E4TTrainer:
         # The frozen CLIP-ViT only needs the image: run it on a side stream under the UNet encoder pass, whose low-resolution
         # levels leave CUs idle (one process per GPU, two HIP streams; joined before the E4T head needs the tokens).  Measured:
         # -2.4 ms/step here; launching it even earlier, under the VAE encode (chip already full), gains nothing.
-        vision, self._vision = (self._vision if self._vision is not None else self._launch_vision(pixel_values)), None
+        joined = self._vision is not None           # prefetched by the previous step: already joined with this stream
+        vision, self._vision = (self._vision if joined else self._launch_vision(pixel_values)), None
         with share:
             enc = self.unet(noisy, timesteps, self.ctx_for_e4t.expand(B, -1, -1), return_encoder_outputs=True)
-            if vision is not None:
+            if vision is not None and not joined:
                 torch.cuda.current_stream().wait_stream(self._side)
                 for t in vision:
                     t.record_stream(torch.cuda.current_stream())
+            if vision is not None:
                 domain = self.encoder(x=pixel_values, unet_down_block_samples=enc["down_block_samples"], vision=vision)
             else:
                 domain = self.encoder(x=pixel_values, unet_down_block_samples=enc["down_block_samples"])
@@ -234,10 +244,65 @@ class E4TTrainer:
             return None
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=pixel_values.device)
+            self._side = self._new_side_stream(pixel_values.device)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             return self.encoder.encode_vision(pixel_values)
+
+    def _new_side_stream(self, device):
+        """The side stream fills what the step's own stream leaves idle: E4T_SIDE_PRIORITY (an int, default 0 = the same as the
+        main stream; larger = lower priority where the runtime offers it) is passed to the stream's constructor."""
+        return torch.cuda.Stream(device=device, priority=int(os.environ.get("E4T_SIDE_PRIORITY", "0")))
+
+    # ---- next-batch prefetch of the frozen front ends ---------------------------------------------------------------------
+    # The CLIP-ViT tower (and the VAE encoder) of a step depend on the step's IMAGES only — not on any weight the optimiser
+    # touches — so, like the loader's H2D copy, they can run one batch ahead: a caller that already holds the next batch
+    # (DeviceLoader prefetches two deep; bench.py's pool) announces it with prefetch(), and the current step starts those
+    # encoders for it on the side stream when its backward begins.  The backward is where the chip has room: the 8 x 8 / 16 x 16
+    # levels leave CUs idle and the GroupNorm / LayerNorm / GEGLU / AdamW passes leave the matrix cores idle, while under the
+    # forward the side stream mostly displaced main-stream work (round 3: -2.4 of the ViT's ~10 ms).  Every step still computes one
+    # ViT (+ VAE) pass — for the batch after it — so the work per step is unchanged; nothing is cached across steps.
+    def prefetch(self, pixel_values_next):
+        """Announce the images of the NEXT train_step (the same tensor object must then be passed to it).  No-op when the ViT is
+        trainable, on CPU, or with E4T_PREFETCH=0."""
+        self._next_px = pixel_values_next if (self.prefetch_mode != "0" and pixel_values_next is not None and pixel_values_next.is_cuda) else None
+        if self._next_px is not None and self.prefetch_at == "start":
+            self._start_prefetch()
+
+    def _start_prefetch(self):
+        px, self._next_px = self._next_px, None
+        if px is None:
+            return
+        pref = dict(px=px, vision=None, latents=None)
+        if "vae" in self.prefetch_mode and self.vae is not None:
+            hl, wl = px.shape[2] // 8, px.shape[3] // 8
+            pref["vae_eps"] = torch.randn((px.shape[0], 4, hl, wl), device=px.device)      # drawn on the main stream, in step order
+        pref["vision"] = self._launch_vision(px)              # (waits for the main stream's position: the start of the backward)
+        if pref["vision"] is None and "vae_eps" not in pref:
+            return
+        if "vae_eps" in pref:
+            if self._side is None:
+                self._side = self._new_side_stream(px.device)
+                self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side), torch.no_grad():
+                pref["latents"] = self.encode_latents(px, pref["vae_eps"])
+        if not getattr(self, "_prefetch_warm", False):
+            # the first pass of a frozen model also writes its one-time bf16 weight copies (PreparedConv / VAEEncoder._prepare):
+            # the main stream may use those copies right away ("start" placement), so it joins the side stream this once
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._prefetch_warm = True
+        self._pref = pref
+
+    def _take_prefetched(self, pixel_values):
+        """(vision, latents) computed for exactly this tensor by the previous step, else (None, None); joins the side stream"""
+        pref, self._pref = self._pref, None
+        if pref is None or pref["px"] is not pixel_values:
+            return None, None
+        main = torch.cuda.current_stream()
+        main.wait_stream(self._side)
+        for t in (pref["vision"] or ()) + ((pref["latents"],) if pref["latents"] is not None else ()):
+            t.record_stream(main)
+        return pref["vision"], pref["latents"]
 
     def encode_latents(self, pixel_values, vae_eps):
         w = next(self.vae.parameters())
@@ -365,14 +430,33 @@ class E4TTrainer:
         self.sync_replicas(include_moments=True)  # a per-rank-different checkpoint read must not start diverged replicas
         ops.bump_weights_epoch()                 # bf16 compute copies of the trainable weights are stale now
 
-    def train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None,
-                   sync=True, loss_scale=1.0):
+    def train_step(self, *args, **kw):
+        """One training step (see _train_step).  E4T_MAIN_PRIORITY=<int> (e.g. -1) runs it on a stream of that priority, joined
+        with the caller's stream on both sides, so that side-stream work (prefetch) only takes what this stream leaves idle."""
+        if self._main_prio is None or not self.flat.data.is_cuda:
+            return self._train_step(*args, **kw)
+        caller = torch.cuda.current_stream()
+        if self._main_stream is None:
+            self._main_stream = torch.cuda.Stream(device=self.device, priority=self._main_prio)
+        self._main_stream.wait_stream(caller)
+        with torch.cuda.stream(self._main_stream):
+            out = self._train_step(*args, **kw)
+        caller.wait_stream(self._main_stream)
+        return out
+
+    def _train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None,
+                    sync=True, loss_scale=1.0):
         """Full step.  Random draws may be passed in (parity tests) or are sampled on the device.
         Gradient accumulation (``accelerator.accumulate``, pretrain_e4t.py:595): call with ``sync=False`` and
         ``loss_scale=1/k`` for the first k-1 micro-batches — gradients accumulate locally, no collective, no optimiser step —
         and with ``sync=True`` (same loss_scale) for the k-th."""
         dev = self.device
         B = pixel_values.shape[0]
+        pre_vision, pre_latents = self._take_prefetched(pixel_values) if self._pref is not None else (None, None)
+        if pre_vision is not None:
+            self._vision = pre_vision
+        if latents is None and pre_latents is not None and vae_eps is None:
+            latents = pre_latents
         if latents is None:
             hl, wl = pixel_values.shape[2] // 8, pixel_values.shape[3] // 8
             if vae_eps is None:
@@ -383,6 +467,8 @@ class E4TTrainer:
         if timesteps is None:
             timesteps = torch.randint(0, self.acp.shape[0], (B,), device=dev).long()
         loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
+        if self._next_px is not None:        # announced by prefetch(): the next batch's frozen encoders start with this backward
+            self._start_prefetch()
         self._armed = bool(sync)             # micro-batches that only accumulate start no collectives
         self._up_events = 0
         if self.comm_timing is not None and self.flat.grad.is_cuda:

@@ -246,11 +246,17 @@ def main():
     # The reference counts ITERATIONS: global_step advances once per micro-batch (pretrain_e4t.py:656-657), so --max_train_steps,
     # --checkpointing_steps and --log_steps are in micro-batches; the optimiser steps every `ga`-th one (accelerator.accumulate).
     t_mark, step_mark = time.perf_counter(), first_step - 1
+    # one batch of look-ahead (the loader prefetches two deep anyway): the trainer starts the frozen CLIP-ViT of the NEXT batch under
+    # the current step's backward (E4TTrainer.prefetch; E4T_PREFETCH=0 switches it off)
+    pending = next(data) if first_step <= args.max_train_steps else None
     for global_step in range(first_step, args.max_train_steps + 1):
         sync = global_step % ga == 0
         if (global_step - 1) % ga == 0:
             sched.apply(tr)
-        batch = next(data)
+        batch = pending
+        pending = next(data) if global_step < args.max_train_steps else None
+        if pending is not None:
+            tr.prefetch(pending[0])
         loss, ld, lr_ = tr.train_step(*batch, sync=sync, loss_scale=1.0 / ga)
         if sync:
             for _ in range(world):

@@ -135,3 +135,45 @@ def test_training_step_is_bitwise_deterministic(hip_env):
     l1, p1 = run()
     assert torch.equal(l0, l1), (l0, l1)
     assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+
+
+@pytest.mark.parametrize("mode,at", [("vit", "bwd"), ("vit+vae", "bwd"), ("vit+vae", "start")])
+def test_next_batch_prefetch_is_result_preserving(hip_env, mode, at):
+    """E4TTrainer.prefetch(): the frozen CLIP-ViT (and VAE encoder) of batch i+1 run on the side stream under step i — same
+    kernels on the same inputs, so losses and every trained parameter after three steps must equal the un-prefetched run bit for
+    bit (the VAE's sampling noise is drawn in step order in both)."""
+    from test_train_step_host_logic import TEXT_CFG, build
+    from e4t.text import CLIPTextModel
+    from e4t.trainer import E4TTrainer
+    from e4t.vae import VAEEncoder
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    B = 2
+    batches = [(torch.rand(B, 3, 128, 128, generator=g) * 2 - 1, torch.randn(B, 4, 16, 16, generator=g), torch.randint(0, 1000, (B,), generator=g),
+                torch.randint(1, 99, (B, 9), generator=g)) for _ in range(3)]
+    pidx = torch.tensor([2, 4], device=dev)
+
+    def run(mode, at):
+        _, _, n_unet, n_enc, text_t = build(seed=0)
+        text = CLIPTextModel(**TEXT_CFG).requires_grad_(False)
+        text.load_state_dict(text_t.state_dict())
+        torch.manual_seed(11)
+        vae = VAEEncoder(block_out_channels=(64, 128, 128, 128)).requires_grad_(False)
+        n_unet.to(dev), n_enc.to(dev), text.to(dev), vae.to(dev)
+        tr = E4TTrainer(n_unet, n_enc, text, vae=vae, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev), device=dev)
+        tr.prefetch_mode, tr.prefetch_at = mode, at
+        torch.manual_seed(5)
+        dbatches = [tuple(t.to(dev) for t in b) for b in batches]
+        losses = []
+        for i, (px, noise, t, ids) in enumerate(dbatches):
+            if i + 1 < len(dbatches):
+                tr.prefetch(dbatches[i + 1][0])
+            out = tr.train_step(px, ids, pidx, noise=noise, timesteps=t)
+            losses.append(torch.stack([o.detach().float() for o in out]).cpu())
+        torch.cuda.synchronize()
+        return torch.stack(losses), tr.flat.data.detach().cpu().clone()
+
+    l0, p0 = run("0", "bwd")
+    l1, p1 = run(mode, at)
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
