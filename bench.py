@@ -118,6 +118,22 @@ def secondary_configs(dev, steps=4, warmup=2):
                                             parity_test="tests/test_configs_gpu.py::test_tuning_step_matches_oracle[tuning_real_width]")
     del tr, unet, enc, text, vae
     torch.cuda.empty_cache()
+    # ---- README recipe (reference README.md:34-54): the headline step with --unfreeze_clip_vision — the 632 M ViT-H-14 parameters train too
+    # (ViT backward on the kernels: +0.67 TFLOP/image over the frozen tower's forward), B = 16
+    unet, enc, text, vae = build_models(dev, "sd14", seed=0)
+    enc.clip_vision.requires_grad_(True)
+    tr = E4TTrainer(unet, enc, text, vae, lr=1e-6, class_token_id=1125, empty_prompt_ids=empty_ids, device=dev)
+    B = 16
+    px = torch.rand((B, 3, 512, 512), generator=gen, device=dev) * 2 - 1
+    ids = torch.randint(0, 49000, (B, 77), generator=gen, device=dev)
+    pidx = torch.randint(1, 20, (B,), generator=gen, device=dev)
+    sec = timed(lambda: tr.train_step(px, ids, pidx), steps)
+    out["README_pretrain_sd14_unfreeze_clip_vision_b16"] = dict(
+        ms_per_step=sec * 1e3, images_per_s=B / sec, trainable_parameters=tr.flat.numel, flop_per_image=4.53e12,
+        step_mfma_frac_necessary=B / sec * 3.39e12 / MFMA_PEAK, step_mfma_frac_whole_step=B / sec * 4.53e12 / MFMA_PEAK,
+        parity_test="tests/test_configs_gpu.py::test_unfrozen_vit_step_matches_oracle[unfrozen_vit_full]")
+    del tr, unet, enc, text, vae
+    torch.cuda.empty_cache()
     # ---- C5
     unet, enc, text, vae = build_models(dev, "sd21", seed=0)
     tr = E4TTrainer(unet, enc, text, vae, lr=1e-6, prediction_type="v_prediction", class_token_id=1125, empty_prompt_ids=empty_ids, device=dev)

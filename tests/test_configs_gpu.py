@@ -42,7 +42,8 @@ def test_sd2_config_step_matches_oracle(hip_env, name):
     _run(name)
 
 
-@pytest.mark.parametrize("name", ["unfrozen_vit_tiny", "unfrozen_vit"])
+@pytest.mark.parametrize("name", ["unfrozen_vit_tiny", "unfrozen_vit", "unfrozen_vit_full"])
 def test_unfrozen_vit_step_matches_oracle(hip_env, name):
+    """unfrozen_vit_full: the README's --unfreeze_clip_vision recipe with the whole 32-layer ViT-H-14 tower trainable"""
     rep = _run(name)
-    assert rep["grads"]["by_part"][".clip_vision."] >= 12          # the ViT tower's gradients were compared, not only the head's
+    assert rep["grads"]["by_part"][".clip_vision."] >= (32 * 12 if name == "unfrozen_vit_full" else 12)    # the tower's gradients were compared, not only the head's
