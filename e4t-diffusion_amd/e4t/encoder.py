@@ -125,9 +125,13 @@ class VisionTransformer(nn.Module):
         h = torch.cat([cls, x.view(B, g * g, w) + pos[1:][None]], dim=1).reshape(B * (g * g + 1), w).contiguous()
         T = g * g + 1
         h = Fn.layer_norm(h, self.ln_pre.weight, self.ln_pre.bias, self.ln_pre.eps)
-        # The residual stream of the frozen tower is fp32, as under the reference's torch.autocast (LayerNorm outputs and the
-        # `x + ...` adds are fp32 there, only the linears run in bf16): the out-proj / fc2 GEMMs add an fp32 residual and store fp32,
-        # the LayerNorms read fp32 rows.  A trainable tower (--unfreeze_clip_vision) keeps the bf16 stream its backward kernels use.
+        # The residual stream of the frozen tower is kept in fp32: the out-proj / fc2 GEMMs add an fp32 residual and store fp32, the
+        # LayerNorms read fp32 rows.  This is a deliberate precision IMPROVEMENT over the reference's --mixed_precision arithmetic, not a
+        # restatement of it: open_clip's LayerNorm casts its result back to the input dtype, so under torch.autocast the tower's stream
+        # is bf16 there (oracle/e4t_oracle.py::_ViTLayerNorm; round-3 review).  It costs nothing measurable and puts the
+        # predicted embedding closer to the fp32 oracle than the stock-autocast run is.  A trainable tower (--unfreeze_clip_vision)
+        # keeps the bf16 stream — the reference's own arithmetic — which its backward kernels use; E4T_VIT_F32_RESIDUAL=0 gives the
+        # frozen tower the bf16 stream too.
         if self.f32_residual and not (torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())):
             h = h.float()
         for blk in self.transformer.resblocks:

@@ -154,21 +154,33 @@ class E4TTrainer:
             for m in (self.unet, self.encoder, self.text_encoder, self.vae):
                 if m is None:
                     continue
-                for t in list(m.parameters()) + list(m.buffers()):
-                    if id(t) not in mine and t.numel() and (t.is_floating_point() or t.dtype in (torch.int32, torch.int64)):
-                        bc(t.data)
+                with torch.no_grad():
+                    for t in list(m.parameters()) + list(m.buffers()):
+                        if id(t) not in mine and t.numel() and (t.is_floating_point() or t.dtype in (torch.int32, torch.int64)):
+                            # broadcast INTO the tensor itself (not .data): the in-place write bumps its _version, which is what the
+                            # bf16 compute copies of frozen weights (PreparedLinear / PreparedConv / the text encoder's fused
+                            # qkv and captured graphs) are keyed on — a forward that ran before this trainer was built must not
+                            # leave ranks > 0 computing with their pre-broadcast copies
+                            bc(t)
         ops.bump_weights_epoch()
 
     def check_replicas(self):
-        """every rank must hold bit-identical trainable parameters (deterministic kernels + the same all-reduced gradient): compare
-        one checksum pair (sum of squares of the parameters and of exp_avg) across ranks; raises on every rank when they differ"""
+        """every rank must hold bit-identical trainable state (deterministic kernels + the same all-reduced gradient): compare a
+        checksum vector — sum and sum of squares of the parameters, of exp_avg and of exp_avg_sq — across ranks (MIN == MAX);
+        raises on every rank when they differ.  A non-finite state is reported as such, not as divergence (NaN != NaN)."""
         if self.world <= 1:
             return True
+        bufs = (self.flat.data, self.exp_avg, self.exp_avg_sq)
         if self.flat.data.is_cuda:
             be = ops.backend()
-            c = torch.stack([be.sumsq(self.flat.data), be.sumsq(self.exp_avg)]).double()
+            c = torch.stack([x for b in bufs for x in (b.sum(dtype=torch.float64), be.sumsq(b).double())])
         else:
-            c = torch.stack([self.flat.data.double().pow(2).sum(), self.exp_avg.double().pow(2).sum()])
+            c = torch.stack([x for b in bufs for x in (b.double().sum(), b.double().pow(2).sum())])
+        finite = torch.isfinite(c).all().to(torch.int32)
+        torch.distributed.all_reduce(finite, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+        if not bool(finite):
+            raise RuntimeError(f"non-finite training state at optimiser step {self.step_count} (a NaN / Inf in the parameters or Adam moments "
+                               f"of at least one rank): checksums {c.tolist()}")
         lo, hi = c.clone(), c.clone()
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.pg)
         torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.pg)

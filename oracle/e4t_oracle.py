@@ -494,12 +494,22 @@ class _ViTMLP(nn.Module):
         return self.c_proj(self.gelu(self.c_fc(x)))
 
 
+class _ViTLayerNorm(nn.LayerNorm):
+    """[3P] open_clip.transformer.LayerNorm: torch's LayerNorm with the result cast back to the input dtype.  In fp32 it IS
+    nn.LayerNorm; under torch.autocast(bf16) — the reference's --mixed_precision run — it hands a bf16 tensor to `x + attn(...)`,
+    so the tower's residual stream is bf16 there (a plain nn.LayerNorm would return fp32 and promote the stream to fp32, which
+    understates the reference's own bf16 error in the calibration leg of tests/parity_step.py; round-3 review)."""
+
+    def forward(self, x):
+        return super().forward(x).to(x.dtype)
+
+
 class _ViTBlock(nn.Module):
     def __init__(self, width, heads, mlp_ratio=4.0):
         super().__init__()
-        self.ln_1 = nn.LayerNorm(width)
+        self.ln_1 = _ViTLayerNorm(width)
         self.attn = nn.MultiheadAttention(width, heads, batch_first=True)
-        self.ln_2 = nn.LayerNorm(width)
+        self.ln_2 = _ViTLayerNorm(width)
         self.mlp = _ViTMLP(width, int(width * mlp_ratio))
 
     def forward(self, x):
@@ -533,9 +543,9 @@ class VisionTransformer(nn.Module):
         scale = width ** -0.5
         self.class_embedding = nn.Parameter(scale * torch.randn(width))
         self.positional_embedding = nn.Parameter(scale * torch.randn(self.grid ** 2 + 1, width))
-        self.ln_pre = nn.LayerNorm(width)
+        self.ln_pre = _ViTLayerNorm(width)
         self.transformer = _ViTTransformer(width, layers, heads, mlp_ratio)
-        self.ln_post = nn.LayerNorm(width)
+        self.ln_post = _ViTLayerNorm(width)
         self.tokens_after_ln_post = tokens_after_ln_post
 
     def forward(self, x):

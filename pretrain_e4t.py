@@ -186,7 +186,20 @@ def main():
         if path == "latest":
             dirs = [d for d in (os.listdir(args.output_dir) if os.path.isdir(args.output_dir) else []) if d.startswith("checkpoint-")]
             path = os.path.join(args.output_dir, max(dirs, key=lambda d: int(d.split("-")[1]))) if dirs else None
-        if path is None or not os.path.exists(os.path.join(path, "trainer_state.pt")):
+        found = path is not None and os.path.exists(os.path.join(path, "trainer_state.pt"))
+        if world > 1:
+            # load_state_dict() broadcasts (collectives): every rank must take the same branch.  Rank 0 decides; a rank that cannot see
+            # what rank 0 sees (no shared filesystem, half-written directory) fails loudly instead of hanging the others.
+            flag = torch.tensor([int(found)], device=dev)
+            mine = int(flag)
+            dist.broadcast(flag, src=0)
+            found = bool(int(flag))
+            agree = torch.tensor([int(mine == int(flag))], device=dev)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if not int(agree):
+                raise SystemExit(f"--resume_from_checkpoint {args.resume_from_checkpoint}: the ranks disagree on whether '{path}' exists "
+                                 "(rank 0 decides; give every rank the same view of the checkpoint directory)")
+        if not found:
             print(f"Checkpoint '{args.resume_from_checkpoint}' does not exist. Starting a new training run.")
         else:
             print(f"Resuming from checkpoint {path}")
