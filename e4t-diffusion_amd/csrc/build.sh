@@ -1,12 +1,23 @@
 #!/bin/bash
-# Build libe4t_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [-j]
+# Build libe4t_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh
+# E4T_EXPERIMENTAL=1 csrc/build.sh additionally builds the measured-and-rejected GEMM variants (3 / 4-stage and 32-wide-K 64 / 128 tiles,
+# 64-wide 256 x 128, 512 x 128 ping-pong, the persistent streaming kernels of gemm_ps.hip) for tools/sweep_*.py — not part of the product.
 set -e
 cd "$(dirname "$0")"
 OUT=../e4t/libe4t_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
+SRCS="core gemm attention norm wo elementwise image"
+STAMP=obj/.experimental
 mkdir -p obj
+if [ -n "$E4T_EXPERIMENTAL" ]; then
+  FLAGS="$FLAGS -DE4T_EXPERIMENTAL"; SRCS="$SRCS gemm_ps"
+  [ -f $STAMP ] || { rm -f obj/gemm.o obj/core.o; touch $STAMP; }
+else
+  if [ -f $STAMP ]; then rm -f obj/gemm.o obj/core.o $STAMP; fi
+  rm -f obj/gemm_ps.o
+fi
 pids=()
-for f in core gemm gemm_ps attention norm wo elementwise image; do
+for f in $SRCS; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || { [[ $f == gemm* ]] && [ gemm_common.h -nt obj/$f.o ]; } || [ ../../include/e4t_hip.h -nt obj/$f.o ]; then
     EXTRA=""
     [ $f = image ] && EXTRA="-ffp-contract=off"      # byte-exact INTER_AREA: float ops must not be fused (see image.hip)

@@ -10,6 +10,13 @@ extern "C" void e4t_set_error(const char* msg) {
 }
 extern "C" const char* e4t_last_error(void) { return g_err; }
 extern "C" int e4t_version(void) { return 100; }
+extern "C" int e4t_build_flags(void) {
+#ifdef E4T_EXPERIMENTAL
+  return E4T_BUILD_EXPERIMENTAL;
+#else
+  return 0;
+#endif
+}
 
 // ---- launch log ------------------------------------------------------------------------------------
 #include <stdarg.h>

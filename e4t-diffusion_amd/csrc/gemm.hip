@@ -864,7 +864,10 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
   const int wr = wave / WC, wc = wave % WC;
   int tile_x, tile_y;
   xcd_tile(tile_x, tile_y, p.group_m);
-  const int m0 = tile_y * BM, n0 = tile_x * BN;
+  int m0 = tile_y * BM;
+  const int n0 = tile_x * BN;
+  const int mrows = p.M - m0;                       // valid (logical) rows of this tile
+  if (p.panel_rows) m0 = (m0 / p.panel_rows) * p.panel_stride + p.panel_off + m0 % p.panel_rows;      // physical first row (panel_rows % 256 == 0)
 
   const int nkt = p.K / BK;
   const int bz = blockIdx.z / p.splitk, sz = blockIdx.z - bz * p.splitk;
@@ -896,7 +899,7 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
     const int r = wave * 32 + j * 16 + drow;
     a_kc[j] = (dslot ^ ((r >> 2) & 3)) * 8;
     const int gr = m0 + r;
-    a_ok[j] = gr < p.M;
+    a_ok[j] = r < mrows;
     if (MODE == 0) {
       a_base[j] = (long long)gr; a_oy[j] = a_ox[j] = 0;
     } else {
@@ -1092,6 +1095,7 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();   // every fragment read and every DMA is done before the epilogue reuses the LDS
+  if (p.panel_rows) p.M = m0 + min(mrows, BM);      // the epilogue bounds PHYSICAL rows (never with split-K: p.M is the slab stride there)
   // 32-row slices of the wave tile: the staging of 8 waves x 32 x (WN + 8) fits the operand buffers, the unrolled epilogue stays small
   // (compile-time row index: a runtime-indexed accumulator array is placed in scratch memory — 704 bytes per lane written and read back
   // through HBM cost ~55 us per tile in the first version of this kernel)
@@ -1110,6 +1114,7 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
   }
 }
 
+#ifdef E4T_EXPERIMENTAL
 // ------------------------------------------------------------------------------------------------
 // 512 x 128 ("tall") ping-pong tile: the same phase machine with the operand roles exchanged, for outputs that are only
 // 128 columns wide (the VAE's 128-channel 3x3 convs at 512^2: M = 4.2 M rows, N = 128 — a 256-wide tile would be half empty
@@ -1341,6 +1346,8 @@ __global__ __launch_bounds__(512) void gemm_pt_kernel(GemmArgs p) {
   __syncthreads();
   write_tile<64, 64, 2, 2>(p, acc[1], wave_stage<64, 64>(smem, wave), lane, m0 + wr * 256 + wc * 64, n0 + 64);
 }
+
+#endif  // E4T_EXPERIMENTAL
 
 #ifdef PP_TRACE
 }  // namespace
@@ -1580,8 +1587,24 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   if (tile_hint >= 3000 && tile_hint < 5000) { stages = tile_hint / 1000; tile_hint %= 1000; }
   else if (tile_hint >= 5000 && tile_hint < 6000) { kt32 = true; stages = 4; tile_hint %= 1000; }
   int tile = tile_hint;
+#ifndef E4T_EXPERIMENTAL
+  // The product library carries the tiles the planner chooses (64 / 128 / 160 two-stage, 5256, 512, 2320) and nothing else: the
+  // measured-and-rejected variants — 3 / 4 LDS stages, 32-wide K-tiles on the 64 / 128 tiles, the 64-wide 256 x 128 tile, the 512 x 128
+  // ping-pong tile, the persistent streaming kernels of gemm_ps.hip — are built only with -DE4T_EXPERIMENTAL (csrc/build.sh:
+  // E4T_EXPERIMENTAL=1).  A hint that names one of them gets the nearest product tile.
+  stages = 2;
+  if (kt32 && tile != 256) kt32 = false;
+  if (tile == 256 && !kt32) { kt32 = true; stages = 3; }
+  if (tile == 640) tile = 128;
+  if (tile == 1128) tile = 128;
+  if (tile == 1160) tile = 160;
+#endif
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
+#ifdef E4T_EXPERIMENTAL
   static const bool auto256 = getenv("E4T_GEMM_AUTO256") != nullptr;    // measured: 128x128/2-stage >= 256x128/3-stage on every E4T shape
+#else
+  const bool auto256 = false;
+#endif
   static const bool r2_rules = getenv("E4T_GEMM_R2RULES") != nullptr;   // A/B switch: the round-2 choices (before tools/sweep_ps.py, round 3)
   const bool whole_k = p.K % BK == 0 && (!p.A2 || p.K1 % BK == 0);
   const bool ps_ok = allow256 && whole_k && batch == 1 && !p.reduce_batch && splitk_req <= 1;      // what gemm_ps_kernel accepts
@@ -1611,7 +1634,11 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     // (the VAE's 128-channel convs, K = 1152 = 18 K-tiles) it measured 526 vs 588 TF/s for the 128 x 128 tile — one 160-KiB
     // workgroup per CU leaves nothing to overlap its (large) epilogue and prologue with, and 18 K-tiles do not amortise
     // them (tools/ab_pt.py).  E4T_GEMM_PT=1 turns the automatic choice on for experiments.
+#ifdef E4T_EXPERIMENTAL
     static const bool auto_pt = getenv("E4T_GEMM_PT") != nullptr;
+#else
+    const bool auto_pt = false;
+#endif
     if (auto_pt && allow256 && tile == 128 && p.N % 128 == 0 && p.N % 256 != 0 && p.K % BK == 0 && nkt >= 16 && !p.A2 &&
         (long long)cdiv(p.M, 512) * (p.N / 128) * batch >= 512) tile = 640;
     const bool general = (p.flags & E4T_ACT_GELU) || (p.rowbias && p.rows_per_batch % 32 != 0);
@@ -1634,7 +1661,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     //    K1280 57 vs 73, K320 26 vs 28; M4096 N10240 K1280 100 vs 112 (ping-pong 256 x 256).  It loses below one round (M16384
     //    N640: 128 tiles) and on the K = 320 GEMMs wider than 320 (epilogue-bound: 83 vs 72 us at N1280).
     static const bool no_pq = getenv("E4T_GEMM_NOPQ") != nullptr;      // A/B switch
-    if (!r2_rules && !no_pq && allow256 && batch == 1 && !general && whole_k && p.N % 320 == 0) {
+    if (!r2_rules && !no_pq && allow256 && batch == 1 && (!general || !conv) && whole_k && p.N % 320 == 0) {
       const long long t320 = (long long)cdiv(p.M, 256) * (p.N / 320);
       const int ncu = device_cu_count();
       const double eff = (double)t320 / (double)(cdivl(t320, ncu) * ncu);
@@ -1645,7 +1672,11 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     // The persistent 256 x 160 / 256 x 128 streaming kernel (gemm_ps.hip).  NOT chosen automatically: correct, but slower than the
     // tiles above on every shape of the step (its ping-pong phases are bound by the DMA-issue / fragment-read segment).
     // E4T_GEMM_PS=1 turns the automatic choice on for experiments.
+#ifdef E4T_EXPERIMENTAL
     static const int auto_ps = getenv("E4T_GEMM_PS") ? atoi(getenv("E4T_GEMM_PS")) : E4T_GEMM_PS_DEFAULT;
+#else
+    const int auto_ps = 0;
+#endif
     if (auto_ps && ps_ok && (tile == 128 || tile == 160)) {
       const int ncu = device_cu_count();
       const long long rows = cdiv(p.M, 256);
@@ -1664,7 +1695,9 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   if (tile == 640 && (!allow256 || p.A2)) tile = 128;
   if ((tile == 1128 || tile == 1160) && !ps_ok) tile = tile == 1160 && p.N % 160 == 0 ? 160 : 128;
   if (tile == 2320 && !allow256) tile = 128;
-  if (tile == 2320 && general_epi) tile = p.N % 160 == 0 ? 160 : 128;      // the GELU / row-lookup epilogue of the 64 x 160 wave tile spills (256 + 44 VGPRs)
+  if (tile == 2320 && general_epi && conv) tile = p.N % 160 == 0 ? 160 : 128;      // (the GENERAL instantiation of the 256 x 320 tile exists for GEMMs only)
+  // row panels exist in the 256 x 320 ping-pong kernel only
+  if (p.panel_rows && !(tile == 2320 && allow256)) tile = (p.N % 320 == 0 && whole_k && !conv) ? 2320 : tile;
   // The DMA kernels address their operands through buffer resources (32-bit byte offsets): operands beyond 4 GB fall back to
   // the register-staged kernel.  The ping-pong kernels additionally need whole K-tiles.
   bool buf_ok = true;
@@ -1672,7 +1705,11 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     const unsigned long long lim = 0xFFFF0000ull;
     unsigned long long ab, a2b = 0, bb = ((unsigned long long)(p.N - 1) * p.ldb + p.K) * 2;
     if (conv) ab = (unsigned long long)((long long)p.M / ((long long)p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * 2;   // batch * Hin * Win * Cin
-    else { ab = ((unsigned long long)(p.M - 1) * p.lda + p.K1) * 2; if (p.A2) a2b = ((unsigned long long)(p.M - 1) * p.lda2 + (p.K - p.K1)) * 2; }
+    else {
+      const unsigned long long last = p.panel_rows ? (unsigned long long)((p.M - 1) / p.panel_rows) * p.panel_stride + p.panel_off + (p.M - 1) % p.panel_rows : (unsigned long long)(p.M - 1);
+      ab = (last * p.lda + p.K1) * 2;
+      if (p.A2) a2b = (last * p.lda2 + (p.K - p.K1)) * 2;
+    }
     buf_ok = ab < lim && a2b < lim && bb < lim;
     if (tile == 512 && (!allow256 || !buf_ok || !whole_k)) tile = 128;
     if (tile == 2320 && (!buf_ok || !whole_k || p.N % 320 != 0)) tile = 128;      // (ragged N is only exercised for the narrower tiles)
@@ -1688,6 +1725,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   // --- split-K: only when the grid underfills the chip and K is long ---
   int splitk = splitk_req;
   if (tile >= 1000 && tile < 2000) splitk = 1;
+  if (p.panel_rows) splitk = 1;
   if (splitk <= 0) {
     splitk = 1;
     const long long tiles = (long long)gx * gy * batch;
@@ -1794,16 +1832,21 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     if (p.ws) E4T_LOG_LAUNCH("%s|M%d N%d nz%d|%.0f|0", vec8 ? "splitk_reduce8_kernel" : "splitk_reduce_kernel",
                              p.M, p.N, p.reduce_batch ? splitk * batch : splitk, 4.0 * (double)p.M * p.N * splitk * batch + osz * (double)p.M * p.N);
   }
+  if (p.panel_rows && !(use_dma && buf_ok && tile == 2320 && splitk == 1 && !p.ws))
+    E4T_FAIL(-22, "gemm: row panels need the 256 x 320 ping-pong tile (N %% 320 == 0, K %% 64 == 0, no split-K); the plan chose tile %d", tile);
   if (use_dma && buf_ok) {
     if (tile == 2320) {
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_pq_kernel<1, 320, false>), grid, block, 0, st, p);
+      else if (general_epi) hipLaunchKernelGGL((gemm_pq_kernel<0, 320, true>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_pq_kernel<0, 320, false>), grid, block, 0, st, p);
+#ifdef E4T_EXPERIMENTAL
     } else if (tile >= 1000) {
       static const bool ps_pre = getenv("E4T_PS_PRE") == nullptr || atoi(getenv("E4T_PS_PRE")) != 0;      // A/B switch
       p.ps_pre = ps_pre && p.fast_epi && nkt >= 2 && (!p.rowbias || p.rows_per_batch % 256 == 0);
       const int rc = e4t_launch_gemm_ps(&p, conv ? 1 : 0, tile - 1000, general_epi ? 1 : 0, device_cu_count(), st);
       if (rc < 0) return rc;
+#endif
     } else if (tile == 512) {
       block = dim3(512);
       if (general_epi) {
@@ -1813,35 +1856,47 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
         if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_pp_kernel<0>), grid, block, 0, st, p);
       }
+#ifdef E4T_EXPERIMENTAL
     } else if (tile == 640) {
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_pt_kernel<1>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_pt_kernel<0>), grid, block, 0, st, p);
+#endif
     } else if (tile == 256 && kt32) {
       block = dim3(512);       // experimental (5256): 256 x 128 with 32-wide K-tiles, 3 x 24 KiB stages = two workgroups per CU
       if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>), grid, block, 0, st, p);
+#ifdef E4T_EXPERIMENTAL
     } else if (tile == 256) {
       block = dim3(512);
       if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 0, 3>), grid, block, 0, st, p);
+#endif
     } else {
       // 64 / 128 / 160 tiles: 2 LDS stages and 2 workgroups per CU by default; 3 or 4 stages (one workgroup per CU, 2-3 K-tiles
       // in flight) when the grid cannot give a CU two workgroups anyway — see the stage choice above
-#define E4T_LAUNCH_DMA(BM_, BN_, WGM_, WGN_, NT_)                                                                         \
-  do {                                                                                                                   \
-    block = dim3(NT_);                                                                                                   \
+#ifdef E4T_EXPERIMENTAL
+#define E4T_LAUNCH_DMA_STAGES(BM_, BN_, WGM_, WGN_)                                                                       \
     if (stages == 4) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 4>), grid, block, 0, st, p); \
                        else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 4>), grid, block, 0, st, p); }    \
     else if (stages == 3) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 3>), grid, block, 0, st, p); \
                             else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 3>), grid, block, 0, st, p); } \
-    else if (general_epi) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 2, true>), grid, block, 0, st, p); \
+    else
+#else
+#define E4T_LAUNCH_DMA_STAGES(BM_, BN_, WGM_, WGN_)
+#endif
+#define E4T_LAUNCH_DMA(BM_, BN_, WGM_, WGN_, NT_)                                                                         \
+  do {                                                                                                                   \
+    block = dim3(NT_);                                                                                                   \
+    E4T_LAUNCH_DMA_STAGES(BM_, BN_, WGM_, WGN_)                                                                          \
+    if (general_epi) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 2, true>), grid, block, 0, st, p); \
                             else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 2, true>), grid, block, 0, st, p); } \
     else { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 2>), grid, block, 0, st, p);            \
            else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 2>), grid, block, 0, st, p); }               \
   } while (0)
       // 128x128: 8 waves (wave tile 32x64): ~4 waves/SIMD at 2 workgroups/CU hide the DMA/LDS latency that the 4-wave
       // version of the same tile exposed (measured +5..18 % on every E4T shape, 8192^3: 956 -> 980 TF)
+#ifdef E4T_EXPERIMENTAL
       if (kt32 && tile == 128) {
         block = dim3(512);
         if (conv) hipLaunchKernelGGL((gemm_dma_kernel<128, 128, 4, 2, 1, 4, false, 32>), grid, block, 0, st, p);
@@ -1850,10 +1905,13 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
         block = dim3(256);
         if (conv) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 1, 4, false, 32>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 0, 4, false, 32>), grid, block, 0, st, p);
-      } else if (tile == 160) E4T_LAUNCH_DMA(128, 160, 4, 1, 256);
+      } else
+#endif
+      if (tile == 160) E4T_LAUNCH_DMA(128, 160, 4, 1, 256);
       else if (tile == 128) E4T_LAUNCH_DMA(128, 128, 4, 2, 512);
       else E4T_LAUNCH_DMA(64, 64, 2, 2, 256);
 #undef E4T_LAUNCH_DMA
+#undef E4T_LAUNCH_DMA_STAGES
     }
   } else if (tile == 128) {
     if (conv) hipLaunchKernelGGL((gemm_kernel<128, 128, 2, 2, 1>), grid, block, 0, st, p);
@@ -1894,6 +1952,7 @@ void fill_gemm_args(const e4t_gemm_desc* d, GemmArgs& p) {
   p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.strideBias = d->strideBias;
   p.reduce_batch = (d->flags & E4T_REDUCE_BATCH) ? 1 : 0;
   p.colstats = d->colstats;
+  p.panel_rows = d->panel_rows; p.panel_stride = d->panel_stride; p.panel_off = d->panel_off;
 }
 
 void fill_conv_args(const e4t_conv_desc* d, GemmArgs& p) {
@@ -1967,6 +2026,12 @@ extern "C" int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream) {
   const int batch = d->batch > 0 ? d->batch : 1;
   E4T_REQUIRE(batch == 1 || (d->strideA % 8 == 0 && d->strideB % 8 == 0), "gemm_nt: batch strides must keep 16-B alignment");
   E4T_REQUIRE(!(d->flags & E4T_REDUCE_BATCH) || !d->A2, "gemm_nt: reduce-batch with two-source A unsupported");
+  if (d->panel_rows) {
+    E4T_REQUIRE(d->panel_rows > 0 && d->panel_rows % 256 == 0 && d->panel_stride >= d->panel_rows && d->panel_off >= 0 && d->M % d->panel_rows == 0,
+                "gemm_nt: row panels need panel_rows %% 256 == 0, panel_stride >= panel_rows, M %% panel_rows == 0");
+    E4T_REQUIRE(batch == 1 && !d->rowbias && !d->colstats && !d->A2 && !(d->flags & (E4T_ACCUM | E4T_REDUCE_BATCH)) && d->splitk <= 1,
+                "gemm_nt: row panels do not combine with batch / row bias / column statistics / two-source A / accumulate / split-K");
+  }
   GemmArgs p;
   fill_gemm_args(d, p);
   return launch_gemm(p, false, d->tile, d->workspace_bytes, d->splitk, batch, (hipStream_t)stream);

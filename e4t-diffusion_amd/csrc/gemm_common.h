@@ -39,6 +39,9 @@ struct GemmArgs {
   int ps_pre;       // persistent kernel: bias / row bias prefetched into LDS by DMA (write_tile<..., PRE>)
   int chan_major;   // stride-1 3x3 conv: K walked channel-chunk-major (cm_step) instead of tap-major
   int xcd3;         // TN kernel with split-K: workgroups re-dealt over (split, tile) so one XCD owns whole K-slices (xcd_tile3)
+  // Row panels (gemm_pq_kernel only): logical row r of A / C / residual lives at physical row (r / panel_rows) * panel_stride + panel_off +
+  // r % panel_rows.  panel_rows = 0: dense.  Lets the 16 x 256 patch tokens of a [16][257] ViT token matrix run as 16 full 256-row tiles.
+  int panel_rows, panel_stride, panel_off;
   int zslab;        // partial-slab index of this workgroup when it is not blockIdx.z (set in-kernel by a re-dealing kernel; host: -1)
   long long strideA, strideB, strideC, strideBias;
   float* colstats;                       // optional [M/32][N][2] column statistics of the output (fast bf16 epilogue only)

@@ -23,6 +23,7 @@ class GemmDesc(C.Structure):
         ("rows_per_batch", i32), ("flags", i32), ("tile", i32), ("splitk", i32), ("batch", i32),
         ("strideA", i64), ("strideB", i64), ("strideC", i64), ("strideBias", i64),
         ("alpha", f32), ("ldrb", i32), ("colstats", vp),
+        ("panel_rows", i32), ("panel_stride", i32), ("panel_off", i32),
     ]
 
 
@@ -52,6 +53,7 @@ class WODesc(C.Structure):
 # (tests/test_abi.py checks the header against this table and against the built library).
 SIGNATURES = {
     "e4t_version": (i32, []),
+    "e4t_build_flags": (i32, []),
     "e4t_last_error": (C.c_char_p, []),
     "e4t_device_info": (i32, [C.c_char_p, i32, C.POINTER(i32)]),
     "e4t_set_launch_log": (i32, [C.c_char_p]),

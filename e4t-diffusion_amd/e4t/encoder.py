@@ -82,8 +82,28 @@ class _ResBlock(nn.Module):
         if torch.is_grad_enabled() and (n.requires_grad or self.mlp.c_fc.weight.requires_grad):
             u = Fn.UnaryFn.apply(Fn.linear(n, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self._pf), 2)   # unfused GELU keeps a backward
         else:
-            u = Fn.linear(n, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self._pf, gelu=True)
+            u = _fc_gelu_frozen(n, self.mlp.c_fc, self._pf, B, T)
         return Fn.linear(u, self.mlp.c_proj.weight, self.mlp.c_proj.bias, self._pp, residual=h, out_f32=f32s)
+
+
+_VIT_PANELS = os.environ.get("E4T_VIT_PANELS", "1") != "0"      # A/B switch
+
+
+def _fc_gelu_frozen(n, fc, prep, B, T):
+    """gelu(c_fc(n)) of a frozen tower.  With T = 1 + 256 tokens per image (ViT-H/L-14 at 224 px) the B x 256 patch rows are handed to
+    the GEMM as B full 256-row panels (e4t_gemm_desc.panel_*: stride T, offset 1) and the B class-token rows as a second, tiny GEMM
+    over a strided view: N = 5120 then is exactly one round of 256 x 320 ping-pong tiles on 256 CUs, where the 16 x 257 = 4112-row
+    matrix is 17 panels, i.e. a second round for 16 rows (round 3: 105 us in the step on the 128 x 128 tile)."""
+    N, K = fc.weight.shape
+    if not (_VIT_PANELS and (T - 1) % 256 == 0 and T > 1 and N % 320 == 0 and K % 64 == 0 and n.shape == (B * T, K)):
+        return Fn.linear(n, fc.weight, fc.bias, prep, gelu=True)
+    be = ops.backend()
+    w, _ = prep.get()
+    w = w[:, :K] if w.shape[1] != K else w
+    y = torch.empty((B * T, N), dtype=n.dtype, device=n.device)
+    be.gemm(n, w, bias=fc.bias, gelu=True, out=y, panels=(T - 1, T, 1, B))
+    be.gemm(n.view(B, T, K)[:, 0], w, bias=fc.bias, gelu=True, out=y.view(B, T, N)[:, 0])
+    return y
 
 
 class _Transformer(nn.Module):

@@ -166,7 +166,10 @@ class HipBackend:
 
     # ------------------------------------------------------------------ GEMM
     def gemm(self, a, b, *, a2=None, bias=None, residual=None, rowbias=None, rows_per_batch=0, out=None,
-             out_dtype=bf16, gelu=False, accum=False, alpha=1.0, reduce_batch=False, tile=0, splitk=0, colstats=False):
+             out_dtype=bf16, gelu=False, accum=False, alpha=1.0, reduce_batch=False, tile=0, splitk=0, colstats=False, panels=None):
+        """panels = (rows, stride, offset, count): only the count x rows logical rows that lie `stride` physical rows apart (the first
+        at `offset`) in a, out and residual are computed / written — e4t_gemm_desc.panel_*; `out` is required and the other rows of
+        it are left untouched."""
         batched = a.dim() == 3
         _rowmajor(a, "gemm A"); _rowmajor(b, "gemm B")
         if batched:
@@ -175,6 +178,11 @@ class HipBackend:
             sA, sB = a.stride(0), b.stride(0)
         else:
             nb, (M, K), N, sA, sB = 1, a.shape, b.shape[0], 0, 0
+        if panels is not None:
+            pr, ps, po, pc = panels
+            assert not batched and out is not None and a.shape[0] >= (pc - 1) * ps + po + pr and out.shape[0] == a.shape[0], "gemm: bad row panels"
+            assert residual is None or residual.shape[0] == a.shape[0]
+            M = pr * pc
         K1 = K
         if a2 is not None:
             _rowmajor(a2, "gemm A2")
@@ -207,6 +215,8 @@ class HipBackend:
         d.strideA, d.strideB = sA, sB
         d.strideC = out.stride(0) if (batched and not reduce_batch) else 0
         d.strideBias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
+        if panels is not None:
+            d.panel_rows, d.panel_stride, d.panel_off = panels[0], panels[1], panels[2]
         pl = self._plan(self.lib.e4t_gemm_plan, d, "e4t_gemm_plan")
         ws = self.workspace(pl.workspace_bytes, a.device) if pl.workspace_bytes else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)

@@ -27,6 +27,10 @@ extern "C" {
 typedef void* e4t_stream; /* hipStream_t */
 
 int e4t_version(void);
+/* bit set of how the library was built: E4T_BUILD_EXPERIMENTAL = the measured-and-rejected GEMM tile variants (codes 3xxx / 4xxx, 5064,
+ * 5128, 256 with 64-wide K-tiles, 640, 1128 / 1160) are compiled in; the default build answers 0 and maps those codes to product tiles */
+#define E4T_BUILD_EXPERIMENTAL 1
+int e4t_build_flags(void);
 const char* e4t_last_error(void);
 /* device sanity: returns 0 and fills arch name (e.g. "gfx950"), CU count */
 int e4t_device_info(char* arch, int arch_len, int* cu_count);
@@ -75,6 +79,11 @@ typedef struct {
   float* colstats;     /* optional out: fp32 [M/32][N][2] = per 32-row block (sum, sum of squares) of every output column, for the
                           GroupNorm that consumes C (e4t_groupnorm_fwd_cs).  Produced only by the single-pass bf16 epilogue
                           (M % 32 == 0, batch 1, no split-K): the call returns 1 when it was written, 0 otherwise */
+  int panel_rows;      /* 0 = dense.  > 0: the M logical rows are panels of panel_rows rows (a multiple of 256, dividing M) that lie */
+  int panel_stride;    /* panel_stride rows apart, the first at row panel_off, in A, C and residual alike: the 16 x 256 patch tokens  */
+  int panel_off;       /* of a [16][257] ViT token matrix (panel_rows 256, stride 257, offset 1) run as 16 full 256-row tiles instead of
+                          17 ragged ones ([3P] open_clip ViT linears, encoder.py:154).  N % 320 == 0, K % 64 == 0; no batch / row bias /
+                          colstats / A2 / accumulate / split-K */
 } e4t_gemm_desc;
 /* returns 0 (or 1, see colstats) on success, a negative errno-style code on error */
 int e4t_gemm_nt(const e4t_gemm_desc* d, e4t_stream stream);

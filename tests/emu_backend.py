@@ -43,7 +43,13 @@ class EmuBackend:
 
     # ------------------------------------------------------------------ GEMM
     def gemm(self, a, b, *, a2=None, bias=None, residual=None, rowbias=None, rows_per_batch=0, out=None,
-             out_dtype=bf16, gelu=False, accum=False, alpha=1.0, reduce_batch=False, tile=0, splitk=0, colstats=False):
+             out_dtype=bf16, gelu=False, accum=False, alpha=1.0, reduce_batch=False, tile=0, splitk=0, colstats=False, panels=None):
+        if panels is not None:      # e4t_gemm_desc.panel_*: only the listed row panels are computed / written
+            pr, ps, po, pc = panels
+            idx = (torch.arange(pc, device=a.device)[:, None] * ps + po + torch.arange(pr, device=a.device)[None, :]).reshape(-1)
+            y = self.gemm(a[idx], b, bias=bias, residual=None if residual is None else residual[idx], out_dtype=out.dtype, gelu=gelu, alpha=alpha)
+            out[idx] = y.to(out.dtype)
+            return out
         A = a.float()
         if a2 is not None:
             A = torch.cat([A, a2.float()], dim=-1)

@@ -12,9 +12,10 @@ from e4t import _C
 lib = _C.load()
 
 
-def gemm_plan(M, N, K, flags=0, tile=0, splitk=0, batch=1, rowbias=False, rows_per_batch=0):
+def gemm_plan(M, N, K, flags=0, tile=0, splitk=0, batch=1, rowbias=False, rows_per_batch=0, panels=(0, 0, 0)):
     d = _C.GemmDesc(M=M, N=N, K=K, K1=K, lda=K, ldb=K, ldc=N, batch=batch, alpha=1.0, flags=flags, tile=tile, splitk=splitk,
-                    rows_per_batch=rows_per_batch, rowbias=(1 << 20) if rowbias else None)      # planner only tests pointers for NULL
+                    rows_per_batch=rows_per_batch, rowbias=(1 << 20) if rowbias else None,      # planner only tests pointers for NULL
+                    panel_rows=panels[0], panel_stride=panels[1], panel_off=panels[2])
     pl = _C.GemmPlan()
     assert lib.e4t_gemm_plan(C.byref(d), C.byref(pl)) == 0, lib.e4t_last_error()
     return pl
@@ -70,12 +71,17 @@ def test_small_map_convs_split_k():
     assert pl.tile == 128 and pl.splitk == 6
 
 
-def test_general_epilogue_demotes_the_wide_tiles():
-    # exact GELU and the per-row row-bias lookup exist as 64 / 128 / 160 instantiations only (gemm_common.h, GENERAL)
+def test_general_epilogue_tiles():
+    # exact GELU and the per-row row-bias lookup (GENERAL epilogue, gemm_common.h) exist as 64 / 128 / 160 / 256 x 256 / 256 x 320 (GEMM only)
+    # instantiations.  The ViT's fc1 at M = 16 x 257 rows is 17 panels of 256: a second round for 16 rows, so it stays on 128 x 128 ...
     assert gemm_plan(4112, 5120, 1280, flags=_C.ACT_GELU).tile == 128
-    assert gemm_plan(65536, 320, 2560, flags=_C.ACT_GELU).tile in (128, 160)
-    assert gemm_plan(65536, 320, 2560, rowbias=True, rows_per_batch=4097).tile in (128, 160)      # rows_per_batch % 32 != 0
+    # ... and goes to the 256 x 320 tile as 16 full panels (the patch tokens; e4t_gemm_desc.panel_*), one round on 256 CUs
+    pl = gemm_plan(4096, 5120, 1280, flags=_C.ACT_GELU, panels=(256, 257, 1))
+    assert (pl.tile, pl.splitk, pl.workspace_bytes) == (2320, 1, 0)
+    assert gemm_plan(65536, 320, 2560, flags=_C.ACT_GELU).tile == 2320
+    assert gemm_plan(65536, 320, 2560, rowbias=True, rows_per_batch=4097).tile == 2320      # rows_per_batch % 32 != 0
     assert gemm_plan(65536, 320, 2560, rowbias=True, rows_per_batch=4096).tile == 2320
+    assert conv_plan(16, 64, 64, 320, 320).tile == 2320
 
 
 def test_a_forced_tile_and_split_are_honoured_or_replaced_by_one_that_fits():
