@@ -538,19 +538,22 @@ __global__ __launch_bounds__(256) void gn_slab_bwd_kernel(GNSrc s, const bf16_t*
   const bf16_t* add = sl.first ? add1 : add2;
   bf16_t* dx = sl.first ? dx1 : dx2;
   const float wa = add ? 1.f : 0.f;
-  int row[NI], qd[NI];
-  bool in[NI];
+  const bf16_t* addp = add ? add : sl.x;          // no shortcut gradient: re-read x (same cache lines as rx), weighted by wa = 0
+  // (per-item offsets are kept as two 32-bit element offsets: the {row, quad, in-range} arrays of the first version were left in
+  // scratch memory by the compiler — 32 / 48 / 96 bytes per lane, profiles/r03_isa_resources.txt — although every index is static)
+  unsigned ox[NI], oc[NI];          // element offset of the quad in x / add / dx (row stride ldx) and its channel offset in the group
   uint2 rx[NI], rd[NI], ra[NI];
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
     const int it = threadIdx.x + k * 256;
-    in[k] = it < items;
-    const int ic = in[k] ? it : items - 1;
-    row[k] = ic / q4; qd[k] = (ic - row[k] * q4) * 4;
-    const size_t pix = (size_t)b * HW + row[k];
-    rx[k] = *(const uint2*)(sl.x + pix * sl.ldx + sl.cx + qd[k]);
-    rd[k] = *(const uint2*)(dy + pix * C + sl.c0 + qd[k]);
-    ra[k] = add ? *(const uint2*)(add + pix * sl.ldx + sl.cx + qd[k]) : rd[k];      // wave-uniform select, no shortcut gradient: ignored
+    const int ic = it < items ? it : items - 1;
+    const int row = ic / q4, qd = (ic - row * q4) * 4;
+    const size_t pix = (size_t)b * HW + row;
+    ox[k] = (unsigned)(pix * sl.ldx + sl.cx + qd);
+    oc[k] = (unsigned)qd;
+    rx[k] = *(const uint2*)(sl.x + ox[k]);
+    rd[k] = *(const uint2*)(dy + pix * C + sl.c0 + qd);
+    ra[k] = *(const uint2*)(addp + ox[k]);                   // unconditional (a conditional load left ra[] in scratch memory: 8 NI bytes per lane)
   }
   const float2 mr = *(const float2*)(mean_rstd + ((size_t)b * G + g) * 2);
   const float mean = mr.x, rstd = mr.y;
@@ -558,12 +561,12 @@ __global__ __launch_bounds__(256) void gn_slab_bwd_kernel(GNSrc s, const bf16_t*
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < NI; ++k) {
-    const float4 g4 = *(const float4*)(gamma + sl.c0 + qd[k]), b4 = *(const float4*)(beta + sl.c0 + qd[k]);
+    const float4 g4 = *(const float4*)(gamma + sl.c0 + oc[k]), b4 = *(const float4*)(beta + sl.c0 + oc[k]);
     const float ga[4] = {g4.x, g4.y, g4.z, g4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
     float f[4], d[4];
     unpack4(rx[k], f);
     unpack4(rd[k], d);
-    const float w = in[k] ? 1.f : 0.f;
+    const float w = (int)(threadIdx.x + k * 256) < items ? 1.f : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       xh[k][j] = (f[j] - mean) * rstd;
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(256) void gn_slab_bwd_kernel(GNSrc s, const bf16_t*
     unpack4(ra[k], a);
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = rstd * (gd[k][j] - g1 - xh[k][j] * g2) + a[j] * wa;
-    if (in[k]) *(uint2*)(dx + ((size_t)b * HW + row[k]) * sl.ldx + sl.cx + qd[k]) = pack4(o);
+    if ((int)(threadIdx.x + k * 256) < items) *(uint2*)(dx + ox[k]) = pack4(o);
   }
 }
 
