@@ -86,7 +86,10 @@ class _ResBlock(nn.Module):
         return Fn.linear(u, self.mlp.c_proj.weight, self.mlp.c_proj.bias, self._pp, residual=h, out_f32=f32s)
 
 
-_VIT_PANELS = os.environ.get("E4T_VIT_PANELS", "1") != "0"      # A/B switch
+# Off by default: measured in the step (round 4, profiles/r04_ab), the 16-panel fc1 on the 256 x 320 tile takes 92 us against 105 us for
+# the 4112-row GEMM on the 128 x 128 tile, and the class-token GEMM that goes with it 33 us — a net loss of 0.6 ms per step on the
+# side stream.  E4T_VIT_PANELS=1 turns it on (the kernel path stays covered by kernel_checks and tests/test_encoder_host_logic.py).
+_VIT_PANELS = os.environ.get("E4T_VIT_PANELS", "0") != "0"
 
 
 def _fc_gelu_frozen(n, fc, prep, B, T):

@@ -298,6 +298,7 @@ class E4TTrainer:
                 self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side), torch.no_grad():
                 pref["latents"] = self.encode_latents(px, pref["vae_eps"])
+        pref["done"] = self._side.record_event()           # the consumer waits for THIS point of the side stream, not for its tail
         if not getattr(self, "_prefetch_warm", False):
             # the first pass of a frozen model also writes its one-time bf16 weight copies (PreparedConv / VAEEncoder._prepare):
             # the main stream may use those copies right away ("start" placement), so it joins the side stream this once
@@ -311,7 +312,7 @@ class E4TTrainer:
         if pref is None or pref["px"] is not pixel_values:
             return None, None
         main = torch.cuda.current_stream()
-        main.wait_stream(self._side)
+        main.wait_event(pref["done"])      # (wait_stream would also wait for a prefetch of the batch after this one, enqueued since)
         for t in (pref["vision"] or ()) + ((pref["latents"],) if pref["latents"] is not None else ()):
             t.record_stream(main)
         return pref["vision"], pref["latents"]

@@ -538,7 +538,7 @@ def check_gemm_races(hip, emu, dev):
         run = lambda: hip.conv3x3(x, w, 16, 32, 32, 32, 32, CONV_S1, tile=code, splitk=sk)
         # the persistent kernels walk K tap-major, every other DMA kernel channel-chunk-major (gemm_common.h, cm_step): a different
         # fp32 summation order, so their bitwise reference is their own first launch (checked against `ref` to tolerance)
-        own = code in (1128, 1160)
+        own = code in (1128, 1160, 5256)        # (5256: 32-wide channel chunks = another fp32 summation order than the 64-wide tiles)
         r = run() if own else ref
         if own:
             out.append((f"conv 32x32 640->640 tile code {code} vs the channel-major kernels", rel(r, ref), TOL2))

@@ -109,6 +109,7 @@ def test_frozen_vit_fc_as_row_panels_matches_the_plain_gemm(emu_fp32, monkeypatc
     nat = E.VisionTransformer(**cfg).requires_grad_(False)
     nat.load_state_dict(ref.state_dict())
     x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    monkeypatch.setattr(E, "_VIT_PANELS", True)          # (off by default: E4T_VIT_PANELS)
     calls = []
     real = E.ops.backend().gemm
     monkeypatch.setattr(E.ops.backend(), "gemm", lambda *a, **k: (calls.append(k.get("panels")), real(*a, **k))[1])
