@@ -141,8 +141,16 @@ def secondary_configs(dev, steps=4, warmup=2):
         px = torch.rand((B, 3, 768, 768), generator=gen, device=dev) * 2 - 1
         ids = torch.randint(0, 49000, (B, 77), generator=gen, device=dev)
         pidx = torch.randint(1, 20, (B,), generator=gen, device=dev)
-        sec = timed(lambda: tr.train_step(px, ids, pidx), steps)
-        out[f"C5_pretrain_sd21_768px_b{B}"] = dict(ms_per_step=sec * 1e3, images_per_s=B / sec, step_mfma_frac_necessary=B / sec * HOT_FLOP_PER_IMAGE["sd21"] / MFMA_PEAK,
+        tr.enable_step_graph(False)
+        eager = timed(lambda: tr.train_step(px, ids, pidx), steps)
+        # the step as ONE replayed HIP graph (E4TTrainer.enable_step_graph: at these batch sizes the eager step is bound by the
+        # host's ~2250 launches, not by the GPU); warm-up = 1 eager step + the capture; bitwise equal to the eager step
+        # (tests/test_model_gpu.py::test_step_graph_replay_equals_eager)
+        graphed = tr.enable_step_graph(True)
+        sec = timed(lambda: tr.train_step(px, ids, pidx), steps) if graphed else eager
+        out[f"C5_pretrain_sd21_768px_b{B}"] = dict(ms_per_step=sec * 1e3, images_per_s=B / sec, step_graph=bool(graphed and tr._step_graphs),
+                                                    ms_per_step_eager_launches=eager * 1e3,
+                                                    step_mfma_frac_necessary=B / sec * HOT_FLOP_PER_IMAGE["sd21"] / MFMA_PEAK,
                                                     step_mfma_frac_whole_step=B / sec * STEP_FLOP_PER_IMAGE["sd21"] / MFMA_PEAK,
                                                     parity_test="tests/test_configs_gpu.py::test_sd2_config_step_matches_oracle[full_sd21]")
     del tr, unet, enc, text, vae
@@ -179,7 +187,7 @@ def main():
     # tokenizer("") of CLIP: BOS + EOS padding (pretrain_e4t.py:565-583); class token "art" = one id of the table
     empty_ids = torch.tensor([[49406] + [49407] * 76], device=dev)
     tr = E4TTrainer(unet, enc, text, vae, lr=1e-6 * args.batch * world, class_token_id=1125, empty_prompt_ids=empty_ids, device=dev)
-    tr_prefetch = (tr.prefetch_mode, tr.prefetch_at)
+    tr_prefetch = tr.prefetch_mode
 
     B = args.batch
     res = 512 if args.model == "sd14" else 768
@@ -326,7 +334,7 @@ def main():
                    config=dict(workload=("SD-1.4 UNet + ViT-H-14 E4T encoder pretrain step, 512px" if args.model == "sd14"
                                          else "SD-2.x UNet (ctx 1024, linear proj) + ViT-H-14 E4T encoder pretrain step, 768px"),
                                per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}", trainable="weight offsets + E4T head (ViT frozen)",
-                               next_batch_prefetch=f"{tr_prefetch[0]} at {tr_prefetch[1]} (E4TTrainer.prefetch: frozen front ends of batch i+1 run under step i's backward)",
+                               next_batch_prefetch=f"{tr_prefetch} (E4TTrainer.prefetch: the frozen front ends of batch i+1 run on a side stream under step i's backward; one pass per step)",
                                frozen_on_stock_torch="none (CLIP text encoder and VAE encoder run on the HIP kernels; only embedding lookups / loss glue are torch ops)", last_loss=float(loss)),
                    roofline=roof, roofline_hbm=roof_hbm, cpu_baseline=cpu, parity=parity, secondary=secondary, comm=comm)
         print(json.dumps(out), flush=True)

@@ -237,8 +237,11 @@ __global__ __launch_bounds__(256) void clip_preprocess_kernel(const float* in, b
 }
 
 // ---- fused AdamW over a flat fp32 buffer (torch.optim.AdamW semantics: decoupled weight decay) ----
+// hyper != nullptr: lr, bc1, bc2_sqrt and the gradient scale are read from DEVICE memory ([4] floats) instead of the launch arguments,
+// so that a captured (hipGraph) training step replays with the values of ITS step (e4t_adamw_hyper); same arithmetic either way.
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
-                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float gscale, const float* hyper) {
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; gscale = hyper[3]; }
   for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * 1024) {
     if (i + 4 <= n) {
       float4 P = *(float4*)(p + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
@@ -393,7 +396,17 @@ extern "C" int e4t_adamw(float* p, const float* g, float* m, float* v, long long
   E4T_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adamw: buffers must be 16-B aligned");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = sqrtf(1.f - powf(beta2, (float)step));
   E4T_LOG_LAUNCH("adamw_kernel|n%lld|%.0f|0", (long long)n, 28.0 * (double)n);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale,
+                     (const float*)nullptr);
+  E4T_CHECK_LAUNCH("adamw_kernel");
+  return 0;
+}
+extern "C" int e4t_adamw_hyper(float* p, const float* g, float* m, float* v, long long n, const float* hyper_dev, float beta1, float beta2, float eps,
+                               float weight_decay, e4t_stream s) {
+  E4T_REQUIRE(p && g && m && v && hyper_dev && n > 0, "adamw_hyper: bad arguments");
+  E4T_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)hyper_dev) & 15) == 0, "adamw_hyper: buffers must be 16-B aligned");
+  E4T_LOG_LAUNCH("adamw_kernel|n%lld|%.0f|0", (long long)n, 28.0 * (double)n);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, 1.f, hyper_dev);
   E4T_CHECK_LAUNCH("adamw_kernel");
   return 0;
 }

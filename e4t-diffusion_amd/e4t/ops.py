@@ -515,6 +515,11 @@ class HipBackend:
         self._timed("adamw", 0.0, lambda: _C.check(self.lib.e4t_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step,
                                                                       grad_scale, _stream()), "e4t_adamw"), 28.0 * p.numel())
 
+    def adamw_hyper(self, p, g, m, v, hyper, beta1, beta2, eps, wd):
+        """the same update with {lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale} read from the device tensor `hyper` (fp32 [4]): replayable"""
+        self._timed("adamw", 0.0, lambda: _C.check(self.lib.e4t_adamw_hyper(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper), beta1, beta2, eps, wd,
+                                                                            _stream()), "e4t_adamw_hyper"), 28.0 * p.numel())
+
     def im2col_T(self, x, B, Hin, Win, Hout, Wout, mode):
         """bf16 [B*Hin*Win, C] -> [9*C, ld] with ld = B*Hout*Wout rounded up to 8 (zero padded): B operand of the wgrad GEMM"""
         assert x.is_contiguous()

@@ -83,14 +83,19 @@ class E4TTrainer:
         self.share_prefix = True     # compute the context-independent UNet prefix once for the step's two passes
         self.overlap_vision = os.environ.get("E4T_OVERLAP_VISION", "1") != "0"
         self._side, self._vision = None, None
-        # Next-batch prefetch of the step's FROZEN, weight-independent front ends (prefetch()): "vit" = CLIP-ViT tokens, "vit+vae" = also
-        # the VAE latents; started on the side stream where E4T_PREFETCH_AT says ("bwd": when the current step's backward begins,
-        # "start": at the start of the current step).  "0" = off: both run inside their own step (round 3 behaviour).
-        self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit")
-        self.prefetch_at = os.environ.get("E4T_PREFETCH_AT", "bwd")
+        # Next-batch prefetch of the step's FROZEN, weight-independent front ends (prefetch()): "vit+vae" (default) = CLIP-ViT tokens and VAE
+        # latents of batch i+1 are computed on the side stream under step i's backward, "vit" = the tokens only, "0" = off: both run
+        # inside their own step (round 3 behaviour).  Measured (round 4, B = 16, one box): off 106.0, vit 105.7, vit+vae 102.6 ms per step.
+        self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit+vae")
         self._next_px, self._pref = None, None
         self._main_prio = int(os.environ["E4T_MAIN_PRIORITY"]) if os.environ.get("E4T_MAIN_PRIORITY") else None
         self._main_stream = None
+        # whole-step HIP graph (enable_step_graph): signature -> captured graph + its static tensors; device copy of AdamW's
+        # step-dependent scalars
+        self._step_graph_on = False
+        self._step_graphs, self._seen_sigs = {}, set()
+        self._hyper = self._hyper_host = None
+        self._capturing = False
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         # E4T_FORCE_COMM=1: run the collective path even in a 1-rank group (exercises the RCCL calls / stream ordering on one GPU)
@@ -278,8 +283,6 @@ class E4TTrainer:
         """Announce the images of the NEXT train_step (the same tensor object must then be passed to it).  No-op when the ViT is
         trainable, on CPU, or with E4T_PREFETCH=0."""
         self._next_px = pixel_values_next if (self.prefetch_mode != "0" and pixel_values_next is not None and pixel_values_next.is_cuda) else None
-        if self._next_px is not None and self.prefetch_at == "start":
-            self._start_prefetch()
 
     def _start_prefetch(self):
         px, self._next_px = self._next_px, None
@@ -300,8 +303,8 @@ class E4TTrainer:
                 pref["latents"] = self.encode_latents(px, pref["vae_eps"])
         pref["done"] = self._side.record_event()           # the consumer waits for THIS point of the side stream, not for its tail
         if not getattr(self, "_prefetch_warm", False):
-            # the first pass of a frozen model also writes its one-time bf16 weight copies (PreparedConv / VAEEncoder._prepare):
-            # the main stream may use those copies right away ("start" placement), so it joins the side stream this once
+            # the first pass of a frozen model also writes its one-time bf16 weight copies (PreparedConv / VAEEncoder._prepare): a
+            # main-stream consumer of those copies must not overtake them, so the main stream joins the side stream this once
             torch.cuda.current_stream().wait_stream(self._side)
             self._prefetch_warm = True
         self._pref = pref
@@ -419,10 +422,84 @@ class E4TTrainer:
         self.flat.grad.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))
 
     def optimizer_step(self):
-        self.step_count += 1
-        ops.backend().adamw(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                            self.eps, self.wd, self.step_count, 1.0 / self.world)
+        if self._hyper is not None:
+            # step-graph mode: lr / bias corrections / gradient scale live in device memory (refreshed by the host before every step, eager
+            # or replayed), so the captured launch is the same launch at every step
+            if not self._capturing:
+                self.step_count += 1
+                self._write_hyper()
+            ops.backend().adamw_hyper(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self._hyper, self.betas[0], self.betas[1],
+                                      self.eps, self.wd)
+        else:
+            self.step_count += 1
+            ops.backend().adamw(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
+                                self.eps, self.wd, self.step_count, 1.0 / self.world)
         ops.bump_weights_epoch()
+
+    # ---- the whole step as ONE HIP graph ----------------------------------------------------------------------------------------
+    # A step is ~2250 launches (SD-1.4) issued from Python at ~20 us each.  At B = 16 the GPU needs 100+ ms for them and the host keeps
+    # ahead; at small batches (BASELINE configs[4] runs SD-2.x at B = 1 per GPU: 17 ms of kernels) the step is host-bound (48 ms).  Shapes
+    # are static per (config, batch): the step — VAE encode, both UNet passes, encoder, text encoder, backward, clip, AdamW, zero-grad — is
+    # captured once per input signature with torch.cuda.graph and replayed; inputs go through static buffers, the random draws are
+    # torch's graph-safe Philox draws, AdamW's step-dependent scalars are read from device memory (e4t_adamw_hyper).  One process per
+    # GPU without a communicator only (the all-reduce hooks live in Python); the first step of a signature runs eagerly (it is also the
+    # warm-up every lazy initialisation needs), the second one captures and replays.
+    def enable_step_graph(self, on=True):
+        if on and (self._comm or not self.flat.data.is_cuda or self.text_trainable):
+            return False
+        self._step_graph_on = bool(on)
+        if on and self._hyper is None:
+            self._hyper = torch.zeros(4, dtype=f32, device=self.device)
+            self._hyper_host = torch.zeros(4, dtype=f32).pin_memory()
+        if not on:
+            self._hyper = self._hyper_host = None
+        return self._step_graph_on
+
+    def _write_hyper(self):
+        import ctypes
+        libm = getattr(E4TTrainer, "_libm", None)
+        if libm is None:
+            libm = E4TTrainer._libm = ctypes.CDLL("libm.so.6")
+            libm.powf.restype, libm.powf.argtypes = ctypes.c_float, [ctypes.c_float, ctypes.c_float]
+            libm.sqrtf.restype, libm.sqrtf.argtypes = ctypes.c_float, [ctypes.c_float]
+        f = lambda x: ctypes.c_float(x).value
+        t = float(self.step_count)
+        # exactly e4t_adamw's host arithmetic (fp32 powf / sqrtf): 1 - beta1^t, sqrt(1 - beta2^t)
+        self._hyper_host[0] = self.lr
+        self._hyper_host[1] = f(1.0 - libm.powf(self.betas[0], t))
+        self._hyper_host[2] = libm.sqrtf(f(1.0 - libm.powf(self.betas[1], t)))
+        self._hyper_host[3] = 1.0 / self.world
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def _graphed_step(self, pixel_values, input_ids, placeholder_idx, noise, timesteps, vae_eps, latents):
+        ins = dict(pixel_values=pixel_values, input_ids=input_ids, placeholder_idx=placeholder_idx, noise=noise, timesteps=timesteps,
+                   vae_eps=vae_eps, latents=latents)
+        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items() if v is not None)
+        ent = self._step_graphs.get(sig)
+        if ent is None:
+            if sig not in self._seen_sigs:            # first step of this signature: eager (= the warm-up)
+                self._seen_sigs.add(sig)
+                return self._train_step(**ins)
+            static = {k: v.clone() for k, v in ins.items() if v is not None}
+            g = torch.cuda.CUDAGraph()
+            self._capturing = True
+            try:
+                with ops.capture_guard():
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g):
+                        out = self._train_step(**{k: static.get(k) for k in ins})
+            finally:
+                self._capturing = False
+            ent = self._step_graphs[sig] = (g, static, out)
+        g, static, out = ent
+        for k, v in static.items():
+            if ins[k].data_ptr() != v.data_ptr():
+                v.copy_(ins[k], non_blocking=True)
+        self.step_count += 1
+        self._write_hyper()
+        g.replay()
+        ops.bump_weights_epoch()
+        return tuple(o.clone() for o in out)
 
     def zero_grad(self):
         self.flat.grad.zero_()
@@ -446,6 +523,11 @@ class E4TTrainer:
     def train_step(self, *args, **kw):
         """One training step (see _train_step).  E4T_MAIN_PRIORITY=<int> (e.g. -1) runs it on a stream of that priority, joined
         with the caller's stream on both sides, so that side-stream work (prefetch) only takes what this stream leaves idle."""
+        if self._step_graph_on and kw.get("sync", True) and kw.get("loss_scale", 1.0) == 1.0 and self._next_px is None and self._pref is None:
+            names = ("pixel_values", "input_ids", "placeholder_idx", "noise", "timesteps", "vae_eps", "latents")
+            a = dict(zip(names, args))
+            a.update({k: v for k, v in kw.items() if k in names})
+            return self._graphed_step(*(a.get(k) for k in names))
         if self._main_prio is None or not self.flat.data.is_cuda:
             return self._train_step(*args, **kw)
         caller = torch.cuda.current_stream()

@@ -275,6 +275,11 @@ int e4t_im2col_T(const void* x, void* out, int B, int Hin, int Win, int C, int H
 int e4t_im2col(const void* x, void* out, int B, int Hin, int Win, int C, int Hout, int Wout, int mode, e4t_stream stream);
 int e4t_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int step, float grad_scale, e4t_stream stream);                                        /* pretrain_e4t.py:387-392,652 */
+/* The same update with the step-dependent scalars in DEVICE memory: hyper_dev = float[4] {lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale}
+ * (16-byte aligned).  A training step captured into a hipGraph (E4TTrainer step graph) replays this launch unchanged and the host
+ * refreshes the four floats before each replay; the arithmetic is that of e4t_adamw with the same values. */
+int e4t_adamw_hyper(float* p, const float* g, float* m, float* v, long long n, const float* hyper_dev, float beta1, float beta2, float eps,
+                    float weight_decay, e4t_stream stream);
 int e4t_sumsq_partial(const float* g, long long n, float* partial, int nblocks, e4t_stream stream);                      /* tuning_e4t.py:335 grad-norm */
 
 /* ---------------------------------------------------------------- probe (probe.hip) ---------- */

@@ -137,8 +137,8 @@ def test_training_step_is_bitwise_deterministic(hip_env):
     assert torch.equal(p0, p1), float((p0 - p1).abs().max())
 
 
-@pytest.mark.parametrize("mode,at", [("vit", "bwd"), ("vit+vae", "bwd")])
-def test_next_batch_prefetch_is_result_preserving(hip_env, mode, at):
+@pytest.mark.parametrize("mode", ["vit", "vit+vae"])
+def test_next_batch_prefetch_is_result_preserving(hip_env, mode):
     """E4TTrainer.prefetch(): the frozen CLIP-ViT (and VAE encoder) of batch i+1 run on the side stream under step i — same
     kernels on the same inputs, so losses and every trained parameter after three steps must equal the un-prefetched run bit for
     bit (the VAE's sampling noise is drawn in step order in both)."""
@@ -153,7 +153,7 @@ def test_next_batch_prefetch_is_result_preserving(hip_env, mode, at):
                 torch.randint(1, 99, (B, 9), generator=g)) for _ in range(3)]
     pidx = torch.tensor([2, 4], device=dev)
 
-    def run(mode, at):
+    def run(mode):
         _, _, n_unet, n_enc, text_t = build(seed=0)
         text = CLIPTextModel(**TEXT_CFG).requires_grad_(False)
         text.load_state_dict(text_t.state_dict())
@@ -161,7 +161,7 @@ def test_next_batch_prefetch_is_result_preserving(hip_env, mode, at):
         vae = VAEEncoder(block_out_channels=(64, 128, 128, 128)).requires_grad_(False)
         n_unet.to(dev), n_enc.to(dev), text.to(dev), vae.to(dev)
         tr = E4TTrainer(n_unet, n_enc, text, vae=vae, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev), device=dev)
-        tr.prefetch_mode, tr.prefetch_at = mode, at
+        tr.prefetch_mode = mode
         torch.manual_seed(5)
         dbatches = [tuple(t.to(dev) for t in b) for b in batches]
         losses = []
@@ -173,7 +173,50 @@ def test_next_batch_prefetch_is_result_preserving(hip_env, mode, at):
         torch.cuda.synchronize()
         return torch.stack(losses), tr.flat.data.detach().cpu().clone()
 
-    l0, p0 = run("0", "bwd")
-    l1, p1 = run(mode, at)
+    l0, p0 = run("0")
+    l1, p1 = run(mode)
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+
+
+@pytest.mark.parametrize("given", [True, False], ids=["inputs_given", "draws_inside"])
+def test_step_graph_replay_equals_eager(hip_env, given):
+    """E4TTrainer.enable_step_graph(): the whole training step (VAE encode, both UNet passes, encoder, text encoder, backward, AdamW,
+    zero-grad) captured into one HIP graph and replayed.  Same kernels in the same order on the same inputs: losses and every trained
+    parameter after four steps (1 eager warm-up, 1 capture + replay, 2 replays) must equal the eager run bit for bit — with the noise /
+    timesteps handed in, and with torch's graph-safe Philox draws inside the graph."""
+    from test_train_step_host_logic import TEXT_CFG, build
+    from e4t.text import CLIPTextModel
+    from e4t.trainer import E4TTrainer
+    from e4t.vae import VAEEncoder
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    B = 2
+    batches = [(torch.rand(B, 3, 128, 128, generator=g) * 2 - 1, torch.randn(B, 4, 16, 16, generator=g), torch.randint(0, 1000, (B,), generator=g),
+                torch.randint(1, 99, (B, 9), generator=g)) for _ in range(4)]
+    pidx = torch.tensor([2, 4], device=dev)
+
+    def run(graph):
+        _, _, n_unet, n_enc, text_t = build(seed=0)
+        text = CLIPTextModel(**TEXT_CFG).requires_grad_(False)
+        text.load_state_dict(text_t.state_dict())
+        torch.manual_seed(11)
+        vae = VAEEncoder(block_out_channels=(64, 128, 128, 128)).requires_grad_(False)
+        n_unet.to(dev), n_enc.to(dev), text.to(dev), vae.to(dev)
+        tr = E4TTrainer(n_unet, n_enc, text, vae=vae, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev), device=dev)
+        assert tr.enable_step_graph(True)
+        tr._step_graph_on = graph                  # the eager leg keeps the device-side AdamW scalars, launches from the host
+        torch.manual_seed(5)
+        losses = []
+        for px, noise, t, ids in batches:
+            kw = dict(noise=noise.to(dev), timesteps=t.to(dev)) if given else {}
+            out = tr.train_step(px.to(dev), ids.to(dev), pidx, **kw)
+            losses.append(torch.stack([o.detach().float() for o in out]).cpu())
+        torch.cuda.synchronize()
+        return torch.stack(losses), tr.flat.data.detach().cpu().clone(), len(tr._step_graphs)
+
+    l0, p0, n0 = run(False)
+    l1, p1, n1 = run(True)
+    assert n0 == 0 and n1 == 1
     assert torch.equal(l0, l1), (l0, l1)
     assert torch.equal(p0, p1), float((p0 - p1).abs().max())

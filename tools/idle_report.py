@@ -1,6 +1,6 @@
 """From a rocprofv3 kernel trace of bench.py: how much of the timed region is the GPU idle (no kernel of any stream running), per
 phase of the step — tells whether the step is kernel-bound or launch-bound.  usage: idle_report.py TRACE_DIR_OR_CSV [n_last_steps]"""
-import csv, glob, os, re, sys
+import collections, csv, glob, os, re, sys
 path = sys.argv[1]
 if os.path.isdir(path):
     path = max(glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getsize)
@@ -34,11 +34,37 @@ busy += cur_e - cur_s
 wall = t1 - t0
 print(f"{n} steps: wall {wall / n / 1e6:.2f} ms/step, some kernel running {busy / n / 1e6:.2f} ms/step, idle {(wall - busy) / n / 1e6:.2f} ms/step ({100 * (wall - busy) / wall:.1f} %), "
       f"kernels/step {len(sel) / n:.0f}, sum of kernel durations {sum(e - s for s, e, _, _ in sel) / n / 1e6:.2f} ms/step")
-import collections
 by = collections.Counter()
 cnt = collections.Counter()
 for g, name in gaps:
     by[name] += g; cnt[name] += 1
+# per stream (queue): busy time, and how much of it ran while a kernel of ANOTHER stream was running too
+qs = collections.defaultdict(list)
+for s_, e_, name, q in sel:
+    qs[q].append((s_, e_))
+def union(iv):
+    out, cs, ce = [], None, None
+    for a, b in sorted(iv):
+        if ce is None or a > ce:
+            if ce is not None: out.append((cs, ce))
+            cs, ce = a, b
+        else:
+            ce = max(ce, b)
+    if ce is not None: out.append((cs, ce))
+    return out
+def overlap(u1, u2):
+    i = j = 0; tot = 0
+    while i < len(u1) and j < len(u2):
+        a, b = max(u1[i][0], u2[j][0]), min(u1[i][1], u2[j][1])
+        if b > a: tot += b - a
+        if u1[i][1] < u2[j][1]: i += 1
+        else: j += 1
+    return tot
+un = {q: union(v) for q, v in qs.items()}
+for q, u in sorted(un.items(), key=lambda kv: -sum(b - a for a, b in kv[1])):
+    busy_q = sum(b - a for a, b in u)
+    others = union([iv for q2, u2 in un.items() if q2 != q for iv in u2])
+    print(f"stream {q}: {len(qs[q]) / n:.0f} kernels/step, busy {busy_q / n / 1e6:.2f} ms/step, of which concurrent with another stream {overlap(u, others) / n / 1e6:.2f} ms/step")
 print("idle time in front of (kernel that ended the gap), top 25, per step:")
 for name, g in by.most_common(25):
     print(f"  {g / n / 1e3:8.1f} us  {cnt[name] / n:6.1f} gaps  avg {g / cnt[name] / 1e3:6.1f} us  {name[:70]}")
