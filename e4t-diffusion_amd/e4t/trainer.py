@@ -87,7 +87,10 @@ class E4TTrainer:
         # latents of batch i+1 are computed on the side stream under step i's backward, "vit" = the tokens only, "0" = off: both run
         # inside their own step (round 3 behaviour).  Measured (round 4, B = 16, one box): off 106.0, vit 105.7, vit+vae 102.6 ms per step.
         self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit+vae")
-        self._next_px, self._pref = None, None
+        # where the side work of batch i+1 starts: "start" = together with step i (it then has the whole step to finish in, and step
+        # i+1 never waits for it), "bwd" = when step i's backward begins
+        self.prefetch_at = os.environ.get("E4T_PREFETCH_AT", "start")
+        self._next_px, self._pref = None, {}          # announced batch; finished / running prefetches by id(pixel tensor)
         self._main_prio = int(os.environ["E4T_MAIN_PRIORITY"]) if os.environ.get("E4T_MAIN_PRIORITY") else None
         self._main_stream = None
         # whole-step HIP graph (enable_step_graph): signature -> captured graph + its static tensors; device copy of AdamW's
@@ -279,10 +282,13 @@ class E4TTrainer:
     # levels leave CUs idle and the GroupNorm / LayerNorm / GEGLU / AdamW passes leave the matrix cores idle, while under the
     # forward the side stream mostly displaced main-stream work (round 3: -2.4 of the ViT's ~10 ms).  Every step still computes one
     # ViT (+ VAE) pass — for the batch after it — so the work per step is unchanged; nothing is cached across steps.
-    def prefetch(self, pixel_values_next):
+    def prefetch(self, pixel_values_next, vae_eps=None):
         """Announce the images of the NEXT train_step (the same tensor object must then be passed to it).  No-op when the ViT is
         trainable, on CPU, or with E4T_PREFETCH=0."""
         self._next_px = pixel_values_next if (self.prefetch_mode != "0" and pixel_values_next is not None and pixel_values_next.is_cuda) else None
+        self._next_eps = vae_eps              # the VAE's sampling noise for that batch (tests); None = drawn when the prefetch starts
+        if self._next_px is not None and self.prefetch_at == "start":
+            self._start_prefetch()
 
     def _start_prefetch(self):
         px, self._next_px = self._next_px, None
@@ -291,7 +297,8 @@ class E4TTrainer:
         pref = dict(px=px, vision=None, latents=None)
         if "vae" in self.prefetch_mode and self.vae is not None:
             hl, wl = px.shape[2] // 8, px.shape[3] // 8
-            pref["vae_eps"] = torch.randn((px.shape[0], 4, hl, wl), device=px.device)      # drawn on the main stream, in step order
+            eps, self._next_eps = getattr(self, "_next_eps", None), None
+            pref["vae_eps"] = eps if eps is not None else torch.randn((px.shape[0], 4, hl, wl), device=px.device)      # drawn on the main stream
         pref["vision"] = self._launch_vision(px)              # (waits for the main stream's position: the start of the backward)
         if pref["vision"] is None and "vae_eps" not in pref:
             return
@@ -307,11 +314,13 @@ class E4TTrainer:
             # main-stream consumer of those copies must not overtake them, so the main stream joins the side stream this once
             torch.cuda.current_stream().wait_stream(self._side)
             self._prefetch_warm = True
-        self._pref = pref
+        if len(self._pref) > 4:                 # announced batches that were never trained on
+            self._pref.pop(next(iter(self._pref)))
+        self._pref[id(px)] = pref
 
     def _take_prefetched(self, pixel_values):
         """(vision, latents) computed for exactly this tensor by the previous step, else (None, None); joins the side stream"""
-        pref, self._pref = self._pref, None
+        pref = self._pref.pop(id(pixel_values), None)
         if pref is None or pref["px"] is not pixel_values:
             return None, None
         main = torch.cuda.current_stream()
@@ -523,7 +532,7 @@ class E4TTrainer:
     def train_step(self, *args, **kw):
         """One training step (see _train_step).  E4T_MAIN_PRIORITY=<int> (e.g. -1) runs it on a stream of that priority, joined
         with the caller's stream on both sides, so that side-stream work (prefetch) only takes what this stream leaves idle."""
-        if self._step_graph_on and kw.get("sync", True) and kw.get("loss_scale", 1.0) == 1.0 and self._next_px is None and self._pref is None:
+        if self._step_graph_on and kw.get("sync", True) and kw.get("loss_scale", 1.0) == 1.0 and self._next_px is None and not self._pref:
             names = ("pixel_values", "input_ids", "placeholder_idx", "noise", "timesteps", "vae_eps", "latents")
             a = dict(zip(names, args))
             a.update({k: v for k, v in kw.items() if k in names})
@@ -547,7 +556,7 @@ class E4TTrainer:
         and with ``sync=True`` (same loss_scale) for the k-th."""
         dev = self.device
         B = pixel_values.shape[0]
-        pre_vision, pre_latents = self._take_prefetched(pixel_values) if self._pref is not None else (None, None)
+        pre_vision, pre_latents = self._take_prefetched(pixel_values) if self._pref else (None, None)
         if pre_vision is not None:
             self._vision = pre_vision
         if latents is None and pre_latents is not None and vae_eps is None:

@@ -137,11 +137,11 @@ def test_training_step_is_bitwise_deterministic(hip_env):
     assert torch.equal(p0, p1), float((p0 - p1).abs().max())
 
 
-@pytest.mark.parametrize("mode", ["vit", "vit+vae"])
-def test_next_batch_prefetch_is_result_preserving(hip_env, mode):
+@pytest.mark.parametrize("mode,at", [("vit", "bwd"), ("vit+vae", "bwd"), ("vit+vae", "start")])
+def test_next_batch_prefetch_is_result_preserving(hip_env, mode, at):
     """E4TTrainer.prefetch(): the frozen CLIP-ViT (and VAE encoder) of batch i+1 run on the side stream under step i — same
     kernels on the same inputs, so losses and every trained parameter after three steps must equal the un-prefetched run bit for
-    bit (the VAE's sampling noise is drawn in step order in both)."""
+    bit.  (The VAE's sampling noise is handed in: the "start" placement draws it one step earlier than the un-prefetched run does.)"""
     from test_train_step_host_logic import TEXT_CFG, build
     from e4t.text import CLIPTextModel
     from e4t.trainer import E4TTrainer
@@ -150,10 +150,10 @@ def test_next_batch_prefetch_is_result_preserving(hip_env, mode):
     g = torch.Generator().manual_seed(7)
     B = 2
     batches = [(torch.rand(B, 3, 128, 128, generator=g) * 2 - 1, torch.randn(B, 4, 16, 16, generator=g), torch.randint(0, 1000, (B,), generator=g),
-                torch.randint(1, 99, (B, 9), generator=g)) for _ in range(3)]
+                torch.randint(1, 99, (B, 9), generator=g), torch.randn(B, 4, 16, 16, generator=g)) for _ in range(3)]
     pidx = torch.tensor([2, 4], device=dev)
 
-    def run(mode):
+    def run(mode, at):
         _, _, n_unet, n_enc, text_t = build(seed=0)
         text = CLIPTextModel(**TEXT_CFG).requires_grad_(False)
         text.load_state_dict(text_t.state_dict())
@@ -161,20 +161,23 @@ def test_next_batch_prefetch_is_result_preserving(hip_env, mode):
         vae = VAEEncoder(block_out_channels=(64, 128, 128, 128)).requires_grad_(False)
         n_unet.to(dev), n_enc.to(dev), text.to(dev), vae.to(dev)
         tr = E4TTrainer(n_unet, n_enc, text, vae=vae, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev), device=dev)
-        tr.prefetch_mode = mode
-        torch.manual_seed(5)
+        tr.prefetch_mode, tr.prefetch_at = mode, at
         dbatches = [tuple(t.to(dev) for t in b) for b in batches]
-        losses = []
-        for i, (px, noise, t, ids) in enumerate(dbatches):
+        losses, used = [], 0
+        for i, (px, noise, t, ids, eps) in enumerate(dbatches):
             if i + 1 < len(dbatches):
-                tr.prefetch(dbatches[i + 1][0])
-            out = tr.train_step(px, ids, pidx, noise=noise, timesteps=t)
+                tr.prefetch(dbatches[i + 1][0], vae_eps=dbatches[i + 1][4])
+            took = bool(tr._pref.get(id(px))) and mode != "0"
+            used += took
+            # a step whose latents were prefetched must not be handed vae_eps (that asks for its own VAE pass)
+            out = tr.train_step(px, ids, pidx, noise=noise, timesteps=t, vae_eps=None if (took and "vae" in mode) else eps)
             losses.append(torch.stack([o.detach().float() for o in out]).cpu())
         torch.cuda.synchronize()
-        return torch.stack(losses), tr.flat.data.detach().cpu().clone()
+        return torch.stack(losses), tr.flat.data.detach().cpu().clone(), used
 
-    l0, p0 = run("0")
-    l1, p1 = run(mode)
+    l0, p0, u0 = run("0", "bwd")
+    l1, p1, u1 = run(mode, at)
+    assert u0 == 0 and u1 == len(batches) - 1          # every step after the first consumed what the step before it prefetched
     assert torch.equal(l0, l1), (l0, l1)
     assert torch.equal(p0, p1), float((p0 - p1).abs().max())
 
