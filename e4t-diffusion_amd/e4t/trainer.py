@@ -89,7 +89,8 @@ class E4TTrainer:
         self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit+vae")
         # where the side work of batch i+1 starts: "start" = together with step i (it then has the whole step to finish in, and step
         # i+1 never waits for it), "bwd" = when step i's backward begins
-        self.prefetch_at = os.environ.get("E4T_PREFETCH_AT", "start")
+        self.prefetch_at = os.environ.get("E4T_PREFETCH_AT", "bwd")
+        self.prepare_ahead = os.environ.get("E4T_PREPARE_AHEAD", "1") != "0"      # A/B switch (_prepare_next_step)
         self._next_px, self._pref = None, {}          # announced batch; finished / running prefetches by id(pixel tensor)
         self._main_prio = int(os.environ["E4T_MAIN_PRIORITY"]) if os.environ.get("E4T_MAIN_PRIORITY") else None
         self._main_stream = None
@@ -299,7 +300,8 @@ class E4TTrainer:
             hl, wl = px.shape[2] // 8, px.shape[3] // 8
             eps, self._next_eps = getattr(self, "_next_eps", None), None
             pref["vae_eps"] = eps if eps is not None else torch.randn((px.shape[0], 4, hl, wl), device=px.device)      # drawn on the main stream
-        pref["vision"] = self._launch_vision(px)              # (waits for the main stream's position: the start of the backward)
+        if "vit" in self.prefetch_mode:
+            pref["vision"] = self._launch_vision(px)          # (waits for the main stream's position: the start of the backward)
         if pref["vision"] is None and "vae_eps" not in pref:
             return
         if "vae_eps" in pref:
@@ -513,6 +515,21 @@ class E4TTrainer:
     def zero_grad(self):
         self.flat.grad.zero_()
 
+    def _prepare_next_step(self):
+        """What the next step needs of the parameters just updated and nothing else — W_eff = W o (1 + offsets) of both weight-offset banks
+        and the bf16 compute copies of the E4T head — evaluated NOW, at the tail of this step, instead of lazily at the head of the next
+        one.  With the next batch's frozen encoders prefetched on the side stream (prefetch()), the step boundary is where the main
+        stream waits for them (profiles/r04_idle_report.txt: ~16 ms per step in which only the side stream runs): this work fills it."""
+        for bank in getattr(self.unet, "wo_banks", ()):
+            bank.prepare_ahead()
+        enc = self.encoder
+        for name in ("_p0", "_p2", "_pf", "_pl"):
+            prep = getattr(enc, name, None)
+            if prep is not None and prep.weight.requires_grad:
+                prep.get()
+        if hasattr(enc, "_stack_prepared") and enc.first_linears[0].weight.requires_grad:
+            enc._stack_prepared()
+
     # ---- training state (accelerator.save_state / load_state of the reference, pretrain_e4t.py:536-558,659-663) ----------
     def state_dict(self):
         return dict(params=self.flat.data.detach().cpu().clone(), exp_avg=self.exp_avg.cpu().clone(), exp_avg_sq=self.exp_avg_sq.cpu().clone(),
@@ -591,6 +608,8 @@ class E4TTrainer:
         self.clip_grad_norm()
         self.optimizer_step()
         self.zero_grad()
+        if self.prepare_ahead and not self.tuning:
+            self._prepare_next_step()
         if self.world > 1 and self.replica_check_every > 0 and self.step_count % self.replica_check_every == 0:
             self.check_replicas()
         return loss.detach(), loss_diff.detach(), loss_reg.detach()
