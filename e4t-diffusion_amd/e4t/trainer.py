@@ -84,13 +84,12 @@ class E4TTrainer:
         self.overlap_vision = os.environ.get("E4T_OVERLAP_VISION", "1") != "0"
         self._side, self._vision = None, None
         # Next-batch prefetch of the step's FROZEN, weight-independent front ends (prefetch()): "vit+vae" (default) = CLIP-ViT tokens and VAE
-        # latents of batch i+1 are computed on the side stream under step i's backward, "vit" = the tokens only, "0" = off: both run
-        # inside their own step (round 3 behaviour).  Measured (round 4, B = 16, one box): off 106.0, vit 105.7, vit+vae 102.6 ms per step.
+        # latents of batch i+1 are computed on the side stream under step i's backward; "vit" / "vae" = one of them (the ViT then runs
+        # in its own step, on the side stream under the UNet encoder pass); "0" = off (round 3 behaviour).  Measured (round 4, B = 16,
+        # one box, +-0.1 ms run to run): off 104.6, vae 102.8, vit+vae 102.2 ms per step.  Starting the side work with the step instead of
+        # with its backward measured 101.1-101.5 against 100.3 ms (another box) and was removed; so was evaluating the next step's W_eff
+        # at the tail of the step (102.13 / 102.23 against 102.12 / 102.35 ms).
         self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit+vae")
-        # where the side work of batch i+1 starts: "start" = together with step i (it then has the whole step to finish in, and step
-        # i+1 never waits for it), "bwd" = when step i's backward begins
-        self.prefetch_at = os.environ.get("E4T_PREFETCH_AT", "bwd")
-        self.prepare_ahead = os.environ.get("E4T_PREPARE_AHEAD", "1") != "0"      # A/B switch (_prepare_next_step)
         self._next_px, self._pref = None, {}          # announced batch; finished / running prefetches by id(pixel tensor)
         self._main_prio = int(os.environ["E4T_MAIN_PRIORITY"]) if os.environ.get("E4T_MAIN_PRIORITY") else None
         self._main_stream = None
@@ -288,8 +287,6 @@ class E4TTrainer:
         trainable, on CPU, or with E4T_PREFETCH=0."""
         self._next_px = pixel_values_next if (self.prefetch_mode != "0" and pixel_values_next is not None and pixel_values_next.is_cuda) else None
         self._next_eps = vae_eps              # the VAE's sampling noise for that batch (tests); None = drawn when the prefetch starts
-        if self._next_px is not None and self.prefetch_at == "start":
-            self._start_prefetch()
 
     def _start_prefetch(self):
         px, self._next_px = self._next_px, None
@@ -515,21 +512,6 @@ class E4TTrainer:
     def zero_grad(self):
         self.flat.grad.zero_()
 
-    def _prepare_next_step(self):
-        """What the next step needs of the parameters just updated and nothing else — W_eff = W o (1 + offsets) of both weight-offset banks
-        and the bf16 compute copies of the E4T head — evaluated NOW, at the tail of this step, instead of lazily at the head of the next
-        one.  With the next batch's frozen encoders prefetched on the side stream (prefetch()), the step boundary is where the main
-        stream waits for them (profiles/r04_idle_report.txt: ~16 ms per step in which only the side stream runs): this work fills it."""
-        for bank in getattr(self.unet, "wo_banks", ()):
-            bank.prepare_ahead()
-        enc = self.encoder
-        for name in ("_p0", "_p2", "_pf", "_pl"):
-            prep = getattr(enc, name, None)
-            if prep is not None and prep.weight.requires_grad:
-                prep.get()
-        if hasattr(enc, "_stack_prepared") and enc.first_linears[0].weight.requires_grad:
-            enc._stack_prepared()
-
     # ---- training state (accelerator.save_state / load_state of the reference, pretrain_e4t.py:536-558,659-663) ----------
     def state_dict(self):
         return dict(params=self.flat.data.detach().cpu().clone(), exp_avg=self.exp_avg.cpu().clone(), exp_avg_sq=self.exp_avg_sq.cpu().clone(),
@@ -608,8 +590,6 @@ class E4TTrainer:
         self.clip_grad_norm()
         self.optimizer_step()
         self.zero_grad()
-        if self.prepare_ahead and not self.tuning:
-            self._prepare_next_step()
         if self.world > 1 and self.replica_check_every > 0 and self.step_count % self.replica_check_every == 0:
             self.check_replicas()
         return loss.detach(), loss_diff.detach(), loss_reg.detach()

@@ -140,20 +140,6 @@ class WOBank:
             self._key = key
         return self._token
 
-    def prepare_ahead(self):
-        """Evaluate W_eff for the current parameters NOW (no autograd), so that the next begin() finds it fresh and only creates its
-        token.  A trainer calls this right after the optimiser step: the evaluation (~1 ms per step for the two banks) then runs while
-        the side stream still works on the next batch's frozen encoders instead of at the head of the next step's critical path."""
-        if self.table is None:
-            return False
-        key = self._state_key()
-        if key == self._key:
-            return False
-        ops.backend().wo_forward(self.table)
-        self._key = key
-        self._token = None              # begin() makes a fresh token and skips the evaluation (_skip_forward)
-        return True
-
     def _run_forward(self):
         if getattr(self, "_skip_forward", False):
             self._skip_forward = False
