@@ -91,8 +91,6 @@ class E4TTrainer:
         # at the tail of the step (102.13 / 102.23 against 102.12 / 102.35 ms).
         self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit+vae")
         self._next_px, self._pref = None, {}          # announced batch; finished / running prefetches by id(pixel tensor)
-        self._main_prio = int(os.environ["E4T_MAIN_PRIORITY"]) if os.environ.get("E4T_MAIN_PRIORITY") else None
-        self._main_stream = None
         # whole-step HIP graph (enable_step_graph): signature -> captured graph + its static tensors; device copy of AdamW's
         # step-dependent scalars
         self._step_graph_on = False
@@ -270,9 +268,9 @@ class E4TTrainer:
             return self.encoder.encode_vision(pixel_values)
 
     def _new_side_stream(self, device):
-        """The side stream fills what the step's own stream leaves idle: E4T_SIDE_PRIORITY (an int, default 0 = the same as the
-        main stream; larger = lower priority where the runtime offers it) is passed to the stream's constructor."""
-        return torch.cuda.Stream(device=device, priority=int(os.environ.get("E4T_SIDE_PRIORITY", "0")))
+        """(HIP offers two stream priorities here, -1 and 0; running the step at -1 or the side stream "low" measured no difference:
+        101.3 vs 101.1-101.5 ms, profiles/r04_ab)"""
+        return torch.cuda.Stream(device=device)
 
     # ---- next-batch prefetch of the frozen front ends ---------------------------------------------------------------------
     # The CLIP-ViT tower (and the VAE encoder) of a step depend on the step's IMAGES only — not on any weight the optimiser
@@ -529,23 +527,14 @@ class E4TTrainer:
         ops.bump_weights_epoch()                 # bf16 compute copies of the trainable weights are stale now
 
     def train_step(self, *args, **kw):
-        """One training step (see _train_step).  E4T_MAIN_PRIORITY=<int> (e.g. -1) runs it on a stream of that priority, joined
-        with the caller's stream on both sides, so that side-stream work (prefetch) only takes what this stream leaves idle."""
+        """One training step (see _train_step); replayed from the step's HIP graph when enable_step_graph() is on and the call is a plain
+        synchronising step."""
         if self._step_graph_on and kw.get("sync", True) and kw.get("loss_scale", 1.0) == 1.0 and self._next_px is None and not self._pref:
             names = ("pixel_values", "input_ids", "placeholder_idx", "noise", "timesteps", "vae_eps", "latents")
             a = dict(zip(names, args))
             a.update({k: v for k, v in kw.items() if k in names})
             return self._graphed_step(*(a.get(k) for k in names))
-        if self._main_prio is None or not self.flat.data.is_cuda:
-            return self._train_step(*args, **kw)
-        caller = torch.cuda.current_stream()
-        if self._main_stream is None:
-            self._main_stream = torch.cuda.Stream(device=self.device, priority=self._main_prio)
-        self._main_stream.wait_stream(caller)
-        with torch.cuda.stream(self._main_stream):
-            out = self._train_step(*args, **kw)
-        caller.wait_stream(self._main_stream)
-        return out
+        return self._train_step(*args, **kw)
 
     def _train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None,
                     sync=True, loss_scale=1.0):
