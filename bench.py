@@ -28,7 +28,7 @@ HOT_FLOP_PER_IMAGE = {"sd14": 2.72e12, "sd21": 7.13e12}
 STEP_FLOP_PER_IMAGE = {"sd14": 3.86e12, "sd21": 9.83e12}   # incl. frozen VAE encode + text encoder
 MFMA_PEAK = 2.5e15                                         # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
 # the newest round whose counter pass (tools/profile_round.sh) is committed under profiles/
-PROFILE_ROUND = next((r for r in ("r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_pmc_traffic.csv"))), "r03")
+PROFILE_ROUND = next((r for r in ("r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_pmc_traffic.csv"))), "r03")
 HBM_PEAK = 8.0e12                                          # HBM3E spec (6.3e12 achievable), same guide
 
 
@@ -237,15 +237,29 @@ def main():
         if rank == 0:
             hip.prof = []
         tr.comm_timing = {} if world > 1 else None      # per-region all-reduce enqueue times + exposed wait of this step (N > 1)
-        tr.prefetch(pool[0][0])                         # same configuration as the timed steps: the next batch's ViT runs under this backward
+        # a steady-state step: it consumes what the last timed step prefetched for it and prefetches the batch after it
+        nxt = (args.warmup + args.steps) % len(pool)
+        tr.prefetch(pool[(nxt + 1) % len(pool)][0])
+        tr.train_step(*pool[nxt])
+        torch.cuda.synchronize()
+        prof_steady, hip.prof = hip.prof, ([] if rank == 0 else None)
+        # ... and one step with the prefetch off (frozen encoders inside their own step, nothing on the side stream during the backward):
+        # the same kernels without the other stream's workgroups competing for CUs and L2 — the kernel-quality view of the same launches
+        mode, tr.prefetch_mode = tr.prefetch_mode, "0"
+        tr._pref.clear()
         tr.train_step(*batch(10_000))
         torch.cuda.synchronize()
+        tr.prefetch_mode = mode
+        prof_alone, hip.prof = hip.prof, prof_steady
     comm = tr.comm_report() if (world > 1 and not args.no_kernel_roofline) else None
     if rank == 0 and not args.no_kernel_roofline:
-        agg = {}
-        for key, fl, nb, e0, e1 in hip.prof:
-            a = agg.setdefault(key, [0.0, 0.0, 0.0, 0])
-            a[0] += fl; a[1] += nb; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
+        def aggregate(prof):
+            agg = {}
+            for key, fl, nb, e0, e1 in prof:
+                a = agg.setdefault(key, [0.0, 0.0, 0.0, 0])
+                a[0] += fl; a[1] += nb; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
+            return agg
+        agg, agg_alone = aggregate(hip.prof), aggregate(prof_alone)
         hip.prof = None
         names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, 2, false, 64>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, 2, false, 64>",
                  "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, 2, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2, false, 64>",
@@ -306,7 +320,16 @@ def main():
         dom = max(agg, key=lambda k: agg[k][2])
         roof = entry(dom)
         roof["traffic_source"] = traffic_src
-        roof["configuration"] = "in-step (ViT side stream on), events on the launch stream; same command as profiles/" + PROFILE_ROUND + "_step_kernel_stats.csv"
+        roof["configuration"] = ("a steady-state step of the timed region (next-batch prefetch " + tr_prefetch + ": the frozen ViT / VAE of batch i+1 run on the side "
+                                 "stream under this step), events on the launch stream; same command as profiles/" + PROFILE_ROUND + "_step_kernel_stats.csv")
+        if dom in agg_alone and agg_alone[dom][2] > 0:
+            fl, nb, sec, n = agg_alone[dom]
+            roof["without_side_stream"] = dict(
+                configuration="the same kernel in a step with the prefetch off (nothing on the side stream while it runs)", launches_per_step=n,
+                avg_launch_ms=sec / n * 1e3, achieved=(fl / sec / 1e12 if roof["bound"] == "mfma" else nb / sec / 1e9),
+                frac=(fl / sec / MFMA_PEAK if roof["bound"] == "mfma" else nb / sec / HBM_PEAK))
+        roof["per_kernel_without_side_stream"] = {k: dict(tflops=v[0] / v[2] / 1e12, gbps=v[1] / v[2] / 1e9, ms_per_step=v[2] * 1e3, launches=v[3])
+                                                  for k, v in sorted(agg_alone.items())}
         roof["per_kernel"] = {k: dict(tflops=v[0] / v[2] / 1e12, gbps=v[1] / v[2] / 1e9, ms_per_step=v[2] * 1e3, launches=v[3],
                                       intensity=(v[0] / v[1] if v[1] else 0.0)) for k, v in sorted(agg.items())}
         roof["step_mfma_frac_necessary"] = ips * HOT_FLOP_PER_IMAGE[args.model] / (world * MFMA_PEAK)
