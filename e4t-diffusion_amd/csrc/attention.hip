@@ -569,7 +569,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
       for (int sub = 0; sub < nsub; ++sub) sub_tile(sub);
     }
   }
-  store_T_acc<DH>(acc, p.scale, p.dQ + b * p.bq + h * DH, p.ldq, q, p.T, hi);
+  int qrow = q;
+  asm volatile("" : "+v"(qrow));      // output addresses computed here, not carried through the loop (see the dK/dV kernel)
+  store_T_acc<DH>(acc, p.scale, p.dQ + b * p.bq + h * DH, p.ldq, qrow, p.T, hi);
 }
 
 // ================================================================================================
@@ -742,14 +744,16 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
       for (int sub = 0; sub < nsub; ++sub) sub_tile(sub);
     }
   }
+  int krow = key;
+  asm volatile("" : "+v"(krow));      // the output addresses are computed HERE (hoisted above the loop they cost the 168-register kernel a spill)
   if (p.tsplit > 1) {        // fp32 partials of this query chunk; the reduce kernel scales dK and rounds once
     float* base = p.part + ((((size_t)ts * gridDim.z + b) * p.H + h) * 2) * (size_t)p.S * DH;
-    store_T_acc_f32<DH>(dvt, base, key, p.S, hi);
-    store_T_acc_f32<DH>(dkt, base + (size_t)p.S * DH, key, p.S, hi);
+    store_T_acc_f32<DH>(dvt, base, krow, p.S, hi);
+    store_T_acc_f32<DH>(dkt, base + (size_t)p.S * DH, krow, p.S, hi);
     return;
   }
-  store_T_acc<DH>(dvt, 1.f, p.dV + b * p.bv + h * DH, p.ldv, key, p.S, hi);
-  store_T_acc<DH>(dkt, p.scale, p.dK + b * p.bk + h * DH, p.ldk, key, p.S, hi);
+  store_T_acc<DH>(dvt, 1.f, p.dV + b * p.bv + h * DH, p.ldv, krow, p.S, hi);
+  store_T_acc<DH>(dkt, p.scale, p.dK + b * p.bk + h * DH, p.ldk, krow, p.S, hi);
 }
 
 // dV / dK = sum over the query chunks' partials (fixed order: deterministic), dK scaled, one bf16 rounding

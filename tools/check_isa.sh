@@ -1,13 +1,13 @@
 #!/bin/bash
 # Static resource report of every kernel of libe4t_hip.so (no GPU needed: hipcc cross-compiles): VGPRs / AGPRs / scratch bytes per
 # lane / occupancy / LDS per workgroup from -Rpass-analysis=kernel-resource-usage, plus the two ISA pathologies found in round 3,
-# counted per kernel from the assembly: scratch spills inside loops and "waterfall" loops around buffer_load ... lds (a scalar
+# (product build: gemm_ps.hip and the other E4T_EXPERIMENTAL variants are not part of it) counted per kernel from the assembly: scratch spills inside loops and "waterfall" loops around buffer_load ... lds (a scalar
 # offset the compiler could not prove uniform).  usage: tools/check_isa.sh [out]   (default profiles/rNN_isa_resources.txt)
 cd "$(dirname "$0")/../e4t-diffusion_amd/csrc"
-OUT=${1:-../../profiles/r03_isa_resources.txt}
+OUT=${1:-../../profiles/r04_isa_resources.txt}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -w"
 echo "# $(git -C ../.. rev-parse --short HEAD)  hipcc $FLAGS" > $OUT
-for f in gemm gemm_ps attention norm wo elementwise image core; do
+for f in gemm attention norm wo elementwise image core; do
   EXTRA=""; [ $f = image ] && EXTRA="-ffp-contract=off"
   hipcc $FLAGS $EXTRA -Rpass-analysis=kernel-resource-usage -c $f.hip -o /tmp/isa_$f.o 2> /tmp/isa_$f.rpt &
   hipcc $FLAGS $EXTRA -S --cuda-device-only $f.hip -o /tmp/isa_$f.s 2> /dev/null &
@@ -17,7 +17,7 @@ python3 - "$OUT" <<'PY'
 import re, subprocess, sys
 out = open(sys.argv[1], "a")
 out.write("file,kernel,vgprs,agprs,scratch_bytes_per_lane,occupancy_waves_per_simd,lds_bytes_per_block,waterfall_loops_around_lds_dma\n")
-for f in "gemm gemm_ps attention norm wo elementwise image core".split():
+for f in "gemm attention norm wo elementwise image core".split():
     rpt = open(f"/tmp/isa_{f}.rpt").read()
     asm = open(f"/tmp/isa_{f}.s").read().split("\n")
     # waterfall loops per kernel symbol
