@@ -827,7 +827,9 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
   static const int dkv_env = getenv("E4T_ATTN_DKV_OCC") ? atoi(getenv("E4T_ATTN_DKV_OCC")) : 0;    // A/B switch (tools/ab_dkv.py)
   // measured (tools/ab_dkv.py, dh 40, B16 H8 T4096): S = 4096 1.790 vs 1.835 ms per backward with 3 workgroups per CU, S = 77
   // 0.194 vs 0.167 ms (one workgroup per (batch, head): nothing to cover the un-prefetched tile loads) -> long key ranges only
-  const int dkv_occ = DH > 64 ? 1 : (dkv_env == 3 || dkv_env == 2) ? dkv_env : (p.S >= 2048 ? 3 : DKV_WAVES);
+  // dh 64 (SD-2.x): three workgroups per CU cost the kernel a 16-byte spill and buy nothing (C5 B = 4: 85.3 vs 85.8 ms per step, B = 1 equal;
+  // profiles/r04_ab/r04g_c5_occ*): it stays at two
+  const int dkv_occ = DH > 64 ? 1 : (dkv_env == 3 || dkv_env == 2) ? dkv_env : ((p.S >= 2048 && DH < 64) ? 3 : DKV_WAVES);
   if (e4t_launch_log_enabled()) {
     const double el = (double)Bn * p.H * DH;      // elements per token row over all heads
     E4T_LOG_LAUNCH("attn_delta_kernel<%d>|B%d H%d T%d|%.0f|0", DH, Bn, p.H, p.T, 4.0 * el * p.T + 4.0 * Bn * p.H * p.T);
