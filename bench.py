@@ -230,10 +230,9 @@ def main():
 
     roof = roof_hbm = None
     if not args.no_kernel_roofline:
-        # one extra, instrumented step (outside the timed region): HIP events around every instrumented launch, recorded on the
-        # stream the kernel is launched on, in the SAME configuration as the timed region and the rocprofv3 run (CLIP-ViT on its
-        # side stream).  EVERY rank runs it — a training step contains the gradient all-reduce, a collective rank 0 must not
-        # enter alone — and rank 0 records and reports.
+        # two extra, instrumented steps (outside the timed region): HIP events around every instrumented launch, recorded on the
+        # stream the kernel is launched on.  EVERY rank runs them — a training step contains the gradient all-reduce, a collective
+        # rank 0 must not enter alone — and rank 0 records and reports.
         if rank == 0:
             hip.prof = []
         tr.comm_timing = {} if world > 1 else None      # per-region all-reduce enqueue times + exposed wait of this step (N > 1)
@@ -259,7 +258,12 @@ def main():
                 a = agg.setdefault(key, [0.0, 0.0, 0.0, 0])
                 a[0] += fl; a[1] += nb; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += 1
             return agg
-        agg, agg_alone = aggregate(hip.prof), aggregate(prof_alone)
+        # `roofline` describes the kernels in the step that has the device to itself (prefetch off for that step: the frozen encoders inside
+        # their own step, nothing on the side stream during the backward) — events bracket a launch on its stream, so in the steady-state
+        # step of the timed region they also count the time a kernel's workgroups wait behind the other stream's (the side stream's ViT
+        # GEMMs read 3x slower there than alone): that view is reported next to it (`in_timed_configuration`), each with the rocprofv3
+        # summary of its own command under profiles/
+        agg_timed, agg = aggregate(hip.prof), aggregate(prof_alone)
         hip.prof = None
         names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, 2, false, 64>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, 2, false, 64>",
                  "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, 2, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2, false, 64>",
@@ -277,10 +281,12 @@ def main():
         # MI355X_MICROARCH.md prescribes; check: adamw_kernel = 28 B x parameters) -> profiles/rNN_pmc_traffic.csv, whose header
         # line names the commit it was collected at; profiles/rNN_roofline_per_shape.csv breaks it down per shape.
         traffic_tab, traffic_src = {}, None
-        csv_path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_traffic.csv")
+        csv_path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_prefetch_off_pmc_traffic.csv")
+        if not os.path.exists(csv_path):
+            csv_path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_pmc_traffic.csv")
         if os.path.exists(csv_path) and args.model == "sd14" and args.batch == 16:
             lines = open(csv_path).read().splitlines()
-            traffic_src = "profiles/" + PROFILE_ROUND + "_pmc_traffic.csv" + (" " + lines[0].lstrip("# ") if lines and lines[0].startswith("#") else "")
+            traffic_src = "profiles/" + os.path.basename(csv_path) + (" " + lines[0].lstrip("# ") if lines and lines[0].startswith("#") else "")
             for line in lines:
                 if line.startswith("#") or line.startswith("kernel,"):
                     continue
@@ -320,18 +326,21 @@ def main():
         dom = max(agg, key=lambda k: agg[k][2])
         roof = entry(dom)
         roof["traffic_source"] = traffic_src
-        roof["configuration"] = ("a steady-state step of the timed region (next-batch prefetch " + tr_prefetch + ": the frozen ViT / VAE of batch i+1 run on the side "
-                                 "stream under this step), events on the launch stream; same command as profiles/" + PROFILE_ROUND + "_step_kernel_stats.csv")
-        if dom in agg_alone and agg_alone[dom][2] > 0:
-            fl, nb, sec, n = agg_alone[dom]
-            roof["without_side_stream"] = dict(
-                configuration="the same kernel in a step with the prefetch off (nothing on the side stream while it runs)", launches_per_step=n,
-                avg_launch_ms=sec / n * 1e3, achieved=(fl / sec / 1e12 if roof["bound"] == "mfma" else nb / sec / 1e9),
+        roof["configuration"] = ("one instrumented step with the next-batch prefetch off for that step (frozen ViT / VAE inside their own step, ViT on its side "
+                                 "stream under the UNet encoder pass as in round 3), events on the launch stream; same command as profiles/" + PROFILE_ROUND +
+                                 "_prefetch_off_step_kernel_stats.csv (E4T_PREFETCH=0 python bench.py)")
+        if dom in agg_timed and agg_timed[dom][2] > 0:
+            fl, nb, sec, n = agg_timed[dom]
+            roof["in_timed_configuration"] = dict(
+                configuration="the same kernel in a steady-state step of the timed region (next-batch prefetch " + tr_prefetch + ": the frozen ViT / VAE of batch i+1 "
+                              "run on the side stream under this step and compete for CUs); same command as profiles/" + PROFILE_ROUND + "_step_kernel_stats.csv",
+                launches_per_step=n, avg_launch_ms=sec / n * 1e3, ms_per_step=sec * 1e3,
+                achieved=(fl / sec / 1e12 if roof["bound"] == "mfma" else nb / sec / 1e9),
                 frac=(fl / sec / MFMA_PEAK if roof["bound"] == "mfma" else nb / sec / HBM_PEAK))
-        roof["per_kernel_without_side_stream"] = {k: dict(tflops=v[0] / v[2] / 1e12, gbps=v[1] / v[2] / 1e9, ms_per_step=v[2] * 1e3, launches=v[3])
-                                                  for k, v in sorted(agg_alone.items())}
         roof["per_kernel"] = {k: dict(tflops=v[0] / v[2] / 1e12, gbps=v[1] / v[2] / 1e9, ms_per_step=v[2] * 1e3, launches=v[3],
                                       intensity=(v[0] / v[1] if v[1] else 0.0)) for k, v in sorted(agg.items())}
+        roof["per_kernel_in_timed_configuration"] = {k: dict(tflops=v[0] / v[2] / 1e12, gbps=v[1] / v[2] / 1e9, ms_per_step=v[2] * 1e3, launches=v[3])
+                                                     for k, v in sorted(agg_timed.items())}
         roof["step_mfma_frac_necessary"] = ips * HOT_FLOP_PER_IMAGE[args.model] / (world * MFMA_PEAK)
         roof["step_mfma_frac_whole_step"] = ips * STEP_FLOP_PER_IMAGE[args.model] / (world * MFMA_PEAK)
         pure_hbm = [k for k in agg if agg[k][0] == 0.0]
