@@ -1578,22 +1578,70 @@ bool ps_rounds_ok(long long units, int ncu) {
   return units * 100 >= rounds * ncu * 85;
 }
 
+// ---- cost model of one launch of the 64 x 64 / 128 x 128 / 128 x 160 DMA tiles (round 4) ---------------------------------------------
+// Below a few rounds of workgroups the time of these kernels is set by how many K-tiles a CU keeps in flight, not by the tile's FLOP per
+// byte: per 64-wide K-tile a workgroup that is ALONE on its CU needs t1 (its own DMA latency / issue chain: 2 stages expose the whole
+// L2 -> LDS latency, 3 - 4 stages hide it but cost the co-resident workgroups their LDS), several co-resident workgroups need tk each
+// (the CU's L2 -> LDS bandwidth, ~60 GB/s per CU: 16 / 32 / 36 KiB per K-tile).  A launch costs
+//     launch + rounds x (prologue + epilogue) + K-tiles per split x [full rounds x occ x tk + the last, partial round]  (+ the split-K reduce)
+// with the workgroups dealt evenly to the CUs.  Constants (us) fitted by least squares to tools/sweep_small_m.py: 75 GEMM / conv shapes
+// of the B = 1 / 4 / 16 steps x every (tile, stages, split) = 2900 graph-replayed, cold-operand timings, rms error 8.6 %; the
+// argmin is within 6 % of the best measured variant on 72 of them (worst 1.18x), the rules it replaces were 5.8 % slower in total.
+struct SmallGridPlan { int tile, stages, splitk; };
+struct SmallGridCand { int tile, stages, tm, tn, occ; float t1, tk, epi; bool general_ok; };
+SmallGridPlan small_grid_plan(int M, int N, int nkt, bool conv, bool general, int splitk_req, bool wants_colstats, int ncu) {
+  static const SmallGridCand cands[] = {
+      {64, 3, 64, 64, 3, 0.350f, 0.230f, 0.30f, true},    {64, 4, 64, 64, 2, 0.305f, 0.230f, 0.30f, false},
+      {128, 2, 128, 128, 2, 0.875f, 0.544f, 1.08f, true}, {128, 4, 128, 128, 1, 0.596f, 0.544f, 1.08f, false},
+      {160, 2, 128, 160, 2, 0.955f, 0.629f, 3.41f, false}, {160, 3, 128, 160, 1, 0.861f, 0.629f, 3.41f, false}};
+  static const int splits[] = {1, 2, 3, 4, 6, 8, 12};
+  const float launch = 1.6f, pro = 0.945f, red0 = 4.49f, red_bytes_per_us = 4.05e6f, conv_mul = 0.916f, stats_pass = 6.0f;
+  SmallGridPlan best = {128, 2, 1};
+  float best_t = 1e30f;
+  for (const SmallGridCand& c : cands) {
+    if (general && !c.general_ok) continue;        // (the GENERAL epilogue is instantiated for these two; the 128 x 160 one is register-bound)
+    if (c.tile == 160 && N % 160 != 0) continue;
+    for (int sk : splits) {
+      if (splitk_req > 0 && sk != 1) continue;     // an explicit split: priced below with the request
+      const int s = splitk_req > 0 ? (splitk_req < nkt ? splitk_req : nkt) : sk;
+      if (s > 1 && splitk_req <= 0 && (nkt / s < 4 || (double)M * N * s * 4.0 > 256e6)) continue;
+      const int kps = cdiv(nkt, s);
+      const long long wgs = (long long)cdiv(M, c.tm) * cdiv(N, c.tn) * s;
+      const long long per_cu = cdivl(wgs, ncu);
+      const long long q = per_cu / c.occ, r = per_cu % c.occ;
+      const float full = c.occ > 1 ? c.occ * c.tk : c.t1;
+      const float rem = r == 0 ? 0.f : (r == 1 ? c.t1 : (float)r * c.tk);
+      float per_kt = (float)q * full + rem;
+      if (conv) per_kt *= conv_mul;
+      const float rounds = (float)cdivl(per_cu, c.occ);
+      float t = launch + rounds * (pro + c.epi) + (float)kps * per_kt;
+      if (s > 1) {
+        t += red0 + ((float)s * 4.f + 2.f) * (float)M * (float)N / red_bytes_per_us + rounds * c.epi * 0.5f;
+        if (wants_colstats) t += stats_pass;       // a split launch leaves no column statistics: the consuming GroupNorm runs its own pass
+      }
+      if (t < best_t) { best_t = t; best = {c.tile, c.stages, s}; }
+    }
+  }
+  return best;
+}
+
 GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, int batch) {
   GemmPlan pl;
   const int nkt = cdiv(p.K, BK);
   // --- tile selection: fill >= ~1.5 waves of the 256 CUs with 128x128 tiles, else drop to 64x64 ---
   int stages = 2;                         // LDS stages of the 64 / 128 / 160 DMA kernels; a hint of 3128 / 4160 / ... forces 3 or 4
+  int model_splitk = 0;                   // > 0: split-K chosen together with the tile by small_grid_plan
   bool kt32 = false;                      // 5128 / 5064 / 5256: the 32-wide K-tile variant (4 stages in the LDS of 2 x 64-wide ones; 5256: 3)
   if (tile_hint >= 3000 && tile_hint < 5000) { stages = tile_hint / 1000; tile_hint %= 1000; }
   else if (tile_hint >= 5000 && tile_hint < 6000) { kt32 = true; stages = 4; tile_hint %= 1000; }
   int tile = tile_hint;
 #ifndef E4T_EXPERIMENTAL
-  // The product library carries the tiles the planner chooses (64 / 128 / 160 two-stage, 5256, 512, 2320) and nothing else: the
-  // measured-and-rejected variants — 3 / 4 LDS stages, 32-wide K-tiles on the 64 / 128 tiles, the 64-wide 256 x 128 tile, the 512 x 128
-  // ping-pong tile, the persistent streaming kernels of gemm_ps.hip — are built only with -DE4T_EXPERIMENTAL (csrc/build.sh:
+  // The product library carries the tiles the planner chooses (64 / 128 / 160 with 2 - 4 LDS stages, 5256, 512, 2320) and nothing else:
+  // the measured-and-rejected variants — 32-wide K-tiles on the 64 / 128 tiles, the 64-wide 256 x 128 tile, the 512 x 128 ping-pong
+  // tile, the persistent streaming kernels of gemm_ps.hip — are built only with -DE4T_EXPERIMENTAL (csrc/build.sh:
   // E4T_EXPERIMENTAL=1).  A hint that names one of them gets the nearest product tile.
-  stages = 2;
-  if (kt32 && tile != 256) kt32 = false;
+  if (kt32 && tile != 256) { kt32 = false; stages = 2; }
+  if (tile != 64 && tile != 128 && tile != 160) stages = 2;
   if (tile == 256 && !kt32) { kt32 = true; stages = 3; }
   if (tile == 640) tile = 128;
   if (tile == 1128) tile = 128;
@@ -1683,11 +1731,18 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
       if (p.N % 160 == 0 && ps_rounds_ok(rows * (p.N / 160), ncu)) tile = 1160;
       else if ((p.N % 128 == 0 || p.N < 128) && ps_rounds_ok(rows * cdiv(p.N, 128), ncu)) tile = 1128;
     }
+    // Round 4: the 64 / 128 / 160 tiles, their LDS depth and split-K are arbitrated by a cost model of the launch (small_grid_plan above)
+    // instead of the rules that chose among them until round 3; the rules above still decide WHETHER one of the big tiles runs.
+    static const bool no_model = getenv("E4T_GEMM_NOMODEL") != nullptr && getenv("E4T_GEMM_NOMODEL")[0] == '1';      // A/B switch: the round-3 rules
+    if (!no_model && allow256 && (tile == 64 || tile == 128 || tile == 160) && batch == 1 && !p.reduce_batch && !p.panel_rows) {
+      const SmallGridPlan sg = small_grid_plan(p.M, p.N, nkt, conv, general, splitk_req, p.colstats != nullptr, device_cu_count());
+      tile = sg.tile; stages = sg.stages; model_splitk = sg.splitk;
+    }
   }
-  // epilogues with the exact GELU or a per-row row-bias lookup run the GENERAL instantiation, built for the 2-stage 64 / 128 / 160 tiles,
-  // the 256 x 256 ping-pong kernel and the persistent kernels
+  // epilogues with the exact GELU or a per-row row-bias lookup run the GENERAL instantiation, built for the 2-stage 64 / 128 / 160 tiles (and
+  // the 3-stage 64 tile), the 256 x 256 / 256 x 320 ping-pong kernels and the persistent kernels
   const bool general_epi = (p.flags & E4T_ACT_GELU) || (p.rowbias && p.rows_per_batch % 32 != 0);
-  if (general_epi) { stages = 2; kt32 = false; if (tile == 256 || tile == 640) tile = 128; }
+  if (general_epi) { if (!(tile == 64 && stages == 3)) stages = 2; kt32 = false; if (tile == 256 || tile == 640) tile = 128; }
   if (kt32 && tile != 128 && tile != 64 && tile != 256) kt32 = false;
   if (kt32 && tile == 256) stages = 3;
   if (tile == 256 && !allow256) tile = 128;
@@ -1726,6 +1781,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
   int splitk = splitk_req;
   if (tile >= 1000 && tile < 2000) splitk = 1;
   if (p.panel_rows) splitk = 1;
+  if (splitk <= 0 && model_splitk > 0 && (tile == 64 || tile == 128 || tile == 160)) splitk = model_splitk;
   if (splitk <= 0) {
     splitk = 1;
     const long long tiles = (long long)gx * gy * batch;
@@ -1875,16 +1931,12 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     } else {
       // 64 / 128 / 160 tiles: 2 LDS stages and 2 workgroups per CU by default; 3 or 4 stages (one workgroup per CU, 2-3 K-tiles
       // in flight) when the grid cannot give a CU two workgroups anyway — see the stage choice above
-#ifdef E4T_EXPERIMENTAL
 #define E4T_LAUNCH_DMA_STAGES(BM_, BN_, WGM_, WGN_)                                                                       \
-    if (stages == 4) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 4>), grid, block, 0, st, p); \
+    if (!general_epi && stages == 4) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 4>), grid, block, 0, st, p); \
                        else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 4>), grid, block, 0, st, p); }    \
-    else if (stages == 3) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 3>), grid, block, 0, st, p); \
+    else if (!general_epi && stages == 3) { if (conv) hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 1, 3>), grid, block, 0, st, p); \
                             else hipLaunchKernelGGL((gemm_dma_kernel<BM_, BN_, WGM_, WGN_, 0, 3>), grid, block, 0, st, p); } \
     else
-#else
-#define E4T_LAUNCH_DMA_STAGES(BM_, BN_, WGM_, WGN_)
-#endif
 #define E4T_LAUNCH_DMA(BM_, BN_, WGM_, WGN_, NT_)                                                                         \
   do {                                                                                                                   \
     block = dim3(NT_);                                                                                                   \
@@ -1907,7 +1959,11 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
         else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 0, 4, false, 32>), grid, block, 0, st, p);
       } else
 #endif
-      if (tile == 160) E4T_LAUNCH_DMA(128, 160, 4, 1, 256);
+      if (tile == 64 && general_epi && stages == 3) {
+        block = dim3(256);
+        if (conv) hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 1, 3, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_dma_kernel<64, 64, 2, 2, 0, 3, true>), grid, block, 0, st, p);
+      } else if (tile == 160) E4T_LAUNCH_DMA(128, 160, 4, 1, 256);
       else if (tile == 128) E4T_LAUNCH_DMA(128, 128, 4, 2, 512);
       else E4T_LAUNCH_DMA(64, 64, 2, 2, 256);
 #undef E4T_LAUNCH_DMA

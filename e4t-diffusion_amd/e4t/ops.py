@@ -217,12 +217,12 @@ class HipBackend:
         d.strideBias = bias.stride(0) if (bias is not None and bias.dim() == 2) else 0
         if panels is not None:
             d.panel_rows, d.panel_stride, d.panel_off = panels[0], panels[1], panels[2]
+        cs = self._colstats_buf(out, M, N, colstats and not batched)
+        d.colstats = _ptr(cs)            # before the plan: whether statistics are wanted prices the split-K variants (they leave none)
         pl = self._plan(self.lib.e4t_gemm_plan, d, "e4t_gemm_plan")
         ws = self.workspace(pl.workspace_bytes, a.device) if pl.workspace_bytes else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
-        cs = self._colstats_buf(out, M, N, colstats and not batched)
-        d.colstats = _ptr(cs)
         # algorithmic bytes: A, B once; C once (+ once more when read: residual / accumulate)
         nbytes = lambda: (2.0 * nb * M * K + 2.0 * N * K * (nb if sB else 1) + out.element_size() * M * N * (1 if reduce_batch else nb) * (2 if accum else 1)
                           + (residual.element_size() * M * N if residual is not None else 0))
@@ -276,12 +276,12 @@ class HipBackend:
             flags |= _C.ACCUM
         d.mode, d.flags, d.tile, d.splitk = mode, flags, tile, splitk
         d.ldrb = rowbias.stride(0) if rowbias is not None else 0
+        cs = self._colstats_buf(out, M, Cout, colstats)
+        d.colstats = _ptr(cs)            # before the plan (see gemm)
         pl = self._plan(self.lib.e4t_conv3x3_plan, d, "e4t_conv3x3_plan")
         ws = self.workspace(pl.workspace_bytes, x.device) if pl.workspace_bytes else None
         d.workspace, d.workspace_bytes = _ptr(ws), (ws.numel() if ws is not None else 0)
         st = _stream()
-        cs = self._colstats_buf(out, M, Cout, colstats)
-        d.colstats = _ptr(cs)
         # algorithmic bytes: the input map once (not once per tap), the weights once, the output once (+ residual)
         nbytes = 2.0 * B * Hin * Win * Cin + 2.0 * Cout * 9 * Cin + out.element_size() * M * Cout * (2 if accum else 1) + \
             (residual.element_size() * M * Cout if residual is not None else 0)

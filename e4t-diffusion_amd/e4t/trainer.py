@@ -302,9 +302,11 @@ class E4TTrainer:
         if "vae_eps" in pref:
             if self._side is None:
                 self._side = self._new_side_stream(px.device)
-                self._side.wait_stream(torch.cuda.current_stream())
+            if pref["vision"] is None:      # (otherwise _launch_vision already made the side stream wait for this point of the main stream)
+                self._side.wait_stream(torch.cuda.current_stream())       # the draw of vae_eps above is main-stream work
             with torch.cuda.stream(self._side), torch.no_grad():
                 pref["latents"] = self.encode_latents(px, pref["vae_eps"])
+        px.record_stream(self._side)        # an announced batch that is dropped untrained must not be freed under the side stream
         pref["done"] = self._side.record_event()           # the consumer waits for THIS point of the side stream, not for its tail
         if not getattr(self, "_prefetch_warm", False):
             # the first pass of a frozen model also writes its one-time bf16 weight copies (PreparedConv / VAEEncoder._prepare): a

@@ -122,8 +122,8 @@ int e4t_conv3x3(const e4t_conv_desc* d, e4t_stream stream);
 /* What the launcher will do for a descriptor, WITHOUT launching: the tile it picks (codes as e4t_gemm_desc.tile; tile_m x tile_n
  * are its dimensions), the split-K factor, and the fp32 workspace (bytes) the call wants for it — e4t_gemm_nt / e4t_conv3x3 fall
  * back to a single pass when handed less in auto mode, and fail with -12 when split-K or REDUCE_BATCH was requested explicitly.
- * The pointer fields of the descriptor are never dereferenced, but whether A2 / rowbias / residual are NULL or not is part of the
- * decision (a two-source A and a row bias restrict the tiles): leave them NULL or non-NULL exactly as the later launch will have
+ * The pointer fields of the descriptor are never dereferenced, but whether A2 / rowbias / residual / colstats are NULL or not is part of the
+ * decision (a two-source A and a row bias restrict the tiles; wanted column statistics price the split-K variants, which leave none): leave them NULL or non-NULL exactly as the later launch will have
  * them (any non-NULL value does).  Shapes, strides, flags, tile, splitk and batch are read as given.
  * This is the one statement of the tile / split-K heuristic: callers size workspaces and label timings from it (SURVEY §8b
  * "query size via e4t_<op>_workspace_bytes"). */

@@ -48,11 +48,12 @@ def check_probe(hip, emu, dev):
 
 def _product_tile(hip, code):
     """False for the tile codes of the measured-and-rejected GEMM variants, which only an E4T_EXPERIMENTAL=1 build of the library
-    carries (3 / 4-stage and 32-wide-K 64 / 128 tiles, 512 x 128 ping-pong, persistent streaming kernels): the default library maps
-    them to product tiles, so checking them there would re-check those tiles under another label."""
+    carries (32-wide-K 64 / 128 tiles, 512 x 128 ping-pong, persistent streaming kernels): the default library maps them to product
+    tiles, so checking them there would re-check those tiles under another label.  (The 3 / 4-stage 64 / 128 / 160 tiles are product
+    code since round 4: the planner picks them for grids under one round.)"""
     if hip.lib.e4t_build_flags() & 1:
         return True
-    return not (code in (640, 1128, 1160, 5064, 5128) or 3000 <= code < 5000)
+    return code not in (640, 1128, 1160, 5064, 5128)
 
 
 def check_gemm(hip, emu, dev):
@@ -119,7 +120,7 @@ def check_gemm(hip, emu, dev):
     out.append(("gemm gelu fp32-out t512", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32, tile=512),
                                                 emu.gemm(a1, b[:, :K1].contiguous(), gelu=True, out_dtype=f32)), TOLF * 50))
     out.append(("gemm gelu", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
-    for t in [t for t in (512, 2320, 1128, 1160) if _product_tile(hip, t)]:      # the GENERAL epilogue instantiations of the ping-pong (/ persistent) kernels
+    for t in [t for t in (3064, 512, 2320, 1128, 1160) if _product_tile(hip, t)]:      # the GENERAL epilogue instantiations of the 3-stage 64 tile, the ping-pong (/ persistent) kernels
         out.append((f"gemm gelu t{t}", rel(hip.gemm(a1, b[:, :K1].contiguous(), gelu=True, tile=t), emu.gemm(a1, b[:, :K1].contiguous(), gelu=True)), TOL1))
         out.append((f"gemm two-source A t{t}", rel(hip.gemm(a1, b, a2=a2, tile=t), emu.gemm(a1, b, a2=a2)), TOL1))
     c0 = rnd(g, M, N, dtype=f32, dev=dev)

@@ -35,7 +35,7 @@ def conv_plan(B, H, W, Cin, Cout, mode=_C.CONV_S1, Hout=None, Wout=None, tile=0,
     ((4096, 10240, 1280), 2320, (256, 320)),     # GEGLU projection at the 16x16 level
     ((16384, 5120, 640), 2320, (256, 320)),
     ((65536, 2560, 320), 5256, (256, 128)),      # K = 320: too short for the ping-pong prologue, N % 128 == 0
-    ((4096, 1280, 1280), 128, (128, 128)),       # 320 tiles: no wider tile has a full round
+    ((4096, 1280, 1280), 160, (128, 160)),       # 256 workgroups of 128 x 160: one per CU, three LDS stages (23 vs 27 us on 128 x 128)
     ((16384, 640, 640), 160, (128, 160)),
     ((4112, 3840, 1280), 512, (256, 256)),       # ViT qkv
 ])
@@ -43,6 +43,23 @@ def test_step_gemms_get_the_documented_tile(shape, tile, dims):
     pl = gemm_plan(*shape)
     assert (pl.tile, pl.tile_m, pl.tile_n) == (tile, *dims), (shape, pl.tile, pl.tile_m, pl.tile_n)
     assert pl.splitk == 1 and pl.workspace_bytes == 0
+
+
+@pytest.mark.parametrize("shape, tile, splitk", [
+    # grids under a few rounds (the B = 1 / B = 4 steps of BASELINE configs[4], the text encoder, the 8 x 8 level): tile, LDS depth and
+    # split-K come from the launch cost model (gemm.hip: small_grid_plan; measured in tools/sweep_small_m.py)
+    ((576, 1280, 1280), 64, 1),                  # 180 workgroups of 64 x 64, deep pipeline: 8.8 us (round 3: 13.9)
+    ((257, 3840, 1280), 64, 1),                  # ViT qkv at B = 1
+    ((1232, 768, 3072), 64, 1),                  # text encoder fc2: 240 workgroups, 48 K-tiles, no split (18 vs 22 us with 3 splits)
+    ((1232, 3072, 768), 128, 1),                 # fc1: 960 workgroups of 64 x 64 would need two rounds; 240 of 128 x 128 with four stages
+    ((1024, 1280, 5120), 128, 3),                # 8 x 8 level, K-deep: 80 tiles x 3 splits
+    ((16384, 640, 640), 160, 1),
+    ((1024, 10240, 1280), 160, 1),               # 512 workgroups of 128 x 160 = one round of two per CU (36 vs 52 us on 128 x 128)
+])
+def test_small_grids_follow_the_cost_model(shape, tile, splitk):
+    pl = gemm_plan(*shape)
+    assert (pl.tile, pl.splitk) == (tile, splitk), (shape, pl.tile, pl.splitk)
+    assert pl.workspace_bytes == (splitk * shape[0] * shape[1] * 4 if splitk > 1 else 0)
 
 
 def test_deep_k_small_grid_uses_ping_pong_with_split_k_and_reports_the_workspace():
@@ -67,8 +84,8 @@ def test_step_convs_get_the_documented_tile(args, tile):
 def test_small_map_convs_split_k():
     pl = conv_plan(16, 16, 16, 1280, 1280)       # 16 x 16 level: 80 ping-pong tiles, K = 11520
     assert pl.tile == 512 and pl.splitk == 3 and pl.workspace_bytes == 3 * 4096 * 1280 * 4
-    pl = conv_plan(16, 8, 8, 1280, 1280)         # 8 x 8 level: 128 x 128 tiles, split 6 ways
-    assert pl.tile == 128 and pl.splitk == 6
+    pl = conv_plan(16, 8, 8, 1280, 1280)         # 8 x 8 level: 80 tiles of 128 x 128 with four LDS stages, split 3 ways (240 workgroups, one per CU)
+    assert pl.tile == 128 and pl.splitk == 3
 
 
 def test_general_epilogue_tiles():

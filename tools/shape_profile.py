@@ -1,4 +1,5 @@
-"""Per-shape time of every GEMM / conv / attention launch in one training step (events around each launch)."""
+"""Per-shape time of every GEMM / conv launch in one training step (events around each launch).
+usage: shape_profile.py [sd14|sd21] [B]      (sd21 = BASELINE configs[4]: 768 px, v-prediction)"""
 import os, sys, collections
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(R, "e4t-diffusion_amd"), R]
@@ -7,13 +8,16 @@ from e4t import ops
 import bench
 dev = torch.device("cuda:0"); torch.cuda.set_device(0)
 hip = ops.backend()
-unet, enc, text, vae = bench.build_models(dev, "sd14", 0)
+MODEL = sys.argv[1] if len(sys.argv) > 1 else "sd14"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+RES = 768 if MODEL == "sd21" else 512
+unet, enc, text, vae = bench.build_models(dev, MODEL, 0)
 from e4t.trainer import E4TTrainer
-tr = E4TTrainer(unet, enc, text, vae, lr=1e-6, class_token_id=1125, device=dev)
-B = 16
+kw = dict(prediction_type="v_prediction", empty_prompt_ids=torch.tensor([[49406] + [49407] * 76], device=dev)) if MODEL == "sd21" else {}
+tr = E4TTrainer(unet, enc, text, vae, lr=1e-6, class_token_id=1125, device=dev, **kw)
 def batch(s):
     g = torch.Generator(device=dev); g.manual_seed(s)
-    return (torch.rand((B, 3, 512, 512), generator=g, device=dev) * 2 - 1, torch.randint(0, 49000, (B, 77), generator=g, device=dev),
+    return (torch.rand((B, 3, RES, RES), generator=g, device=dev) * 2 - 1, torch.randint(0, 49000, (B, 77), generator=g, device=dev),
             torch.randint(1, 20, (B,), generator=g, device=dev))
 for s in range(2): tr.train_step(*batch(s))
 # monkeypatch _timed to key by shape
