@@ -12,6 +12,7 @@ config + ViT-H-14 E4T encoder, 512 px, bf16, per-GPU batch 16, random-init weigh
 from __future__ import annotations
 
 import argparse
+import fnmatch
 import json
 import os
 import sys
@@ -265,9 +266,10 @@ def main():
         # summary of its own command under profiles/
         agg_timed, agg = aggregate(hip.prof), aggregate(prof_alone)
         hip.prof = None
-        names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, 2, false, 64>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, 2, false, 64>",
-                 "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, 2, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, 2, false, 64>",
-                 "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, 2, false, 64>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, 2, false, 64>",
+        # (the 64 / 128 / 160 tiles run with 2 - 4 LDS stages, chosen per launch by the planner: `*` in the stages slot)
+        names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, *, false, 64>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, *, false, 64>",
+                 "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, *, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, *, false, 64>",
+                 "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, *, false, 64>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, *, false, 64>",
                  "conv512": "gemm_pp_kernel<1, false>", "gemm512": "gemm_pp_kernel<0, false>", "gemm_tn": "gemm_tn_kernel",
                  "conv2320": "gemm_pq_kernel<1, 320, false>", "gemm2320": "gemm_pq_kernel<0, 320, false>",
                  "conv5256": "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>", "gemm5256": "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>",
@@ -302,7 +304,7 @@ def main():
             if key in ("gn_fwd_colstats", "gn_fwd_2pass"):
                 return None
             parts = [q.strip() for q in name.split("+")]
-            rows = [[v for k, v in traffic_tab.items() if (k.startswith(q[:-2]) if q.endswith("*>") else k == q)] for q in parts]
+            rows = [[v for k, v in traffic_tab.items() if (fnmatch.fnmatchcase(k, q) if "*" in q else k == q)] for q in parts]
             if not all(rows):
                 return None
             return sum(n * b for r in rows for n, b in r) / sum(n for n, _ in rows[0])
