@@ -61,7 +61,8 @@ def cpu_baseline_and_parity(model, threads, dev):
     # (strict=False so that the JSON line is still printed; main() turns n_bad != 0 into a non-zero exit code)
     torch.cuda.empty_cache()
     par = dict(case=case.name, rule=rep["rule"], n_quantities=rep["n_quantities"], n_bad=rep["n_bad"], bad=rep["bad"],
-               kink_elements_aligned=rep["kink_elements_aligned"], **{"kink_elements_within_1e-2": rep["kink_elements_within_1e-2"]})
+               kink_elements_aligned=rep["kink_elements_aligned"], kink_sign_disagreements=rep.get("kink_sign_disagreements"),
+               **{"kink_elements_within_1e-2": rep["kink_elements_within_1e-2"]})
     for kind, key in (("losses", "loss_rel"), ("enc_maps", "enc_maps_rel"), ("grads", "grad_rel"), ("other", "latents_embed_ehat_rel"),
                       ("adamw", "adamw_step_rel")):
         if kind in rep:
