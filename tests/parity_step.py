@@ -50,6 +50,11 @@ FLOOR = 3e-3
 # its entry) full_sd14, each with the measurement that asked for it.  Each report counts the elements it re-branched and how many of them a 1e-2 band would have (`kink_elements_aligned`,
 # `kink_elements_within_1e-2`); E4T_KINK_TOL overrides the band of every case for experiments.
 KINK_TOL_ENV = float(os.environ["E4T_KINK_TOL"]) if os.environ.get("E4T_KINK_TOL") else None
+# Opt-in (round 4, prepared for the next GPU run of all cases; default off = the per-case constants above): E4T_KINK_SIGMA=k makes the band a
+# MEASUREMENT — k x the stock-autocast leg's own error at each LeakyReLU input, rms(autocast - oracle) / median|x| — instead of a name, and adds
+# the native error at those inputs to the compared quantities (`kink_input_0/1`, under the same 2 x autocast + FLOOR rule): an element may follow
+# a leg's branch exactly when its value lies inside k standard deviations of the error the calibration shows to be normal there.
+KINK_SIGMA_ENV = float(os.environ["E4T_KINK_SIGMA"]) if os.environ.get("E4T_KINK_SIGMA") else None
 KINK_TIGHT = 1e-2
 ADAM = dict(lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)      # the optimiser step both legs take (torch.optim.AdamW defaults, pretrain_e4t.py:387-392)
 
@@ -241,8 +246,11 @@ class _Kinks:
     """Records the inputs of the encoder's two LeakyReLUs (call order: unet_feature_embedder.1, act) and, given another
     leg's recorded inputs, makes the ambiguous elements take that leg's branch."""
 
-    def __init__(self, enc, follow=None, band=1e-2):
+    def __init__(self, enc, follow=None, band=1e-2, sigma=None, sigma_ref=None):
+        """sigma = k: the band at input i is k x sigma_ref[i] (a calibration leg's measured error there) or, without sigma_ref, k x this
+        leg's own error — used for the calibration legs themselves"""
         self.seen, self.follow, self.aligned, self.aligned_tight, self.band = [], follow, 0, 0, band
+        self.sigma, self.sigma_ref, self.bands_used = sigma, sigma_ref, []
         self.disagree, self.err_scale = [], []       # report only: |x| / median|x| of every sign-disagreeing element; rms(leg - oracle) / median|x|
         self.handles = [m.register_forward_hook(self._hook) for m in (enc.unet_feature_embedder[1], enc.act)]
 
@@ -255,9 +263,12 @@ class _Kinks:
         other = self.follow[i].to(x.device).reshape(x.shape)
         differ = torch.sign(other) != torch.sign(x.detach())
         med = x.detach().abs().median()
-        amb = (x.detach().abs() <= self.band * med) & differ
+        err = float((other.float() - x.detach().float()).pow(2).mean().sqrt() / med)
+        band = self.band if self.sigma is None else self.sigma * (self.sigma_ref[i] if self.sigma_ref is not None else err)
+        self.bands_used.append(band)
+        amb = (x.detach().abs() <= band * med) & differ
         self.disagree += sorted(float(v) for v in (x.detach().abs()[differ] / med).flatten().tolist())
-        self.err_scale.append(float((other.float() - x.detach().float()).pow(2).mean().sqrt() / med))
+        self.err_scale.append(err)
         self.aligned += int(amb.sum())
         self.aligned_tight += int(((x.detach().abs() <= KINK_TIGHT * x.detach().abs().median()) & differ).sum())
         pos = torch.where(amb, other > 0, x.detach() > 0)
@@ -268,7 +279,7 @@ class _Kinks:
             h.remove()
 
 
-def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collect=True, follow_kinks=None):
+def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collect=True, follow_kinks=None, sigma_ref=None):
     """fp32 on the CPU = the reference answer; autocast=True on `dev` = the calibration leg (on copies of the models).
     follow_kinks: another leg's recorded LeakyReLU inputs (see _Kinks).  Returns the results dict; ["_kinks"] holds this
     leg's own recorded inputs, ["_aligned"] the number of elements that followed."""
@@ -283,7 +294,7 @@ def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collec
     acp = mv(orc.ddpm_alphas_cumprod())
     ctx_mgr = torch.autocast(dev.type, dtype=torch.bfloat16) if autocast else torch.autocast(dev.type, enabled=False)
     out = {}
-    kinks = _Kinks(enc, follow_kinks, band=case.band)
+    kinks = _Kinks(enc, follow_kinks, band=case.band, sigma=KINK_SIGMA_ENV, sigma_ref=sigma_ref)
     ehat = {}
     eh = enc.register_forward_hook(lambda m, a, y: ehat.__setitem__("y", y.detach().float()))
     with ctx_mgr:
@@ -324,7 +335,10 @@ def oracle_leg(case: Case, o, d, dev=torch.device("cpu"), autocast=False, collec
         out[f"upd/{n}"] = -ADAM["lr"] * (g / (g.abs() + ADAM["eps"]) + ADAM["weight_decay"] * p.detach().float())
     out = {k: v.cpu() for k, v in out.items()}
     out["_kinks"], out["_aligned"], out["_aligned_tight"] = kinks.seen, kinks.aligned, kinks.aligned_tight
-    out["_kink_disagree"], out["_kink_err_scale"] = sorted(kinks.disagree), kinks.err_scale
+    out["_kink_disagree"], out["_kink_err_scale"], out["_kink_bands"] = sorted(kinks.disagree), kinks.err_scale, kinks.bands_used
+    if follow_kinks is not None and KINK_SIGMA_ENV is not None:
+        for i, (mine, theirs) in enumerate(zip(kinks.seen, follow_kinks)):      # the leg's LeakyReLU inputs become compared quantities
+            out[f"kink_input_{i}"] = mine.reshape(theirs.shape)
     return out
 
 
@@ -436,12 +450,15 @@ def compare(case: Case, nat, ref, cals, verbose=True, strict=True):
         if not (e <= bound):
             bad.append((k, e, c))
     kinds = dict(enc_maps=[r for r in rows if r[0].startswith("enc_map")], losses=[r for r in rows if r[0].startswith("loss")],
-                 grads=[r for r in rows if r[0].startswith("grad/")], other=[r for r in rows if r[0] in ("latents", "domain_embed", "e_hat", "grad_norm")],
+                 grads=[r for r in rows if r[0].startswith("grad/")],
+                 other=[r for r in rows if r[0] in ("latents", "domain_embed", "e_hat", "grad_norm") or r[0].startswith("kink_input_")],
                  adamw=[r for r in rows if r[0].startswith("upd/")])
     worst = lambda rs: max(rs, key=lambda r: r[1]) if rs else None
     ratio = lambda rs: max(rs, key=lambda r: r[1] / (2 * r[2] + FLOOR)) if rs else None
     rep = dict(case=case.name, n_quantities=len(rows), n_bad=len(bad), calibration_legs=len(cals),
-               kink_elements_aligned=dict(native=ref.get("_aligned", 0), autocast=[r.get("_aligned", 0) for _, r in cals], band=case.band),
+               kink_elements_aligned=dict(native=ref.get("_aligned", 0), autocast=[r.get("_aligned", 0) for _, r in cals],
+                                          band=case.band if KINK_SIGMA_ENV is None else dict(sigma=KINK_SIGMA_ENV, native=ref.get("_kink_bands"),
+                                                                                             autocast=[r.get("_kink_bands") for _, r in cals])),
                **{"kink_elements_within_1e-2": dict(native=ref.get("_aligned_tight", 0), autocast=[r.get("_aligned_tight", 0) for _, r in cals])})
     # what the band is measured against: |x_oracle| / median|x| of EVERY element whose sign the leg disagrees on (largest 12), and the leg's
     # own error at the two LeakyReLU inputs, rms(leg - oracle) / median|x| — an element can flip when its value is inside that error
@@ -486,8 +503,14 @@ def evaluate(case: Case, o, d, nat, dev, verbose=True, strict=True, timings=None
     if case.cpu_calib and dev.type != "cpu":
         legs.append(oracle_leg(case, o, d, dev=torch.device("cpu"), autocast=True))      # ... and on the CPU (oneDNN)
     if case.align_kinks:
-        ref_nat = oracle_leg(case, o, d, follow_kinks=nat["_kinks"])
         cals = [(c, oracle_leg(case, o, d, follow_kinks=c["_kinks"])) for c in legs]
+        sigma_ref = None
+        if KINK_SIGMA_ENV is not None:        # the native leg's band: k x the largest calibration error at each LeakyReLU input
+            sigma_ref = [max(r["_kink_err_scale"][i] for _, r in cals) for i in range(len(cals[0][1]["_kink_err_scale"]))]
+            for c, _ in cals:
+                c.update({f"kink_input_{i}": x for i, x in enumerate(c["_kinks"])})
+            nat.update({f"kink_input_{i}": x for i, x in enumerate(nat["_kinks"])})
+        ref_nat = oracle_leg(case, o, d, follow_kinks=nat["_kinks"], sigma_ref=sigma_ref)
     else:
         ref_nat, cals = ref, [(c, ref) for c in legs]
     if timings is not None:

@@ -62,6 +62,25 @@ def test_small_grids_follow_the_cost_model(shape, tile, splitk):
     assert pl.workspace_bytes == (splitk * shape[0] * shape[1] * 4 if splitk > 1 else 0)
 
 
+def test_cost_model_respects_what_each_instantiation_can_do():
+    # the GENERAL epilogue (exact GELU, per-row row-bias lookup) exists for the 64 x 64 (3-stage) and 128 x 128 (2-stage) tiles only
+    for shape in [(257, 5120, 1280), (576, 5120, 1280), (1028, 5120, 1280), (77, 3072, 768)]:
+        assert gemm_plan(*shape, flags=_C.ACT_GELU).tile in (64, 128), shape
+        assert gemm_plan(*shape, rowbias=True, rows_per_batch=77).tile in (64, 128), shape
+    # N % 160 != 0 never gets the 128 x 160 tile; ragged M / N / K are priced by whole tiles
+    for shape in [(4096, 1024, 1280), (1000, 200, 328), (130, 72, 1032), (4097, 1281, 1283)]:
+        pl = gemm_plan(*shape)
+        assert pl.tile in (64, 128) and pl.tile_n == pl.tile, (shape, pl.tile)
+    # an explicit split is kept as asked (only the tile and its depth are chosen around it); an explicit tile bypasses the model
+    pl = gemm_plan(1024, 1280, 5120, splitk=2)
+    assert pl.splitk == 2 and pl.workspace_bytes == 2 * 1024 * 1280 * 4
+    assert gemm_plan(576, 1280, 1280, tile=128).tile == 128 and gemm_plan(4096, 1280, 1280, tile=3128).tile == 128
+    # split-K keeps at least four K-tiles per split and never splits a one-K-tile GEMM
+    assert gemm_plan(77, 1024, 64).splitk == 1 and gemm_plan(16, 1280, 192).splitk == 1
+    # batched and batch-reducing GEMMs (the grouped E4T head) stay with the rules: the model prices single GEMMs
+    assert gemm_plan(1280, 1280, 8, batch=129, flags=_C.OUT_F32 | _C.REDUCE_BATCH).splitk >= 1
+
+
 def test_deep_k_small_grid_uses_ping_pong_with_split_k_and_reports_the_workspace():
     M, N, K = 4096, 1280, 10240                  # 80 tiles of 256 x 256 on 256 CUs, 160 K-tiles
     pl = gemm_plan(M, N, K)
