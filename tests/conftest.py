@@ -4,6 +4,12 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if not os.path.exists("/dev/kfd"):
+    # No GPU here (set before torch / libgomp load): idle OpenMP workers sleep instead of spinning.  Measured on the 8-core build container
+    # (round 4, whole `-m "not gpu"` suite): quiet box 3 min 49 s passive / 2 min 31 s spinning; with six busy neighbour processes
+    # 5 min 06 s passive / 13 min 46 s spinning — the 20-40-minute runs of earlier rounds were spinning workers fighting the neighbours.
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
 for p in (os.path.join(ROOT, "e4t-diffusion_amd"), ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
