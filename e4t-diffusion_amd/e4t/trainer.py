@@ -91,11 +91,12 @@ class E4TTrainer:
         # at the tail of the step (102.13 / 102.23 against 102.12 / 102.35 ms).
         self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit+vae")
         self._next_px, self._pref = None, {}          # announced batch; finished / running prefetches by id(pixel tensor)
+        self._next_eps = None                         # the VAE's sampling noise for the announced batch (tests); None = drawn when the prefetch starts
         # whole-step HIP graph (enable_step_graph): signature -> captured graph + its static tensors; device copy of AdamW's
         # step-dependent scalars
         self._step_graph_on = False
         self._step_graphs, self._seen_sigs = {}, set()
-        self._hyper = self._hyper_host = None
+        self._hyper, self._hyper_ring, self._hyper_i = None, [], 0
         self._capturing = False
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
@@ -293,7 +294,7 @@ class E4TTrainer:
         pref = dict(px=px, vision=None, latents=None)
         if "vae" in self.prefetch_mode and self.vae is not None:
             hl, wl = px.shape[2] // 8, px.shape[3] // 8
-            eps, self._next_eps = getattr(self, "_next_eps", None), None
+            eps, self._next_eps = self._next_eps, None
             pref["vae_eps"] = eps if eps is not None else torch.randn((px.shape[0], 4, hl, wl), device=px.device)      # drawn on the main stream
         if "vit" in self.prefetch_mode:
             pref["vision"] = self._launch_vision(px)          # (waits for the main stream's position: the start of the backward)
@@ -457,13 +458,22 @@ class E4TTrainer:
             return False
         self._step_graph_on = bool(on)
         if on and self._hyper is None:
+            # allocated once and kept for the trainer's lifetime: captured graphs hold its raw pointer
             self._hyper = torch.zeros(4, dtype=f32, device=self.device)
-            self._hyper_host = torch.zeros(4, dtype=f32).pin_memory()
+            self._hyper_ring = [[torch.zeros(4, dtype=f32).pin_memory(), None] for _ in range(self._HYPER_SLOTS)]
         if not on:
-            self._hyper = self._hyper_host = None
+            # graphs own whole-step memory pools: drop them (a later enable re-captures); _hyper stays
+            self._step_graphs, self._seen_sigs = {}, set()
         return self._step_graph_on
 
+    _HYPER_SLOTS = 8
+
     def _write_hyper(self):
+        """AdamW's step-dependent scalars -> device memory, ordered on the step's stream.  With graph replay the host enqueues a step in
+        ~1 ms against 40-100 ms of GPU work and runs several steps ahead, so ONE pinned staging buffer would be overwritten before
+        its queued copy executed (round-4 advisor finding: later steps' lr / bias corrections seen by earlier updates).  The staging is a
+        ring of pinned slots, each with the event of the copy that last read it; a slot is rewritten only after that copy has run,
+        which also bounds the host's lead to _HYPER_SLOTS steps."""
         import ctypes
         libm = getattr(E4TTrainer, "_libm", None)
         if libm is None:
@@ -472,12 +482,19 @@ class E4TTrainer:
             libm.sqrtf.restype, libm.sqrtf.argtypes = ctypes.c_float, [ctypes.c_float]
         f = lambda x: ctypes.c_float(x).value
         t = float(self.step_count)
+        slot = self._hyper_ring[self._hyper_i % len(self._hyper_ring)]
+        self._hyper_i += 1
+        host, ev = slot
+        if ev is not None:
+            ev.synchronize()
         # exactly e4t_adamw's host arithmetic (fp32 powf / sqrtf): 1 - beta1^t, sqrt(1 - beta2^t)
-        self._hyper_host[0] = self.lr
-        self._hyper_host[1] = f(1.0 - libm.powf(self.betas[0], t))
-        self._hyper_host[2] = libm.sqrtf(f(1.0 - libm.powf(self.betas[1], t)))
-        self._hyper_host[3] = 1.0 / self.world
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        host[0] = self.lr
+        host[1] = f(1.0 - libm.powf(self.betas[0], t))
+        host[2] = libm.sqrtf(f(1.0 - libm.powf(self.betas[1], t)))
+        host[3] = 1.0 / self.world
+        self._hyper.copy_(host, non_blocking=True)
+        ev = slot[1] = torch.cuda.Event()
+        ev.record()
 
     def _graphed_step(self, pixel_values, input_ids, placeholder_idx, noise, timesteps, vae_eps, latents):
         ins = dict(pixel_values=pixel_values, input_ids=input_ids, placeholder_idx=placeholder_idx, noise=noise, timesteps=timesteps,
@@ -528,15 +545,13 @@ class E4TTrainer:
         self.sync_replicas(include_moments=True)  # a per-rank-different checkpoint read must not start diverged replicas
         ops.bump_weights_epoch()                 # bf16 compute copies of the trainable weights are stale now
 
-    def train_step(self, *args, **kw):
+    def train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None,
+                   sync=True, loss_scale=1.0):
         """One training step (see _train_step); replayed from the step's HIP graph when enable_step_graph() is on and the call is a plain
         synchronising step."""
-        if self._step_graph_on and kw.get("sync", True) and kw.get("loss_scale", 1.0) == 1.0 and self._next_px is None and not self._pref:
-            names = ("pixel_values", "input_ids", "placeholder_idx", "noise", "timesteps", "vae_eps", "latents")
-            a = dict(zip(names, args))
-            a.update({k: v for k, v in kw.items() if k in names})
-            return self._graphed_step(*(a.get(k) for k in names))
-        return self._train_step(*args, **kw)
+        if self._step_graph_on and sync and loss_scale == 1.0 and self._next_px is None and not self._pref:
+            return self._graphed_step(pixel_values, input_ids, placeholder_idx, noise, timesteps, vae_eps, latents)
+        return self._train_step(pixel_values, input_ids, placeholder_idx, noise, timesteps, vae_eps, latents, sync, loss_scale)
 
     def _train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None,
                     sync=True, loss_scale=1.0):

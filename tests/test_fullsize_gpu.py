@@ -33,3 +33,18 @@ def test_full_sd14_batch16_step_matches_sixteen_single_sample_steps(hip_env):
         with open(os.path.join(out, "parity_full_sd14_batch16.json"), "w") as fh:
             json.dump(rep, fh, indent=1)
     assert rep["n_bad"] == 0, rep["bad"]
+
+
+def test_tuning_full_batch16_step_matches_sixteen_single_sample_steps(hip_env):
+    """BASELINE configs[3] at the size bench.py's `secondary` block times it (tuning_e4t.py:266-338): full SD-1.4 UNet on 64 x 64 latents,
+    every UNet weight trainable — 3x3-conv dW through im2col + split-K TN GEMM at M = 16 x 4096 rows — ViT-H-14, B = 16, against sixteen
+    B = 1 steps of the same samples (the ORACLE leg of the tuning step is `tuning_real_width`, test_configs_gpu.py).  Was an offline
+    tool call in round 4 (tools/gpu_r04_a.sh); 27 s."""
+    import parity_step
+    rep = parity_step.batch_consistency("tuning_full", torch.device("cuda:0"), B=16)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_tuning_full_batch16.json"), "w") as fh:
+            json.dump(rep, fh, indent=1)
+    assert rep["n_bad"] == 0, rep["bad"]
+    assert rep["n_quantities"] > 1700           # every UNet parameter's gradient, not only the weight offsets

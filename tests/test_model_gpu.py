@@ -223,3 +223,47 @@ def test_step_graph_replay_equals_eager(hip_env, given):
     assert n0 == 0 and n1 == 1
     assert torch.equal(l0, l1), (l0, l1)
     assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+
+
+def test_step_graph_replays_queued_ahead_keep_their_own_adamw_scalars(hip_env):
+    """Round-4 advisor finding: with graph replay the host enqueues a step far faster than the GPU runs it, so several steps' worth of
+    AdamW scalars (lr, 1 - beta1^t, sqrt(1 - beta2^t)) are in flight at once; each queued update must see the values of ITS step.  The
+    device is held busy (torch.cuda._sleep) while six replays are enqueued with no synchronisation in between; losses and parameters
+    must equal the eager run that synchronises every step, bit for bit (bc1 is 0.1 at t = 1 and 0.41 at t = 5: a mixed-up step is an
+    O(1) difference in the update)."""
+    from test_train_step_host_logic import TEXT_CFG, build
+    from e4t.text import CLIPTextModel
+    from e4t.trainer import E4TTrainer
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(13)
+    B, steps = 2, 8
+    batches = [(torch.rand(B, 3, 128, 128, generator=g) * 2 - 1, torch.randn(B, 4, 16, 16, generator=g), torch.randn(B, 4, 16, 16, generator=g),
+                torch.randint(0, 1000, (B,), generator=g), torch.randint(1, 99, (B, 9), generator=g)) for _ in range(steps)]
+    pidx = torch.tensor([2, 4], device=dev)
+
+    def run(graph):
+        _, _, n_unet, n_enc, text_t = build(seed=0)
+        text = CLIPTextModel(**TEXT_CFG).requires_grad_(False)
+        text.load_state_dict(text_t.state_dict())
+        n_unet.to(dev), n_enc.to(dev), text.to(dev)
+        tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev), device=dev)
+        if graph:
+            assert tr.enable_step_graph(True)
+        dbatches = [tuple(t.to(dev) for t in b) for b in batches]
+        losses = []
+        for i, (px, lat, noise, t, ids) in enumerate(dbatches):
+            if graph and i == 2:
+                torch.cuda.synchronize()
+                torch.cuda._sleep(int(1.5e9))          # ~0.7 s of busy device: every remaining replay is enqueued behind it
+            out = tr.train_step(px, ids, pidx, noise=noise, timesteps=t, latents=lat)
+            losses.append(torch.stack([o.detach().float() for o in out]))
+            if not graph:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), tr.flat.data.detach().cpu().clone(), len(tr._step_graphs)
+
+    l0, p0, n0 = run(False)
+    l1, p1, n1 = run(True)
+    assert n0 == 0 and n1 == 1
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
