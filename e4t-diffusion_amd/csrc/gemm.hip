@@ -505,6 +505,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : 1) vo
   } else {
     write_tile<WM, WN, FM, FN, GENERAL>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
   }
+  // tail rows: only in the 128 x 160 instantiations (and the ping-pong kernels), which have the registers for its 16 loads in flight — inlined
+  // into the 64 / 128 / 256 x 128 tiles it cost them an occupancy step (92 -> 162 VGPRs on the 128 x 128 tile); the planner knows (plan_gemm_tail)
+  if constexpr (MODE == 0 && BN == 160) {
+    static_assert(NSTAGE * TILE * 2 >= NW * 16 * 64 * 4, "tail reduction must fit the operand buffers");
+    if (p.tail_rows) gemm_tail<NW, GENERAL>(p, (float*)smem, wave, lane);      // (its first barrier orders it behind the staging reads above)
+  }
 #endif
   DT(12);
 }
@@ -820,6 +826,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   write_tile<64, 64, 2, 2, GENERAL>(p, *(f32x16(*)[2][2])(acc + 0), wave_stage<64, 64>(smem, wave), lane, m0 + wr * 128, n0 + wc * 64);
   __syncthreads();
   write_tile<64, 64, 2, 2, GENERAL>(p, *(f32x16(*)[2][2])(acc + 2), wave_stage<64, 64>(smem, wave), lane, m0 + wr * 128 + 64, n0 + wc * 64);
+  if constexpr (MODE == 0) {
+    if (p.tail_rows) gemm_tail<8, GENERAL>(p, (float*)smem, wave, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1111,6 +1120,9 @@ __global__ __launch_bounds__(512) void gemm_pq_kernel(GemmArgs p) {
     slice(I2{});
     __syncthreads();
     slice(I3{});
+  }
+  if constexpr (MODE == 0) {
+    if (p.tail_rows) gemm_tail<8, GENERAL>(p, (float*)smem, wave, lane);
   }
 }
 
@@ -1815,8 +1827,31 @@ size_t plan_workspace_bytes(const GemmPlan& pl, const GemmArgs& p, int batch) {
   return (pl.splitk > 1 || p.reduce_batch) ? (size_t)pl.splitk * batch * p.M * p.N * sizeof(float) : 0;
 }
 
+// Tail rows (gemm_common.h, gemm_tail): a dense GEMM whose M is a multiple of 128 plus at most 32 rows — the CLIP-ViT's 16 x 257 =
+// 4112 token rows — is planned for its first M - r rows; the r tail rows are computed at the end of the same launch.  Returns the plan
+// and sets `tail` (0: the ordinary plan over all M rows).  The plan of the M - r rows must be a single pass of one of the LDS-DMA kernels
+// that carry the tail code (128 x 160, 256 x 256 and 256 x 320 tiles): anything else falls back to the plan over all rows.  E4T_GEMM_NOTAIL=1: A/B switch.
+GemmPlan plan_gemm_tail(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, int batch, int& tail) {
+  static const bool no_tail = getenv("E4T_GEMM_NOTAIL") != nullptr && getenv("E4T_GEMM_NOTAIL")[0] == '1';
+  static const bool use_dma = getenv("E4T_GEMM_REGSTAGE") == nullptr;
+  tail = 0;
+  const int r = p.M % 128;
+  if (!no_tail && use_dma && !conv && batch == 1 && !p.reduce_batch && !p.A2 && !p.panel_rows && !p.colstats && splitk_req <= 1 && r > 0 && r <= 32 &&
+      p.M - r >= 1024 && p.K % 16 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && (((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0) {
+    GemmArgs q = p;
+    q.M = p.M - r;
+    const GemmPlan pl = plan_gemm(q, conv, tile_hint, splitk_req, batch);
+    const bool kernel_ok = pl.buf_ok && pl.splitk == 1 && (pl.tile == 160 || pl.tile == 512 || pl.tile == 2320);      // the kernels that carry gemm_tail()
+    if (kernel_ok) { tail = r; return pl; }
+  }
+  return plan_gemm(p, conv, tile_hint, splitk_req, batch);
+}
+
 int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int splitk_req, int batch, hipStream_t st) {
-  const GemmPlan pl = plan_gemm(p, conv, tile_hint, splitk_req, batch);
+  int tail = 0;
+  const GemmPlan pl = plan_gemm_tail(p, conv, tile_hint, splitk_req, batch, tail);
+  const int m_all = p.M;                 // (launch log: the caller's shape)
+  if (tail) { p.M -= tail; p.tail_row0 = p.M; p.tail_rows = tail; }      // the tile grid covers [0, M - tail); gemm_tail() the rest
   const int nkt = cdiv(p.K, BK);
   const int tile = pl.tile, stages = pl.stages, gx = pl.gx, gy = pl.gy;
   const bool kt32 = pl.kt32, general_epi = pl.general_epi, buf_ok = pl.buf_ok;
@@ -1883,8 +1918,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     }
     if (conv) E4T_LOG_LAUNCH("%s|conv mode%d %dx%d->%dx%d Cin%d Cout%d M%d splitk%d|%.0f|%.0f", sym, p.mode, p.Hin, p.Win, p.Hout, p.Wout, p.Cin, p.N,
                              p.M, splitk, by, 2.0 * p.M * p.N * (double)p.K);
-    else E4T_LOG_LAUNCH("%s|gemm M%d N%d K%d batch%d splitk%d flags%d|%.0f|%.0f", sym, p.M, p.N, p.K, batch, splitk, p.flags, by,
-                        2.0 * p.M * p.N * (double)p.K * batch);
+    else E4T_LOG_LAUNCH("%s|gemm M%d N%d K%d batch%d splitk%d flags%d|%.0f|%.0f", sym, m_all, p.N, p.K, batch, splitk, p.flags,
+                        by + (double)tail * (2.0 * p.K + (osz + (p.residual ? ((p.flags & E4T_RES_F32) ? 4.0 : 2.0) : 0.0)) * p.N), 2.0 * m_all * p.N * (double)p.K * batch);
     if (p.ws) E4T_LOG_LAUNCH("%s|M%d N%d nz%d|%.0f|0", vec8 ? "splitk_reduce8_kernel" : "splitk_reduce_kernel",
                              p.M, p.N, p.reduce_batch ? splitk * batch : splitk, 4.0 * (double)p.M * p.N * splitk * batch + osz * (double)p.M * p.N);
   }
@@ -2037,9 +2072,10 @@ int tn_splitk(int M, int N, int K, int req) {
   return cdiv(nkt, cdiv(nkt, splitk));
 }
 
-void export_plan(const GemmPlan& pl, const GemmArgs& p, int batch, e4t_gemm_plan_t* out) {
+void export_plan(const GemmPlan& pl, const GemmArgs& p, int batch, e4t_gemm_plan_t* out, int tail = 0) {
   out->tile = pl.kt32 ? 5000 + pl.tile : pl.tile; out->tile_m = pl.tm; out->tile_n = pl.tn; out->splitk = pl.splitk;
   out->workspace_bytes = plan_workspace_bytes(pl, p, batch);
+  out->tail_rows = tail; out->reserved = 0;
 }
 
 }  // namespace
@@ -2049,7 +2085,9 @@ extern "C" int e4t_gemm_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out) {
   GemmArgs p;
   fill_gemm_args(d, p);
   const int batch = d->batch > 0 ? d->batch : 1;
-  export_plan(plan_gemm(p, false, d->tile, d->splitk, batch), p, batch, out);
+  int tail = 0;
+  const GemmPlan pl = plan_gemm_tail(p, false, d->tile, d->splitk, batch, tail);
+  export_plan(pl, p, batch, out, tail);      // (no workspace with tail rows: their plan is a single pass)
   return 0;
 }
 
@@ -2063,7 +2101,7 @@ extern "C" int e4t_conv3x3_plan(const e4t_conv_desc* d, e4t_gemm_plan_t* out) {
 
 extern "C" int e4t_gemm_tn_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out) {
   E4T_REQUIRE(d && out && d->M > 0 && d->N > 0 && d->K > 0, "gemm_tn_plan: bad arguments");
-  out->tile = 128; out->tile_m = out->tile_n = 128;
+  out->tile = 128; out->tile_m = out->tile_n = 128; out->tail_rows = out->reserved = 0;
   out->splitk = tn_splitk(d->M, d->N, d->K, d->splitk);
   out->workspace_bytes = out->splitk > 1 ? (size_t)out->splitk * d->M * d->N * sizeof(float) : 0;
   return 0;

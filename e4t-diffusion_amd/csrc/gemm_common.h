@@ -43,6 +43,9 @@ struct GemmArgs {
   // r % panel_rows.  panel_rows = 0: dense.  Lets the 16 x 256 patch tokens of a [16][257] ViT token matrix run as 16 full 256-row tiles.
   int panel_rows, panel_stride, panel_off;
   int zslab;        // partial-slab index of this workgroup when it is not blockIdx.z (set in-kernel by a re-dealing kernel; host: -1)
+  // Tail rows (dense GEMMs, round 5): the tile grid covers rows [0, M) and the few rows [tail_row0, tail_row0 + tail_rows) behind it
+  // (tail_rows <= 32, 0 = none) are computed by gemm_tail() at the end of the same launch — see there.
+  int tail_row0, tail_rows;
   long long strideA, strideB, strideC, strideBias;
   float* colstats;                       // optional [M/32][N][2] column statistics of the output (fast bf16 epilogue only)
   unsigned a_bytes, a2_bytes, b_bytes;   // operand extents from the (batch-adjusted) base pointers, for buffer resources (pp kernel)
@@ -54,11 +57,12 @@ constexpr int BK = 64;        // K-tile (bf16 elements)
 constexpr int LDS_LD = BK + 8;  // padded LDS row stride (elements): 144 B
 
 
+template <bool GELU_OK = true>
 __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float v, int row, int col) {
   v *= p.alpha;
   if (p.bias) v += p.bias[col];
   if (p.rowbias) v += p.rowbias[(size_t)(row / p.rows_per_batch) * p.ldrb + col];
-  if (p.flags & E4T_ACT_GELU) v = gelu_f(v);
+  if constexpr (GELU_OK) { if (p.flags & E4T_ACT_GELU) v = gelu_f(v); }
   if (p.residual) {
     if (p.flags & E4T_RES_F32) v += ((const float*)p.residual)[(size_t)row * p.ldr + col];
     else v += bf2f(((const bf16_t*)p.residual)[(size_t)row * p.ldr + col]);
@@ -399,6 +403,69 @@ __device__ __forceinline__ unsigned cm_shift_bytes(const GemmArgs& p) { return (
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t cm_rsrc(const GemmArgs& p) {
   const unsigned sh = cm_shift_bytes(p);
   return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - sh), 0, (int)(p.a_bytes + sh), 0x00020000);
+}
+
+// ---- tail rows of a dense GEMM -------------------------------------------------------------------------------------------------
+// The CLIP-ViT's token matrix at B = 16 has 16 x 257 = 4112 = 32 x 128 + 16 rows.  Every tiling of 4112 rows pays a whole extra
+// round of workgroups for the last 16: measured in the step (profiles/r04_prefetch_off_roofline_per_shape.csv), the SAME N / K at
+// M = 4096 (the UNet's 16 x 16 level) and at M = 4112 take 24.7 vs 44.9 us (N1280 K1280), 73.6 vs 89.6 + 35.9 us (N1280 K5120: the
+// 4112-row plan needs split-K and its reduce), 58.7 vs 94.6 us (N5120 K1280).  The launcher therefore plans such a GEMM for its
+// first M - r rows (r = M % 128 <= 32) and hands the r tail rows to this function, which runs at the END of the same launch in the
+// workgroups with the lowest linear ids: one 32-column block of the tail per workgroup, the K range split evenly over the workgroup's
+// waves, operands read straight from global memory into MFMA fragments (16 bytes per lane and k-step for each operand: the
+// fragment layout of v_mfma_f32_32x32x16_bf16 is 8 consecutive k per lane, no LDS needed), the waves' partial accumulators summed
+// through LDS in wave order (deterministic), then the ordinary scalar epilogue.  A 16 x N x K tail is 0.4 % of the GEMM's work.
+// Requires: dense A (no second source, no panels), no split-K / batch, K % 16 == 0, 16-byte aligned rows (the launcher checks).
+// `red`: NW x 16 x 64 floats of LDS (the kernel's operand buffers: dead after the main epilogue).
+// (GELU only in the GENERAL instantiations, as everywhere else: its expansion next to a plain epilogue costs registers)
+template <int NW, bool GENERAL>
+__device__ __forceinline__ void gemm_tail(const GemmArgs& p, float* red, int wave_v, int lane) {
+  const int wave = __builtin_amdgcn_readfirstlane(wave_v);   // (uniform by construction: scalar loop control)
+  const int nblk = (p.N + 31) >> 5;
+  const int lin = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+  if (lin >= nblk) return;                                   // workgroup-uniform
+  const int ksteps = p.K >> 4;
+  const int per = (ksteps + NW - 1) / NW;
+  const int ks0 = wave * per, ks1 = min(ks0 + per, ksteps);
+  const int frow = lane & 31, fhi = lane >> 5;
+  // rows >= tail_rows of the 32-row fragment re-read the last valid row: row i of C depends on row i of A only, and those rows are never stored
+  const bf16_t* Ap = p.A + (size_t)(p.tail_row0 + min(frow, p.tail_rows - 1)) * p.lda + fhi * 8;
+  for (int blk = lin; blk < nblk; blk += nwg) {
+    const int n0 = blk << 5;
+    const bf16_t* Bp = p.B + (size_t)min(n0 + frow, p.N - 1) * p.ldb + fhi * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int ks = ks0;
+    for (; ks + 8 <= ks1; ks += 8) {                         // 16 independent 16-byte loads in flight per lane
+      bf16x8 a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a[u] = *(const bf16x8*)(Ap + (ks + u) * 16);
+        b[u] = *(const bf16x8*)(Bp + (ks + u) * 16);
+      }
+      __builtin_amdgcn_sched_barrier(0);                     // all 16 loads leave before the first MFMA waits for one (the scheduler rolled them into a 6-deep window)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; ks < ks1; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(Ap + ks * 16), *(const bf16x8*)(Bp + ks * 16), acc, 0, 0, 0);
+    __syncthreads();                                         // the LDS is free: main epilogue / previous block's reduction done
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+      const int col = n0 + frow;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[(w * 16 + r) * 64 + lane];
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fhi;    // C/D layout of the 32 x 32 MFMA
+        if (row < p.tail_rows && col < p.N) epilogue_store<GENERAL>(p, v, p.tail_row0 + row, col);
+      }
+    }
+  }
 }
 
 template <int N>

@@ -131,6 +131,11 @@ typedef struct {
   int tile, tile_m, tile_n;
   int splitk;
   size_t workspace_bytes;
+  /* > 0: the last `tail_rows` (<= 32) rows of a dense GEMM whose M is a multiple of 128 plus a few rows (the CLIP-ViT's 16 x 257 = 4112
+   * token rows, [3P] open_clip via e4t/encoder.py:154) are computed by a tail stage at the end of the same launch and the tile, split-K and
+   * workspace above are those of the first M - tail_rows rows (gemm.hip: plan_gemm_tail) */
+  int tail_rows;
+  int reserved;
 } e4t_gemm_plan_t;
 int e4t_gemm_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out);
 int e4t_gemm_tn_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out);

@@ -128,6 +128,29 @@ def check_gemm(hip, emu, dev):
     hip.gemm(a1, b[:, :K1].contiguous(), out=c1, accum=True, alpha=0.5)
     emu.gemm(a1, b[:, :K1].contiguous(), out=c2, accum=True, alpha=0.5)
     out.append(("gemm fp32 out + accumulate + alpha", rel(c1, c2), TOLF * 50))
+    # tail rows (round 5): M = 128 k + r, r <= 32 — the tile grid covers M - r rows, gemm_tail() computes the rest at the end of the launch
+    # (the CLIP-ViT's 16 x 257 = 4112 token rows).  The tail rows are ALSO compared on their own: 16 of 4112 rows move the whole-matrix
+    # rel-L2 by 6 % when they are garbage but a subtler error would drown in it.
+    gt = gen(35, dev)
+    import ctypes as _ct
+    from e4t import _C as _Cm
+    for (Mt, Nt, Kt, kw) in [(4112, 1280, 1280, dict(f32=True)), (4112, 5120, 1280, dict(gelu=True)), (4112, 1280, 5120, dict(f32=True)), (4112, 3840, 1280, {}),
+                             (8224, 1280, 1280, dict(res=True)), (8224, 5120, 1280, dict(gelu=True)), (4096 + 1, 1280, 1280, dict(res=True)), (4096 + 31, 3840, 1280, {}),
+                             (4112, 1280, 1296, dict(f32=True)), (2056, 1280, 5120, {})]:
+        at, bt = rnd(gt, Mt, Kt, dev=dev), rnd(gt, Nt, Kt, scale=Kt ** -0.5, dev=dev)
+        bi = rnd(gt, Nt, dtype=f32, dev=dev)
+        res = rnd(gt, Mt, Nt, dtype=f32 if kw.get("f32") else bf16, dev=dev) if (kw.get("f32") or kw.get("res")) else None
+        args = dict(bias=bi, residual=res, gelu=bool(kw.get("gelu")), out_dtype=f32 if kw.get("f32") else bf16)
+        d = _Cm.GemmDesc(M=Mt, N=Nt, K=Kt, K1=Kt, lda=Kt, ldb=Kt, ldc=Nt, batch=1, alpha=1.0,
+                         flags=(_Cm.OUT_F32 | _Cm.RES_F32 if kw.get("f32") else 0) | (_Cm.ACT_GELU if kw.get("gelu") else 0), residual=(1 << 20) if res is not None else None)
+        pl = _Cm.GemmPlan()
+        hip.lib.e4t_gemm_plan(_ct.byref(d), _ct.byref(pl))
+        y, yr = hip.gemm(at, bt, **args), emu.gemm(at, bt, **args)
+        tol = TOLF * 50 if kw.get("f32") else TOL1
+        r = pl.tail_rows
+        out.append((f"gemm {Mt}x{Nt}x{Kt} tail{r} t{pl.tile} {'gelu ' if kw.get('gelu') else ''}{'f32' if kw.get('f32') else 'bf16'}", rel(y, yr), tol))
+        out.append((f"gemm {Mt}x{Nt}x{Kt} tail{r}: the tail rows alone", rel(y[Mt - max(r, 1):], yr[Mt - max(r, 1):]) if r > 0 else 1.0, tol))
+        out.append((f"gemm {Mt}x{Nt}x{Kt} tail{r}: the last tile rows in front of the tail", rel(y[Mt - r - 64:Mt - r], yr[Mt - r - 64:Mt - r]), tol))
     # fp32 C + fp32 residual (the CLIP-ViT's fp32 residual stream): the line-wide direct-store epilogue, every kernel family
     gv = gen(33, dev)
     for (Mv, Nv, Kv, t) in [(4112, 1280, 1280, 0), (4112, 1280, 5120, 0), (1000, 1280, 320, 160), (700, 512, 256, 512), (513, 200, 64, 64), (2048, 256, 128, 1128), (900, 384, 96, 5256),
@@ -545,6 +568,13 @@ def check_gemm_races(hip, emu, dev):
             out.append((f"conv 32x32 640->640 tile code {code} vs the channel-major kernels", rel(r, ref), TOL2))
         differing = sum(int((run() != r).sum() > 0) for _ in range(6))
         out.append((f"conv 32x32 640->640 tile code {code}: launches (of 6) differing", float(differing), 0.0))
+    # tail rows (gemm_tail: cross-wave reduction through LDS in wave order, behind the tile epilogue's staging): repeated launches of the
+    # ViT's shapes on the 128 x 160 / 256 x 320 / 256 x 256 tiles must be bitwise reproducible
+    for (Mt, Nt, Kt, gelu) in [(4112, 1280, 5120, False), (4112, 5120, 1280, True), (4112, 3840, 1280, False)]:
+        at, bt = rnd(g, Mt, Kt, dev=dev), rnd(g, Nt, Kt, scale=Kt ** -0.5, dev=dev)
+        ref = hip.gemm(at, bt, gelu=gelu)
+        differing = sum(int((hip.gemm(at, bt, gelu=gelu) != ref).sum() > 0) for _ in range(12))
+        out.append((f"gemm {Mt}x{Nt}x{Kt} with tail rows: launches (of 12) differing", float(differing), 0.0))
     dy, xx = rnd(g, 16384, 640, dev=dev), rnd(g, 16384, 1280, dev=dev)
     ref = hip.gemm_tn(dy, xx)
     differing = sum(int((hip.gemm_tn(dy, xx) != ref).sum() > 0) for _ in range(12))

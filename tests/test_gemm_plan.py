@@ -109,9 +109,11 @@ def test_small_map_convs_split_k():
 
 def test_general_epilogue_tiles():
     # exact GELU and the per-row row-bias lookup (GENERAL epilogue, gemm_common.h) exist as 64 / 128 / 160 / 256 x 256 / 256 x 320 (GEMM only)
-    # instantiations.  The ViT's fc1 at M = 16 x 257 rows is 17 panels of 256: a second round for 16 rows, so it stays on 128 x 128 ...
-    assert gemm_plan(4112, 5120, 1280, flags=_C.ACT_GELU).tile == 128
-    # ... and goes to the 256 x 320 tile as 16 full panels (the patch tokens; e4t_gemm_desc.panel_*), one round on 256 CUs
+    # instantiations.  The ViT's fc1 at M = 16 x 257 rows is 17 panels of 256: a second round for 16 rows — since round 5 the planner
+    # hands those 16 rows to the tail stage and runs the other 4096 as ONE round of 256 x 320 tiles (test_tail_rows below) ...
+    pl = gemm_plan(4112, 5120, 1280, flags=_C.ACT_GELU)
+    assert (pl.tile, pl.tail_rows) == (2320, 16)
+    # ... as it does for 16 full panels (the patch tokens; e4t_gemm_desc.panel_*)
     pl = gemm_plan(4096, 5120, 1280, flags=_C.ACT_GELU, panels=(256, 257, 1))
     assert (pl.tile, pl.splitk, pl.workspace_bytes) == (2320, 1, 0)
     assert gemm_plan(65536, 320, 2560, flags=_C.ACT_GELU).tile == 2320
@@ -133,3 +135,28 @@ def test_tn_plan_reports_split_k_over_the_rows():
     pl = _C.GemmPlan()
     assert lib.e4t_gemm_tn_plan(C.byref(d), C.byref(pl)) == 0, lib.e4t_last_error()
     assert pl.splitk > 1 and pl.workspace_bytes == pl.splitk * 320 * 320 * 4
+
+
+def test_tail_rows():
+    """M = 128 k + r, r <= 32 (the CLIP-ViT's 16 x 257 = 4112 token rows): the plan is the plan of the first M - r rows, the r tail rows
+    are computed at the end of the same launch (gemm_common.h: gemm_tail) — every tiling of 4112 rows paid a whole extra round of
+    workgroups for the last 16 (same N / K at M = 4096 vs 4112 in the round-4 step: 24.7 vs 44.9 us, 73.6 vs 125.5 us, 58.7 vs 94.6 us)."""
+    for (M, N, K, flags), (tile, tail) in {
+            (4112, 1280, 1280, _C.OUT_F32 | _C.RES_F32): (160, 16),      # ViT attention out-proj (fp32 residual stream)
+            (4112, 1280, 5120, _C.OUT_F32 | _C.RES_F32): (160, 16),      # ViT fc2: no split-K (and no 84 MB of fp32 partials) any more
+            (4112, 5120, 1280, _C.ACT_GELU): (2320, 16),                 # ViT fc1: one round of 256 x 320 tiles
+            (4112, 3840, 1280, 0): (512, 16),                            # ViT qkv: 240 ping-pong tiles + tail (was 255 tiles)
+            (8224, 1280, 5120, 0): (160, 32),                            # B = 32: 64 x 128 + 32
+    }.items():
+        pl = gemm_plan(M, N, K, flags=flags)
+        ref = gemm_plan(M - tail, N, K, flags=flags)
+        assert (pl.tile, pl.tail_rows, pl.splitk, pl.workspace_bytes) == (tile, tail, 1, 0), (M, N, K, pl.tile, pl.tail_rows, pl.splitk)
+        assert (ref.tile, ref.tile_m, ref.tile_n, ref.tail_rows) == (pl.tile, pl.tile_m, pl.tile_n, 0)
+    # no tail: remainder too large / M too small / the plan of the main rows is not a single pass of a kernel that carries the tail code
+    assert gemm_plan(1232, 768, 3072).tail_rows == 0                    # text encoder: 1232 = 9 x 128 + 80
+    assert gemm_plan(257, 3840, 1280).tail_rows == 0                    # ViT at B = 1
+    assert gemm_plan(4112, 1000, 1280).tail_rows == 0                   # N fits none of the 160 / 256 / 320-wide tiles
+    assert gemm_plan(2056, 1280, 5120).tail_rows == 0                   # B = 8: the 2048 main rows want split-K on the 128 x 128 tile
+    assert gemm_plan(4112, 1280, 1280, splitk=3).tail_rows == 0         # an explicit split
+    assert gemm_plan(4112, 1280, 1280, rowbias=True, rows_per_batch=257).tail_rows in (0, 16)     # (allowed: the scalar epilogue handles row biases)
+    assert gemm_plan(4096 + 32, 1280, 1280).tail_rows == 32 and gemm_plan(4096 + 33, 1280, 1280).tail_rows == 0
