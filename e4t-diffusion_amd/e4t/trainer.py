@@ -270,8 +270,22 @@ class E4TTrainer:
 
     def _new_side_stream(self, device):
         """(HIP offers two stream priorities here, -1 and 0; running the step at -1 or the side stream "low" measured no difference:
-        101.3 vs 101.1-101.5 ms, profiles/r04_ab)"""
-        return torch.cuda.Stream(device=device)
+        101.3 vs 101.1-101.5 ms, profiles/r04_ab)
+        E4T_SIDE_CUS=n (experiment, round-4 review item 7): the side stream is created with hipExtStreamCreateWithCUMask and may only use n
+        of the 256 CUs (bit i of the mask = CU i / 8 of XCD i % 8: the first n bits take n / 8 CUs of every XCD), so that the main stream's
+        tile rounds keep the other CUs to themselves.  Result in DESIGN §2.6."""
+        n = int(os.environ.get("E4T_SIDE_CUS", "0") or 0)
+        if n <= 0 or device.type != "cuda":
+            return torch.cuda.Stream(device=device)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        words = 8                                   # 256 CUs
+        mask = (ctypes.c_uint32 * words)(*[((1 << max(0, min(32, n - 32 * w))) - 1) & 0xFFFFFFFF for w in range(words)])
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+        if rc != 0 or not st.value:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
+        return torch.cuda.ExternalStream(st.value, device=device)
 
     # ---- next-batch prefetch of the frozen front ends ---------------------------------------------------------------------
     # The CLIP-ViT tower (and the VAE encoder) of a step depend on the step's IMAGES only — not on any weight the optimiser
