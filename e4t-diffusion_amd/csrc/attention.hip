@@ -451,26 +451,27 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
 }
 
 // ================================================================================================
-// backward: Delta[b][h][q] = sum_d dO * O
+// backward: Delta[b][h][q] = sum_d dO * O — computed in the PROLOGUE of the dQ kernel (round 5; was a kernel of its own: 13 launches
+// per step that read O and dO once more).  The dQ kernel holds its 32 queries' dO rows as MFMA fragments anyway — lane (li, hi) owns
+// the 8-element slices [16 ks + 8 hi, +8) of row q = li — so Delta is the same slices of O multiplied in, summed per lane and across
+// the two halves of the wave.  It is written to p.Delta for the dK/dV kernel, which therefore runs AFTER the dQ kernel (launch_bwd).
 // ================================================================================================
 template <int DH>
-__global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p, int Bn) {
-  const long long total = (long long)Bn * p.H * p.T;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int q = (int)(i % p.T); const long long t = i / p.T; const int h = (int)(t % p.H); const int b = (int)(t / p.H);
-    const bf16_t* o = p.O + b * p.bo + (long long)q * p.ldo + h * DH;
-    const bf16_t* d = p.dO + b * p.bo + (long long)q * p.ldo + h * DH;
-    float s = 0.f;
+__device__ __forceinline__ float row_delta(const bf16_t* o_base, int ldo, int row, int R, int hi, const bf16x8* dof) {
+  bf16x8 of[Cfg<DH>::NKS];
+  load_row_frags<DH>(o_base, ldo, row, R, hi, of);
+  float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < DH / 8; ++c) {
-      float a[8], g[8];
-      unpack8(*(const uint4*)(o + c * 8), a);
-      unpack8(*(const uint4*)(d + c * 8), g);
+  for (int ks = 0; ks < Cfg<DH>::NKS; ++ks) {
+    Frag a, g;
+    a.v = of[ks]; g.v = dof[ks];
+    float x[8], y[8];
+    unpack8(a.q, x);
+    unpack8(g.q, y);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += a[k] * g[k];
-    }
-    p.Delta[i] = s;
+    for (int k = 0; k < 8; ++k) s = fmaf(x[k], y[k], s);
   }
+  return s + __shfl_xor(s, 32, 64);
 }
 
 // ================================================================================================
@@ -493,8 +494,12 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
   bf16x8 qf[C::NKS], dof[C::NKS];
   load_row_frags<DH>(p.Q + b * p.bq + h * DH, p.ldq, q, p.T, hi, qf);
   load_row_frags<DH>(p.dO + b * p.bo + h * DH, p.ldo, q, p.T, hi, dof);
-  float Lq = 0.f, Dq = 0.f;
-  if (q < p.T) { Lq = p.L[((long long)b * p.H + h) * p.T + q]; Dq = p.Delta[((long long)b * p.H + h) * p.T + q]; }
+  float Lq = 0.f;
+  const float Dq = row_delta<DH>(p.O + b * p.bo + h * DH, p.ldo, q, p.T, hi, dof);      // (0 for q >= T: both fragments are zero there)
+  if (q < p.T) {
+    Lq = p.L[((long long)b * p.H + h) * p.T + q];
+    if (hi == 0) p.Delta[((long long)b * p.H + h) * p.T + q] = Dq;      // for the dK/dV kernel, launched behind this one
+  }
 
   f32x16 acc[C::NDT];
 #pragma unroll
@@ -822,8 +827,6 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
     if (ws_floats >= need) p.part = p.Delta + (((size_t)total + 3) & ~(size_t)3);     // 16-byte aligned behind Delta
     if (ws_floats < need + 3) { p.tsplit = 1; p.part = nullptr; }                     // caller sized the workspace for Delta only
   }
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
   static const int dkv_env = getenv("E4T_ATTN_DKV_OCC") ? atoi(getenv("E4T_ATTN_DKV_OCC")) : 0;    // A/B switch (tools/ab_dkv.py)
   // measured (tools/ab_dkv.py, dh 40, B16 H8 T4096): S = 4096 1.790 vs 1.835 ms per backward with 3 workgroups per CU, S = 77
   // 0.194 vs 0.167 ms (one workgroup per (batch, head): nothing to cover the un-prefetched tile loads) -> long key ranges only
@@ -832,14 +835,14 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
   const int dkv_occ = DH > 64 ? 1 : (dkv_env == 3 || dkv_env == 2) ? dkv_env : ((p.S >= 2048 && DH < 64) ? 3 : DKV_WAVES);
   if (e4t_launch_log_enabled()) {
     const double el = (double)Bn * p.H * DH;      // elements per token row over all heads
-    E4T_LOG_LAUNCH("attn_delta_kernel<%d>|B%d H%d T%d|%.0f|0", DH, Bn, p.H, p.T, 4.0 * el * p.T + 4.0 * Bn * p.H * p.T);
+    E4T_LOG_LAUNCH("attn_bwd_dq_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
+                   2.0 * el * (4.0 * p.T + 2.0 * p.S) + 8.0 * Bn * p.H * p.T, 6.0 * Bn * p.H * (double)p.T * p.S * DH);
     E4T_LOG_LAUNCH("attn_bwd_dkv_kernel<%d, %d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, dkv_occ, Bn, p.H, p.T, p.S, p.causal,
                    2.0 * el * (2.0 * p.T + 4.0 * p.S) + 8.0 * Bn * p.H * p.T, 8.0 * Bn * p.H * (double)p.T * p.S * DH);
-    E4T_LOG_LAUNCH("attn_bwd_dq_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
-                   2.0 * el * (3.0 * p.T + 2.0 * p.S) + 8.0 * Bn * p.H * p.T, 6.0 * Bn * p.H * (double)p.T * p.S * DH);
   }
-  hipLaunchKernelGGL((attn_delta_kernel<DH>), dim3(blocks), dim3(256), 0, st, p, Bn);
-  E4T_CHECK_LAUNCH("attn_delta_kernel");
+  // dQ first: its prologue also produces Delta (row_delta), which the dK/dV kernel behind it reads
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
+  E4T_CHECK_LAUNCH("attn_bwd_dq_kernel");
   const dim3 gdkv(cdiv(p.S, 128) * p.tsplit, p.H, Bn);
   if constexpr (DH <= 64) {
     if (dkv_occ == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 3>), gdkv, dim3(256), 0, st, p);
@@ -855,8 +858,6 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
     hipLaunchKernelGGL((attn_dkv_reduce_kernel<DH>), dim3(rb), dim3(256), 0, st, p, Bn);
     E4T_CHECK_LAUNCH("attn_dkv_reduce_kernel");
   }
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
-  E4T_CHECK_LAUNCH("attn_bwd_dq_kernel");
   return 0;
 }
 

@@ -1561,6 +1561,37 @@ __global__ __launch_bounds__(256) void splitk_reduce8_kernel(GemmArgs p, int nz)
   }
 }
 
+// ... and for fp32 C without bias / row bias / residual / activation — every weight-gradient GEMM (gemm_tn_kernel, the batched head
+// gradients): 4 columns per thread, float4 loads of all splits of a trip in flight, optional accumulate into C.  The scalar kernel
+// above ran these at 1.2-3.4 TB/s (one 4-byte load per split and element: profiles/r04_prefetch_off_roofline_per_shape.csv, e.g.
+// M320 N320 nz32 11.1 us, M16 N1280 nz129 35.8 us).  Same summation order (z ascending).
+__global__ __launch_bounds__(256) void splitk_reduce4f_kernel(GemmArgs p, int nz) {
+  const int n4 = p.N >> 2;
+  const size_t total = (size_t)p.M * p.N, total4 = (size_t)p.M * n4;
+  const int bz = blockIdx.y;
+  float* Cf = (float*)p.C + (p.reduce_batch ? 0 : bz * p.strideC);
+  const float* ws = p.ws + (size_t)bz * nz * total;
+  for (size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * 256) {
+    const int row = (int)(i4 / n4), c4 = (int)(i4 - (size_t)row * n4) * 4;
+    const size_t idx = (size_t)row * p.N + c4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z0 = 0; z0 < nz; z0 += 8) {
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = *(const float4*)(ws + (size_t)min(z0 + u, nz - 1) * total + idx);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float w = z0 + u < nz ? 1.f : 0.f;
+        v.x += t[u].x * w; v.y += t[u].y * w; v.z += t[u].z * w; v.w += t[u].w * w;
+      }
+    }
+    float4* c = (float4*)(Cf + (size_t)row * p.ldc + c4);
+    float4 o = make_float4(v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha);
+    if (p.flags & E4T_ACCUM) { const float4 a = *c; o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w; }
+    *c = o;
+  }
+}
+
 // What launch_gemm() will run for a problem: the ONE place where tiles and split-K are chosen (e4t_gemm_plan / e4t_conv3x3_plan
 // export it, so that callers size workspaces and label timings from the launcher's own decision instead of mirroring it).
 struct GemmPlan {
@@ -1847,6 +1878,12 @@ GemmPlan plan_gemm_tail(const GemmArgs& p, bool conv, int tile_hint, int splitk_
   return plan_gemm(p, conv, tile_hint, splitk_req, batch);
 }
 
+// the float4 reduction: fp32 C, nothing in the epilogue but alpha (and accumulate), 16-byte aligned rows
+bool reduce4f_ok(const GemmArgs& p) {
+  return p.ws && (p.flags & E4T_OUT_F32) && !(p.flags & E4T_ACT_GELU) && !p.bias && !p.rowbias && !p.residual && p.N % 4 == 0 && p.ldc % 4 == 0 &&
+         p.strideC % 4 == 0 && (((uintptr_t)p.C | (uintptr_t)p.ws) & 15) == 0;
+}
+
 int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int splitk_req, int batch, hipStream_t st) {
   int tail = 0;
   const GemmPlan pl = plan_gemm_tail(p, conv, tile_hint, splitk_req, batch, tail);
@@ -1920,7 +1957,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                              p.M, splitk, by, 2.0 * p.M * p.N * (double)p.K);
     else E4T_LOG_LAUNCH("%s|gemm M%d N%d K%d batch%d splitk%d flags%d|%.0f|%.0f", sym, m_all, p.N, p.K, batch, splitk, p.flags,
                         by + (double)tail * (2.0 * p.K + (osz + (p.residual ? ((p.flags & E4T_RES_F32) ? 4.0 : 2.0) : 0.0)) * p.N), 2.0 * m_all * p.N * (double)p.K * batch);
-    if (p.ws) E4T_LOG_LAUNCH("%s|M%d N%d nz%d|%.0f|0", vec8 ? "splitk_reduce8_kernel" : "splitk_reduce_kernel",
+    if (p.ws) E4T_LOG_LAUNCH("%s|M%d N%d nz%d|%.0f|0", vec8 ? "splitk_reduce8_kernel" : reduce4f_ok(p) ? "splitk_reduce4f_kernel" : "splitk_reduce_kernel",
                              p.M, p.N, p.reduce_batch ? splitk * batch : splitk, 4.0 * (double)p.M * p.N * splitk * batch + osz * (double)p.M * p.N);
   }
   if (p.panel_rows && !(use_dma && buf_ok && tile == 2320 && splitk == 1 && !p.ws))
@@ -2021,6 +2058,10 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
       int b8 = (int)((total / 8 + 255) / 256);
       if (b8 > 2048) b8 = 2048;
       hipLaunchKernelGGL(splitk_reduce8_kernel, dim3(b8, p.reduce_batch ? 1 : batch), dim3(256), 0, st, p, nz);
+    } else if (reduce4f_ok(p)) {
+      int b4 = (int)((total / 4 + 255) / 256);
+      if (b4 > 2048) b4 = 2048;
+      hipLaunchKernelGGL(splitk_reduce4f_kernel, dim3(b4, p.reduce_batch ? 1 : batch), dim3(256), 0, st, p, nz);
     } else {
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, p.reduce_batch ? 1 : batch), dim3(256), 0, st, p, nz);
     }
@@ -2171,7 +2212,8 @@ extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
     const double osz = (p.flags & E4T_OUT_F32) ? 4.0 : 2.0;
     E4T_LOG_LAUNCH("gemm_tn_kernel|gemm_tn M%d N%d K%d splitk%d flags%d|%.0f|%.0f", p.M, p.N, p.K, splitk, p.flags,
                    2.0 * (double)p.K * (p.M + p.N) + osz * (double)p.M * p.N * ((p.flags & E4T_ACCUM) ? 2 : 1), 2.0 * p.M * p.N * (double)p.K);
-    if (p.ws) E4T_LOG_LAUNCH("splitk_reduce_kernel|M%d N%d nz%d|%.0f|0", p.M, p.N, splitk, 4.0 * (double)p.M * p.N * splitk + osz * (double)p.M * p.N);
+    if (p.ws) E4T_LOG_LAUNCH("%s|M%d N%d nz%d|%.0f|0", reduce4f_ok(p) ? "splitk_reduce4f_kernel" : "splitk_reduce_kernel", p.M, p.N, splitk,
+                             4.0 * (double)p.M * p.N * splitk + osz * (double)p.M * p.N);
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(gx, gy, splitk), dim3(512), 0, st, p);
   E4T_CHECK_LAUNCH("gemm_tn_kernel");
@@ -2179,7 +2221,13 @@ extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
     const size_t total = (size_t)p.M * p.N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, p, splitk);
+    if (reduce4f_ok(p)) {
+      int b4 = (int)((total / 4 + 255) / 256);
+      if (b4 > 2048) b4 = 2048;
+      hipLaunchKernelGGL(splitk_reduce4f_kernel, dim3(b4, 1), dim3(256), 0, st, p, splitk);
+    } else {
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, 1), dim3(256), 0, st, p, splitk);
+    }
     E4T_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return 0;

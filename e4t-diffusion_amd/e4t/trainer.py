@@ -82,7 +82,7 @@ class E4TTrainer:
         self.scale, self.reg_lambda, self.pred_type = domain_embed_scale, reg_lambda, prediction_type
         self.share_prefix = True     # compute the context-independent UNet prefix once for the step's two passes
         self.overlap_vision = os.environ.get("E4T_OVERLAP_VISION", "1") != "0"
-        self._side, self._vision = None, None
+        self._side, self._vision, self._vision_event = None, None, None
         # Next-batch prefetch of the step's FROZEN, weight-independent front ends (prefetch()): "vit+vae" (default) = CLIP-ViT tokens and VAE
         # latents of batch i+1 are computed on the side stream under step i's backward; "vit" / "vae" = one of them (the ViT then runs
         # in its own step, on the side stream under the UNet encoder pass); "0" = off (round 3 behaviour).  Measured (round 4, B = 16,
@@ -90,6 +90,7 @@ class E4TTrainer:
         # with its backward measured 101.1-101.5 against 100.3 ms (another box) and was removed; so was evaluating the next step's W_eff
         # at the tail of the step (102.13 / 102.23 against 102.12 / 102.35 ms).
         self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit+vae")
+        self._prefetch_at_step_start = os.environ.get("E4T_PREFETCH_AT", "backward") == "step"
         self._next_px, self._pref = None, {}          # announced batch; finished / running prefetches by id(pixel tensor)
         self._next_eps = None                         # the VAE's sampling noise for the announced batch (tests); None = drawn when the prefetch starts
         # whole-step HIP graph (enable_step_graph): signature -> captured graph + its static tensors; device copy of AdamW's
@@ -230,12 +231,17 @@ class E4TTrainer:
         # The frozen CLIP-ViT only needs the image: run it on a side stream under the UNet encoder pass, whose low-resolution
         # levels leave CUs idle (one process per GPU, two HIP streams; joined before the E4T head needs the tokens).  Measured:
         # -2.4 ms/step here; launching it even earlier, under the VAE encode (chip already full), gains nothing.
-        joined = self._vision is not None           # prefetched by the previous step: already joined with this stream
+        joined = self._vision is not None           # prefetched by the previous step: joined below, where the tokens are consumed
         vision, self._vision = (self._vision if joined else self._launch_vision(pixel_values)), None
+        vis_ev, self._vision_event = self._vision_event, None
         with share:
             enc = self.unet(noisy, timesteps, self.ctx_for_e4t.expand(B, -1, -1), return_encoder_outputs=True)
             if vision is not None and not joined:
                 torch.cuda.current_stream().wait_stream(self._side)
+                for t in vision:
+                    t.record_stream(torch.cuda.current_stream())
+            elif vision is not None and vis_ev is not None:      # prefetched tokens: the ViT's tail ran under the encoder pass above
+                torch.cuda.current_stream().wait_event(vis_ev)
                 for t in vision:
                     t.record_stream(torch.cuda.current_stream())
             if vision is not None:
@@ -257,9 +263,12 @@ class E4TTrainer:
         loss_reg = self.reg_lambda * domain.pow(2).sum()
         return loss_diff + loss_reg, loss_diff, loss_reg
 
+    def _vision_applicable(self, pixel_values):
+        return bool(self.overlap_vision and pixel_values.is_cuda and hasattr(self.encoder, "encode_vision") and self.encoder.vision_is_frozen())
+
     def _launch_vision(self, pixel_values):
         """Start the frozen CLIP-ViT on the side stream (None when not applicable: CPU, trainable ViT, switched off)."""
-        if not (self.overlap_vision and pixel_values.is_cuda and hasattr(self.encoder, "encode_vision") and self.encoder.vision_is_frozen()):
+        if not self._vision_applicable(pixel_values):
             return None
         main = torch.cuda.current_stream()
         if self._side is None:
@@ -302,46 +311,56 @@ class E4TTrainer:
         self._next_eps = vae_eps              # the VAE's sampling noise for that batch (tests); None = drawn when the prefetch starts
 
     def _start_prefetch(self):
+        """Start the frozen front ends of the announced batch on the side stream: the VAE encoder FIRST, then the CLIP-ViT, each with its own
+        event.  The next step needs the latents at once (noise -> UNet encoder pass) but the ViT tokens only when the E4T head runs, after
+        the whole encoder pass: with one event behind both (round 4) the main stream sat idle at every step boundary until the LAST side
+        kernel had finished (tools/idle_report.py, profiles/r04_idle_report.txt: 16.9 of 112 ms per step with only the side stream
+        running); now it waits for the latents only and the tail of the ViT runs under the next step's encoder pass."""
         px, self._next_px = self._next_px, None
         if px is None:
             return
-        pref = dict(px=px, vision=None, latents=None)
-        if "vae" in self.prefetch_mode and self.vae is not None:
+        pref = dict(px=px, vision=None, latents=None, done=None, done_vision=None)
+        want_vae = "vae" in self.prefetch_mode and self.vae is not None
+        want_vit = "vit" in self.prefetch_mode and self._vision_applicable(px)
+        if not (want_vae or want_vit):
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = self._new_side_stream(px.device)
+        if want_vae:
             hl, wl = px.shape[2] // 8, px.shape[3] // 8
             eps, self._next_eps = self._next_eps, None
-            pref["vae_eps"] = eps if eps is not None else torch.randn((px.shape[0], 4, hl, wl), device=px.device)      # drawn on the main stream
-        if "vit" in self.prefetch_mode:
-            pref["vision"] = self._launch_vision(px)          # (waits for the main stream's position: the start of the backward)
-        if pref["vision"] is None and "vae_eps" not in pref:
-            return
-        if "vae_eps" in pref:
-            if self._side is None:
-                self._side = self._new_side_stream(px.device)
-            if pref["vision"] is None:      # (otherwise _launch_vision already made the side stream wait for this point of the main stream)
-                self._side.wait_stream(torch.cuda.current_stream())       # the draw of vae_eps above is main-stream work
+            vae_eps = eps if eps is not None else torch.randn((px.shape[0], 4, hl, wl), device=px.device)      # drawn on the main stream, in step order
+        self._side.wait_stream(main)            # the main stream's position: the start of this step's backward
+        if want_vae:
             with torch.cuda.stream(self._side), torch.no_grad():
-                pref["latents"] = self.encode_latents(px, pref["vae_eps"])
+                pref["latents"] = self.encode_latents(px, vae_eps)
+            pref["done"] = self._side.record_event()
+        if want_vit:
+            with torch.cuda.stream(self._side):
+                pref["vision"] = self.encoder.encode_vision(px)
+            pref["done_vision"] = self._side.record_event()
         px.record_stream(self._side)        # an announced batch that is dropped untrained must not be freed under the side stream
-        pref["done"] = self._side.record_event()           # the consumer waits for THIS point of the side stream, not for its tail
         if not getattr(self, "_prefetch_warm", False):
             # the first pass of a frozen model also writes its one-time bf16 weight copies (PreparedConv / VAEEncoder._prepare): a
             # main-stream consumer of those copies must not overtake them, so the main stream joins the side stream this once
-            torch.cuda.current_stream().wait_stream(self._side)
+            main.wait_stream(self._side)
             self._prefetch_warm = True
         if len(self._pref) > 4:                 # announced batches that were never trained on
             self._pref.pop(next(iter(self._pref)))
         self._pref[id(px)] = pref
 
     def _take_prefetched(self, pixel_values):
-        """(vision, latents) computed for exactly this tensor by the previous step, else (None, None); joins the side stream"""
+        """(vision, latents, vision event) computed for exactly this tensor by the previous step, else (None, None, None).  Joins the side
+        stream at the LATENTS' event only; the caller waits for `vision event` where the tokens are consumed (losses)."""
         pref = self._pref.pop(id(pixel_values), None)
         if pref is None or pref["px"] is not pixel_values:
-            return None, None
+            return None, None, None
         main = torch.cuda.current_stream()
-        main.wait_event(pref["done"])      # (wait_stream would also wait for a prefetch of the batch after this one, enqueued since)
-        for t in (pref["vision"] or ()) + ((pref["latents"],) if pref["latents"] is not None else ()):
-            t.record_stream(main)
-        return pref["vision"], pref["latents"]
+        if pref["latents"] is not None:
+            main.wait_event(pref["done"])      # (wait_stream would also wait for the ViT behind it, and for a prefetch of the batch after this one)
+            pref["latents"].record_stream(main)
+        return pref["vision"], pref["latents"], pref["done_vision"]
 
     def encode_latents(self, pixel_values, vae_eps):
         w = next(self.vae.parameters())
@@ -575,9 +594,9 @@ class E4TTrainer:
         and with ``sync=True`` (same loss_scale) for the k-th."""
         dev = self.device
         B = pixel_values.shape[0]
-        pre_vision, pre_latents = self._take_prefetched(pixel_values) if self._pref else (None, None)
+        pre_vision, pre_latents, vis_ev = self._take_prefetched(pixel_values) if self._pref else (None, None, None)
         if pre_vision is not None:
-            self._vision = pre_vision
+            self._vision, self._vision_event = pre_vision, vis_ev
         if latents is None and pre_latents is not None and vae_eps is None:
             latents = pre_latents
         if latents is None:
@@ -589,6 +608,8 @@ class E4TTrainer:
             noise = torch.randn_like(latents)
         if timesteps is None:
             timesteps = torch.randint(0, self.acp.shape[0], (B,), device=dev).long()
+        if self._next_px is not None and self._prefetch_at_step_start:       # (experiment switch E4T_PREFETCH_AT=step)
+            self._start_prefetch()
         loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
         if self._next_px is not None:        # announced by prefetch(): the next batch's frozen encoders start with this backward
             self._start_prefetch()
