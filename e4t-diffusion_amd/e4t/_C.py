@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libe4t_hip.so")
+# E4T_LIB: another build of the same library (tools/build_variant.sh: compile-time A/B of kernel variants); default = the in-tree build
+LIB_PATH = os.environ.get("E4T_LIB") or os.path.join(_HERE, "libe4t_hip.so")
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
 
