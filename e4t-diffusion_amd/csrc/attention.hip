@@ -784,8 +784,8 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs p, int Bn
   }
 }
 
-inline int xcd_raster_on() {                      // A/B switch: E4T_ATTN_NOXCD=1 restores the hardware's round-robin deal
-  static const int on = [] { const char* e = getenv("E4T_ATTN_NOXCD"); return (e && e[0] == '1') ? 0 : 1; }();
+inline int xcd_raster_on() {                      // (the hardware's round-robin deal measured equal in time at 3.1-4.6 x the HBM traffic: profiles/r03_attention_xcd_raster_checks.txt)
+  static const int on = 1;
   return on;
 }
 
@@ -795,7 +795,7 @@ inline int xcd_raster_on() {                      // A/B switch: E4T_ATTN_NOXCD=
 // so that ~1024 workgroups exist turns it into ~8 trips each; the partials are tiny (S x DH per head).  Long key ranges
 // (self-attention) already fill the chip: never split.
 inline void dkv_tsplit(int Bn, int H, int T, int S, int* tsplit, int* tchunk) {
-  static const bool off = getenv("E4T_ATTN_NOTSPLIT") != nullptr;      // A/B switch
+  const bool off = false;
   const long long wgs = (long long)cdiv(S, 128) * H * Bn;
   int n = 1;
   if (!off && wgs < 512 && T >= 512) {
@@ -813,7 +813,7 @@ int launch_fwd(const AttnArgs& p, int Bn, hipStream_t st) {
   // algorithmic bytes: Q, K, V read once, O written once (bf16) + the fp32 log-sum-exp
   E4T_LOG_LAUNCH("attn_fwd_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
                  2.0 * Bn * p.H * DH * (2.0 * p.T + 2.0 * p.S) + 4.0 * Bn * p.H * p.T, 4.0 * Bn * p.H * (double)p.T * p.S * DH);
-  static const int probe_lds = (ATTN_PROBE >= 0 && getenv("E4T_ATTN_PROBE_LDS")) ? atoi(getenv("E4T_ATTN_PROBE_LDS")) : 0;   // occupancy probe: extra dynamic LDS bytes
+  const int probe_lds = 0;
   hipLaunchKernelGGL((attn_fwd_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), probe_lds, st, p);
   E4T_CHECK_LAUNCH("attn_fwd_kernel");
   return 0;
@@ -827,12 +827,11 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
     if (ws_floats >= need) p.part = p.Delta + (((size_t)total + 3) & ~(size_t)3);     // 16-byte aligned behind Delta
     if (ws_floats < need + 3) { p.tsplit = 1; p.part = nullptr; }                     // caller sized the workspace for Delta only
   }
-  static const int dkv_env = getenv("E4T_ATTN_DKV_OCC") ? atoi(getenv("E4T_ATTN_DKV_OCC")) : 0;    // A/B switch (tools/ab_dkv.py)
   // measured (tools/ab_dkv.py, dh 40, B16 H8 T4096): S = 4096 1.790 vs 1.835 ms per backward with 3 workgroups per CU, S = 77
   // 0.194 vs 0.167 ms (one workgroup per (batch, head): nothing to cover the un-prefetched tile loads) -> long key ranges only
   // dh 64 (SD-2.x): three workgroups per CU cost the kernel a 16-byte spill and buy nothing (C5 B = 4: 85.3 vs 85.8 ms per step, B = 1 equal;
   // profiles/r04_ab/r04g_c5_occ*): it stays at two
-  const int dkv_occ = DH > 64 ? 1 : (dkv_env == 3 || dkv_env == 2) ? dkv_env : ((p.S >= 2048 && DH < 64) ? 3 : DKV_WAVES);
+  const int dkv_occ = DH > 64 ? 1 : ((p.S >= 2048 && DH < 64) ? 3 : DKV_WAVES);
   if (e4t_launch_log_enabled()) {
     const double el = (double)Bn * p.H * DH;      // elements per token row over all heads
     E4T_LOG_LAUNCH("attn_bwd_dq_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,

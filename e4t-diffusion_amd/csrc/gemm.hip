@@ -1696,7 +1696,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
 #else
   const bool auto256 = false;
 #endif
-  static const bool r2_rules = getenv("E4T_GEMM_R2RULES") != nullptr;   // A/B switch: the round-2 choices (before tools/sweep_ps.py, round 3)
+  const bool r2_rules = false;           // (round 2's rules: 112.5 vs 110.8 ms per step, profiles/r03_ab/r03c_*)
   const bool whole_k = p.K % BK == 0 && (!p.A2 || p.K1 % BK == 0);
   const bool ps_ok = allow256 && whole_k && batch == 1 && !p.reduce_batch && splitk_req <= 1;      // what gemm_ps_kernel accepts
   if (tile != 64 && tile != 128 && tile != 256 && tile != 160 && tile != 512 && tile != 640 && tile != 1128 && tile != 1160 && tile != 2320) {
@@ -1710,7 +1710,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     if (allow256 && tile == 128 && p.N % 160 == 0 && p.N <= 960 && (long long)cdiv(p.M, 128) * (p.N / 160) * batch >= 128) tile = 160;
     // K-deep shapes whose N is a multiple of 256 and that fill the chip at least twice with 256x256 tiles (the VAE's 256-
     // and 512-channel convs): the ping-pong kernel (conv 512->512 @128^2: 1075 vs 928 TF, 8192^3: 1173 vs 971 TF)
-    static const bool no_pp = getenv("E4T_GEMM_NOPP") != nullptr;     // A/B switch
+    const bool no_pp = false;
     const long long tpp = (long long)cdiv(p.M, 256) * (p.N / 256) * batch;
     if (allow256 && !no_pp && tile == 128 && p.N % 256 == 0 && whole_k && nkt >= (conv ? 16 : (r2_rules ? 32 : 20)) && tpp >= 512) tile = 512;
     // ... and, with split-K, for the very K-deep shapes of the 16x16 level that give it less than one round of tiles (1280-channel
@@ -1751,7 +1751,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     //    M16384 354 vs 439 (1366 TF/s), nearest-x2 + conv 1280->1280 339 vs 472 (1424 TF/s); GEMM M65536 N320 K2560 103 vs 135,
     //    K1280 57 vs 73, K320 26 vs 28; M4096 N10240 K1280 100 vs 112 (ping-pong 256 x 256).  It loses below one round (M16384
     //    N640: 128 tiles) and on the K = 320 GEMMs wider than 320 (epilogue-bound: 83 vs 72 us at N1280).
-    static const bool no_pq = getenv("E4T_GEMM_NOPQ") != nullptr;      // A/B switch
+    const bool no_pq = false;              // (without the 256 x 320 tile: 108.0 vs 106.4 ms per step, profiles/r03_ab/r03h_*)
     if (!r2_rules && !no_pq && allow256 && batch == 1 && (!general || !conv) && whole_k && p.N % 320 == 0) {
       const long long t320 = (long long)cdiv(p.M, 256) * (p.N / 320);
       const int ncu = device_cu_count();
@@ -1776,7 +1776,7 @@ GemmPlan plan_gemm(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, 
     }
     // Round 4: the 64 / 128 / 160 tiles, their LDS depth and split-K are arbitrated by a cost model of the launch (small_grid_plan above)
     // instead of the rules that chose among them until round 3; the rules above still decide WHETHER one of the big tiles runs.
-    static const bool no_model = getenv("E4T_GEMM_NOMODEL") != nullptr && getenv("E4T_GEMM_NOMODEL")[0] == '1';      // A/B switch: the round-3 rules
+    const bool no_model = false;           // (the round-3 rules instead of the cost model: C5 B = 1 44.4 vs 39.8 ms, profiles/r04_ab/r04s_*)
     if (!no_model && allow256 && (tile == 64 || tile == 128 || tile == 160) && batch == 1 && !p.reduce_batch && !p.panel_rows) {
       const SmallGridPlan sg = small_grid_plan(p.M, p.N, nkt, conv, general, splitk_req, p.colstats != nullptr, device_cu_count());
       tile = sg.tile; stages = sg.stages; model_splitk = sg.splitk;
@@ -1861,9 +1861,9 @@ size_t plan_workspace_bytes(const GemmPlan& pl, const GemmArgs& p, int batch) {
 // Tail rows (gemm_common.h, gemm_tail): a dense GEMM whose M is a multiple of 128 plus at most 32 rows — the CLIP-ViT's 16 x 257 =
 // 4112 token rows — is planned for its first M - r rows; the r tail rows are computed at the end of the same launch.  Returns the plan
 // and sets `tail` (0: the ordinary plan over all M rows).  The plan of the M - r rows must be a single pass of one of the LDS-DMA kernels
-// that carry the tail code (128 x 160, 256 x 256 and 256 x 320 tiles): anything else falls back to the plan over all rows.  E4T_GEMM_NOTAIL=1: A/B switch.
+// that carry the tail code (128 x 160, 256 x 256 and 256 x 320 tiles): anything else falls back to the plan over all rows.
 GemmPlan plan_gemm_tail(const GemmArgs& p, bool conv, int tile_hint, int splitk_req, int batch, int& tail) {
-  static const bool no_tail = getenv("E4T_GEMM_NOTAIL") != nullptr && getenv("E4T_GEMM_NOTAIL")[0] == '1';
+  const bool no_tail = false;              // (without the tail stage: README recipe 134.1 vs 133.5 ms, C4 139.6 vs 139.4, headline step equal; profiles/r05_ab)
   static const bool use_dma = getenv("E4T_GEMM_REGSTAGE") == nullptr;
   tail = 0;
   const int r = p.M % 128;
@@ -1895,8 +1895,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   int splitk = pl.splitk;
   p.ktiles_per_split = pl.ktiles_per_split;
   p.a_bytes = pl.a_bytes; p.a2_bytes = pl.a2_bytes; p.b_bytes = pl.b_bytes;
-  // stride-1 3x3 convs walk K channel-chunk-major (gemm_common.h, cm_step) in every DMA kernel; A/B switch: E4T_CONV_TAPMAJOR=1
-  static const bool tap_major = getenv("E4T_CONV_TAPMAJOR") != nullptr && getenv("E4T_CONV_TAPMAJOR")[0] == '1';
+  // stride-1 3x3 convs walk K channel-chunk-major (gemm_common.h, cm_step) in every DMA kernel
+  const bool tap_major = false;            // (tap-major K order: 109.7 vs 107.5 ms per step, 2.4-5.2 x the HBM traffic; profiles/r03_ab/r03p_*)
   p.chan_major = conv && !tap_major && buf_ok && p.mode == E4T_CONV_S1 && p.Cin % BK == 0 && p.K == 9 * p.Cin && batch == 1 &&
                  (unsigned long long)p.a_bytes + (unsigned long long)(p.Win + 1) * p.Cin * 2 < 0xFFFF0000ull;
   static const bool allow256 = getenv("E4T_GEMM_REGSTAGE") == nullptr;
@@ -1911,8 +1911,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
   }
   if (!(splitk > 1 || p.reduce_batch)) p.ws = nullptr;
   p.splitk = splitk;
-  static const int gm_env = getenv("E4T_GEMM_GM") ? atoi(getenv("E4T_GEMM_GM")) : 8;
-  p.group_m = gm_env;
+  p.group_m = 8;                           // row panels per raster group (swept in round 4: profiles/r04_ab/r04f_*)
   p.fast_epi = !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                (p.strideC % 8 == 0) && (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
   p.fast_f32 = (p.flags & E4T_OUT_F32) && !(p.flags & E4T_ACCUM) && !p.rowbias && (!p.residual || (p.flags & E4T_RES_F32)) &&
@@ -2203,8 +2202,7 @@ extern "C" int e4t_gemm_tn(const e4t_gemm_desc* d, e4t_stream stream) {
   if (splitk <= 1) p.ws = nullptr;
   p.splitk = splitk;
   p.group_m = 8;
-  static const bool no_xcd3 = getenv("E4T_TN_NOXCD3") != nullptr;      // A/B switch
-  p.xcd3 = splitk > 1 && !no_xcd3;
+  p.xcd3 = splitk > 1;                     // (2-D raster: gemm_tn M960 N320 K65536 90.6 vs 67.4 us)
   p.fast_epi = !(p.flags & (E4T_OUT_F32 | E4T_ACCUM | E4T_RES_F32)) && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
                (!p.residual || (p.ldr % 8 == 0 && ((uintptr_t)p.residual & 15) == 0));
   hipStream_t st = (hipStream_t)stream;

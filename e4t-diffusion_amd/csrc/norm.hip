@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void gn_slab_bwd_kernel(GNSrc s, const bf16_t*
 
 // quads per thread of the slab kernels for this shape, 0 = not eligible
 int gn_slab_ni(int C1, int C2, int HW, int G) {
-  static const bool off = getenv("E4T_GN_NOSLAB") != nullptr;      // A/B switch
+  const bool off = false;
   const int C = C1 + C2, cpg = C / G;
   if (off || cpg % 4 != 0 || (C2 > 0 && C1 % cpg != 0) || (long long)HW * cpg > GN_SLAB_MAX) return 0;
   const int ni = cdiv(HW * (cpg / 4), 256);
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* part,
 int colreduce_splits(int M) { int n = cdiv(M, 1024); return n > 128 ? 128 : (n < 1 ? 1 : n); }
 
 int gn_chunks(int Bn, int HW) {
-  static const int target = getenv("E4T_GN_BLOCKS") ? atoi(getenv("E4T_GN_BLOCKS")) : 1024;      // workgroups per launch (tuning knob)
+  const int target = 1024;      // workgroups per launch (swept in round 4: profiles/r04_ab/r04f_*)
   int ch = target / (Bn > 0 ? Bn : 1);
   if (ch < 1) ch = 1;
   const int maxch = HW / 8 > 0 ? HW / 8 : 1;

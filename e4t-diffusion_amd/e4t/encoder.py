@@ -19,7 +19,6 @@ What runs instead of the reference's ops:
 from __future__ import annotations
 
 
-import os
 
 import torch
 from torch import nn
@@ -82,31 +81,11 @@ class _ResBlock(nn.Module):
         if torch.is_grad_enabled() and (n.requires_grad or self.mlp.c_fc.weight.requires_grad):
             u = Fn.UnaryFn.apply(Fn.linear(n, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self._pf), 2)   # unfused GELU keeps a backward
         else:
-            u = _fc_gelu_frozen(n, self.mlp.c_fc, self._pf, B, T)
+            # frozen tower: GELU in the GEMM epilogue.  (B x 257 token rows: the library runs the first B x 257 - r rows as full tiles and
+            # the r = M % 128 tail rows at the end of the same launch — gemm.hip plan_gemm_tail; round 4's row-panel variant of this call,
+            # 16 panels of 256 patch rows + a class-token GEMM, measured slower and is gone)
+            u = Fn.linear(n, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self._pf, gelu=True)
         return Fn.linear(u, self.mlp.c_proj.weight, self.mlp.c_proj.bias, self._pp, residual=h, out_f32=f32s)
-
-
-# Off by default: measured in the step (round 4, profiles/r04_ab), the 16-panel fc1 on the 256 x 320 tile takes 92 us against 105 us for
-# the 4112-row GEMM on the 128 x 128 tile, and the class-token GEMM that goes with it 33 us — a net loss of 0.6 ms per step on the
-# side stream.  E4T_VIT_PANELS=1 turns it on (the kernel path stays covered by kernel_checks and tests/test_encoder_host_logic.py).
-_VIT_PANELS = os.environ.get("E4T_VIT_PANELS", "0") != "0"
-
-
-def _fc_gelu_frozen(n, fc, prep, B, T):
-    """gelu(c_fc(n)) of a frozen tower.  With T = 1 + 256 tokens per image (ViT-H/L-14 at 224 px) the B x 256 patch rows are handed to
-    the GEMM as B full 256-row panels (e4t_gemm_desc.panel_*: stride T, offset 1) and the B class-token rows as a second, tiny GEMM
-    over a strided view: N = 5120 then is exactly one round of 256 x 320 ping-pong tiles on 256 CUs, where the 16 x 257 = 4112-row
-    matrix is 17 panels, i.e. a second round for 16 rows (round 3: 105 us in the step on the 128 x 128 tile)."""
-    N, K = fc.weight.shape
-    if not (_VIT_PANELS and (T - 1) % 256 == 0 and T > 1 and N % 320 == 0 and K % 64 == 0 and n.shape == (B * T, K)):
-        return Fn.linear(n, fc.weight, fc.bias, prep, gelu=True)
-    be = ops.backend()
-    w, _ = prep.get()
-    w = w[:, :K] if w.shape[1] != K else w
-    y = torch.empty((B * T, N), dtype=n.dtype, device=n.device)
-    be.gemm(n, w, bias=fc.bias, gelu=True, out=y, panels=(T - 1, T, 1, B))
-    be.gemm(n.view(B, T, K)[:, 0], w, bias=fc.bias, gelu=True, out=y.view(B, T, N)[:, 0])
-    return y
 
 
 class _Transformer(nn.Module):
@@ -130,7 +109,7 @@ class VisionTransformer(nn.Module):
         self.proj = None
         self.output_tokens = True
         self.tokens_after_ln_post = False    # open_clip >= 2.20 behaviour when True
-        self.f32_residual = os.environ.get("E4T_VIT_F32_RESIDUAL", "1") != "0"      # A/B switch
+        self.f32_residual = True             # (bf16 stream in the frozen tower: e_hat error 1.0e-2 instead of 4.7e-3, time equal; profiles/r03_ab/r03e_*)
         self._pc = Fn.PreparedLinear(self.conv1.weight)
 
     def forward(self, pixels):
@@ -153,8 +132,7 @@ class VisionTransformer(nn.Module):
         # restatement of it: open_clip's LayerNorm casts its result back to the input dtype, so under torch.autocast the tower's stream
         # is bf16 there (oracle/e4t_oracle.py::_ViTLayerNorm; round-3 review).  It costs nothing measurable and puts the
         # predicted embedding closer to the fp32 oracle than the stock-autocast run is.  A trainable tower (--unfreeze_clip_vision)
-        # keeps the bf16 stream — the reference's own arithmetic — which its backward kernels use; E4T_VIT_F32_RESIDUAL=0 gives the
-        # frozen tower the bf16 stream too.
+        # keeps the bf16 stream — the reference's own arithmetic — which its backward kernels use.
         if self.f32_residual and not (torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())):
             h = h.float()
         for blk in self.transformer.resblocks:

@@ -13,7 +13,7 @@ Launch-bound: at B x 77 tokens every kernel of the 12 (23) layers runs 5-25 us w
 training step the GPU idled ~2.5 ms per step in front of these launches (tools/idle_report.py).  With frozen weights the layer
 stack is therefore captured once per input shape into two HIP graphs (forward | backward w.r.t. the embeddings,
 torch.cuda.make_graphed_callables) and replayed: same kernels, same order, bit-identical results, ~250 launches -> 2 per step.
-E4T_TEXT_GRAPH=0 switches it off; it is off by itself under E4T_LAUNCH_LOG (the per-launch log the roofline tools join with
+It is off under E4T_LAUNCH_LOG (the per-launch log the roofline tools join with
 rocprofv3's trace only sees launches that go through the host)."""
 from __future__ import annotations
 
@@ -33,7 +33,7 @@ class CLIPTextModel(_CLIPTextTree):
         super().__init__(**cfg)
         self._fused = None
         self._graphs = {}            # (shape, dtype) -> (fused-weights key, graphed callable)
-        self._graph_ok = os.environ.get("E4T_TEXT_GRAPH", "1") != "0" and not os.environ.get("E4T_LAUNCH_LOG")
+        self._graph_ok = not os.environ.get("E4T_LAUNCH_LOG")
 
     def _prepare(self, trainable):
         """Per layer: fused q|k|v weight + bias and the PreparedLinear handles of every projection.  Frozen: detached copies made

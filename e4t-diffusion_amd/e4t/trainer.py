@@ -81,7 +81,7 @@ class E4TTrainer:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.scale, self.reg_lambda, self.pred_type = domain_embed_scale, reg_lambda, prediction_type
         self.share_prefix = True     # compute the context-independent UNet prefix once for the step's two passes
-        self.overlap_vision = os.environ.get("E4T_OVERLAP_VISION", "1") != "0"
+        self.overlap_vision = True           # the frozen CLIP-ViT on a side stream (under the encoder pass / one batch ahead)
         self._side, self._vision, self._vision_event = None, None, None
         # Next-batch prefetch of the step's FROZEN, weight-independent front ends (prefetch()): "vit+vae" (default) = CLIP-ViT tokens and VAE
         # latents of batch i+1 are computed on the side stream under step i's backward; "vit" / "vae" = one of them (the ViT then runs
@@ -90,7 +90,6 @@ class E4TTrainer:
         # with its backward measured 101.1-101.5 against 100.3 ms (another box) and was removed; so was evaluating the next step's W_eff
         # at the tail of the step (102.13 / 102.23 against 102.12 / 102.35 ms).
         self.prefetch_mode = os.environ.get("E4T_PREFETCH", "vit+vae")
-        self._prefetch_at_step_start = os.environ.get("E4T_PREFETCH_AT", "backward") == "step"
         self._next_px, self._pref = None, {}          # announced batch; finished / running prefetches by id(pixel tensor)
         self._next_eps = None                         # the VAE's sampling noise for the announced batch (tests); None = drawn when the prefetch starts
         # whole-step HIP graph (enable_step_graph): signature -> captured graph + its static tensors; device copy of AdamW's
@@ -279,22 +278,10 @@ class E4TTrainer:
 
     def _new_side_stream(self, device):
         """(HIP offers two stream priorities here, -1 and 0; running the step at -1 or the side stream "low" measured no difference:
-        101.3 vs 101.1-101.5 ms, profiles/r04_ab)
-        E4T_SIDE_CUS=n (experiment, round-4 review item 7): the side stream is created with hipExtStreamCreateWithCUMask and may only use n
-        of the 256 CUs (bit i of the mask = CU i / 8 of XCD i % 8: the first n bits take n / 8 CUs of every XCD), so that the main stream's
-        tile rounds keep the other CUs to themselves.  Result in DESIGN §2.6."""
-        n = int(os.environ.get("E4T_SIDE_CUS", "0") or 0)
-        if n <= 0 or device.type != "cuda":
-            return torch.cuda.Stream(device=device)
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        words = 8                                   # 256 CUs
-        mask = (ctypes.c_uint32 * words)(*[((1 << max(0, min(32, n - 32 * w))) - 1) & 0xFFFFFFFF for w in range(words)])
-        st = ctypes.c_void_p()
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
-        if rc != 0 or not st.value:
-            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
-        return torch.cuda.ExternalStream(st.value, device=device)
+        101.3 vs 101.1-101.5 ms, profiles/r04_ab.  A side stream confined to 64 / 128 of the 256 CUs with hipExtStreamCreateWithCUMask —
+        round-4 review item 7 — measured 177.4 / 137.9 ms per step against 104.8: the side work is ~35 ms of full-chip time and a slice of
+        the chip stretches it past the backward it hides under; profiles/r05_ab/r05a_side_cus*.json.)"""
+        return torch.cuda.Stream(device=device)
 
     # ---- next-batch prefetch of the frozen front ends ---------------------------------------------------------------------
     # The CLIP-ViT tower (and the VAE encoder) of a step depend on the step's IMAGES only — not on any weight the optimiser
@@ -608,11 +595,9 @@ class E4TTrainer:
             noise = torch.randn_like(latents)
         if timesteps is None:
             timesteps = torch.randint(0, self.acp.shape[0], (B,), device=dev).long()
-        if self._next_px is not None and self._prefetch_at_step_start:       # (experiment switch E4T_PREFETCH_AT=step)
-            self._start_prefetch()
         loss, loss_diff, loss_reg = self.losses(pixel_values, latents, noise, timesteps, input_ids, placeholder_idx)
         if self._next_px is not None:        # announced by prefetch(): the next batch's frozen encoders start with this backward
-            self._start_prefetch()
+            self._start_prefetch()           # (starting them with the step instead: 101.95 vs 101.8 ms, profiles/r05_ab/r05b_at_step.json)
         self._armed = bool(sync)             # micro-batches that only accumulate start no collectives
         self._up_events = 0
         if self.comm_timing is not None and self.flat.grad.is_cuda:

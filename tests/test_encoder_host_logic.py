@@ -98,31 +98,3 @@ def test_vit_restatement_matches_installed_transformers_clip_vision(emu_fp32):
     torch.testing.assert_close(pooled_n.float(), want.pooler_output, rtol=2e-4, atol=2e-4)
     torch.testing.assert_close(tokens_n.float(), want.last_hidden_state[:, 1:], rtol=2e-4, atol=2e-4)
 
-
-def test_frozen_vit_fc_as_row_panels_matches_the_plain_gemm(emu_fp32, monkeypatch):
-    """T = 257 tokens per image: the frozen tower hands fc1 to the GEMM as B panels of 256 patch rows (e4t_gemm_desc.panel_*) plus a
-    class-token GEMM over a strided view (encoder.py::_fc_gelu_frozen).  Same tokens out as the one 4112-row GEMM, against the oracle."""
-    from e4t import encoder as E
-    cfg = dict(image_size=224, patch_size=14, width=320, layers=2, heads=4, mlp_ratio=4.0)      # hidden 1280 % 320 == 0, K = 320 % 64 == 0
-    torch.manual_seed(3)
-    ref = orc.VisionTransformer(**cfg).requires_grad_(False)
-    nat = E.VisionTransformer(**cfg).requires_grad_(False)
-    nat.load_state_dict(ref.state_dict())
-    x = torch.rand(2, 3, 96, 96, generator=torch.Generator().manual_seed(4)) * 2 - 1
-    monkeypatch.setattr(E, "_VIT_PANELS", True)          # (off by default: E4T_VIT_PANELS)
-    calls = []
-    real = E.ops.backend().gemm
-    monkeypatch.setattr(E.ops.backend(), "gemm", lambda *a, **k: (calls.append(k.get("panels")), real(*a, **k))[1])
-    with torch.no_grad():
-        cls_p, tok_p = nat(x)
-        monkeypatch.setattr(E, "_VIT_PANELS", False)
-        n_panel_calls = sum(c is not None for c in calls)
-        cls_d, tok_d = nat(x)
-        mean = torch.tensor(orc.CLIP_MEAN).view(1, 3, 1, 1)
-        std = torch.tensor(orc.CLIP_STD).view(1, 3, 1, 1)
-        xr = torch.nn.functional.interpolate((x + 1) / 2, size=(224, 224), mode="bicubic", align_corners=True)
-        cls_r, tok_r = ref((xr - mean) / std)
-    assert n_panel_calls == cfg["layers"] and calls.count((256, 257, 1, 2)) == cfg["layers"]
-    torch.testing.assert_close(tok_p, tok_d, rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(cls_p, cls_d, rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(tok_p, tok_r, rtol=2e-3, atol=2e-3)
