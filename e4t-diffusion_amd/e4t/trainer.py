@@ -97,7 +97,7 @@ class E4TTrainer:
         self._step_graph_on = False
         self._step_graphs, self._seen_sigs = {}, set()
         self._hyper, self._hyper_ring, self._hyper_i = None, [], 0
-        self._capturing = False
+        self._capturing = self._graph_failed = False
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         # E4T_FORCE_COMM=1: run the collective path even in a 1-rank group (exercises the RCCL calls / stream ordering on one GPU)
@@ -470,11 +470,14 @@ class E4TTrainer:
     # ahead; at small batches (BASELINE configs[4] runs SD-2.x at B = 1 per GPU: 17 ms of kernels) the step is host-bound (48 ms).  Shapes
     # are static per (config, batch): the step — VAE encode, both UNet passes, encoder, text encoder, backward, clip, AdamW, zero-grad — is
     # captured once per input signature with torch.cuda.graph and replayed; inputs go through static buffers, the random draws are
-    # torch's graph-safe Philox draws, AdamW's step-dependent scalars are read from device memory (e4t_adamw_hyper).  One process per
-    # GPU without a communicator only (the all-reduce hooks live in Python); the first step of a signature runs eagerly (it is also the
-    # warm-up every lazy initialisation needs), the second one captures and replays.
+    # torch's graph-safe Philox draws, AdamW's step-dependent scalars are read from device memory (e4t_adamw_hyper).  The first step of a
+    # signature runs eagerly (it is also the warm-up every lazy initialisation needs), the second one captures and replays.
+    # Under a communicator (round 5: BASELINE configs[4] IS one image per GPU on eight GPUs) the gradient regions' all-reduces are captured
+    # WITH the step: the hooks run during the capture, RCCL's enqueues on its own stream become graph nodes joined to the step's stream by
+    # the handles' waits, and every rank captures the same sequence.  The replica check (a host read) runs outside the replay.  Should a
+    # capture fail (an RCCL / HIP build that refuses a collective under capture), the trainer says so once and goes on eagerly.
     def enable_step_graph(self, on=True):
-        if on and (self._comm or not self.flat.data.is_cuda or self.text_trainable):
+        if on and (not self.flat.data.is_cuda or self.text_trainable or self._graph_failed):
             return False
         self._step_graph_on = bool(on)
         if on and self._hyper is None:
@@ -533,6 +536,15 @@ class E4TTrainer:
                     torch.cuda.synchronize()
                     with torch.cuda.graph(g):
                         out = self._train_step(**{k: static.get(k) for k in ins})
+            except Exception as e:                    # e.g. a collective the RCCL build will not capture: eager from here on
+                if not self._comm:
+                    raise
+                import warnings
+                warnings.warn(f"E4TTrainer: capturing the step with its collectives failed ({type(e).__name__}: {e}); running eagerly")
+                self._capturing, self._step_graph_on, self._graph_failed = False, False, True
+                self._works, self._done = [], set()
+                torch.cuda.synchronize()
+                return self._train_step(**ins)
             finally:
                 self._capturing = False
             ent = self._step_graphs[sig] = (g, static, out)
@@ -544,6 +556,8 @@ class E4TTrainer:
         self._write_hyper()
         g.replay()
         ops.bump_weights_epoch()
+        if self.world > 1 and self.replica_check_every > 0 and self.step_count % self.replica_check_every == 0:
+            self.check_replicas()
         return tuple(o.clone() for o in out)
 
     def zero_grad(self):
@@ -616,7 +630,7 @@ class E4TTrainer:
         self.clip_grad_norm()
         self.optimizer_step()
         self.zero_grad()
-        if self.world > 1 and self.replica_check_every > 0 and self.step_count % self.replica_check_every == 0:
+        if self.world > 1 and self.replica_check_every > 0 and self.step_count % self.replica_check_every == 0 and not self._capturing:
             self.check_replicas()
         return loss.detach(), loss_diff.detach(), loss_reg.detach()
 

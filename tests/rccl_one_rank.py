@@ -54,6 +54,33 @@ def run(dev, comm, tuning, steps=3):
     return torch.stack(losses), tr.flat.data.detach().cpu().clone(), log
 
 
+def run_graph(dev, comm, graph, steps=4):
+    """plain synchronising steps; graph=True: the whole step INCLUDING the regions' all-reduces replayed from one HIP graph"""
+    from test_train_step_host_logic import TEXT_CFG, build
+    from e4t.text import CLIPTextModel
+    from e4t.trainer import E4TTrainer
+    os.environ["E4T_FORCE_COMM"] = "1" if comm else "0"
+    _, _, n_unet, n_enc, text_t = build(seed=0)
+    text = CLIPTextModel(**TEXT_CFG).requires_grad_(False)
+    text.load_state_dict(text_t.state_dict())
+    n_unet.to(dev), n_enc.to(dev), text.to(dev)
+    tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev), device=dev)
+    assert tr._comm == comm
+    if graph:
+        assert tr.enable_step_graph(True)
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    pidx = torch.tensor([2, 4], device=dev)
+    losses = []
+    for s in range(steps):
+        px, lat = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1, torch.randn(B, 4, 16, 16, generator=g) * 0.18215
+        noise, t, ids = torch.randn(B, 4, 16, 16, generator=g), torch.randint(0, 1000, (B,), generator=g), torch.randint(1, 99, (B, 9), generator=g)
+        out = tr.train_step(px.to(dev), ids.to(dev), pidx, noise=noise.to(dev), timesteps=t.to(dev), latents=lat.to(dev))
+        losses.append(torch.stack([o.detach().float() for o in out]).cpu())
+    torch.cuda.synchronize()
+    return torch.stack(losses), tr.flat.data.detach().cpu().clone(), (len(tr._step_graphs), tr._graph_failed)
+
+
 def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -68,6 +95,13 @@ def main():
         # two synchronising steps, each: U, H announced by the backward hooks, D by the mid/down bank — none by the sweep
         assert log == [("U", False), ("H", False), ("D", False)] * 2, log
         print(f"rccl one-rank {'tuning' if tuning else 'pretrain'}: {p0.numel()} parameters bit-identical with / without the collective path; regions {log[:3]}")
+    # the step graph under a communicator (BASELINE configs[4] is one image per GPU on eight GPUs): collectives captured with the step
+    l0, p0, _ = run_graph(dev, comm=False, graph=False)
+    l1, p1, (n_graphs, failed) = run_graph(dev, comm=True, graph=True)
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+    assert (n_graphs == 1) != failed, (n_graphs, failed)
+    print(f"rccl one-rank step graph with the collectives inside: {'replayed, ' if n_graphs else 'capture refused -> eager fallback, '}bit-identical to the eager no-comm run")
     dist.barrier()
     dist.destroy_process_group()
     print("RCCL_ONE_RANK_OK")
