@@ -271,7 +271,7 @@ def main():
         names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, *, false, 64>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, *, false, 64>",
                  "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, *, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, *, false, 64>",
                  "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, *, false, 64>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, *, false, 64>",
-                 "conv512": "gemm_pp_kernel<1, false>", "gemm512": "gemm_pp_kernel<0, false>", "gemm_tn": "gemm_tn_kernel",
+                 "conv512": "gemm_pp_kernel<1, false, true>", "gemm512": "gemm_pp_kernel<0, false, false>", "gemm_tn": "gemm_tn_kernel",
                  "conv2320": "gemm_pq_kernel<1, 320, false>", "gemm2320": "gemm_pq_kernel<0, 320, false>",
                  "conv5256": "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>", "gemm5256": "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>",
                  "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",

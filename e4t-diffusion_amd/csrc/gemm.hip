@@ -559,7 +559,12 @@ __device__ unsigned long long g_pp_trace[2 * 6 * 64];
 #else
 #define PP_LDSREAD(ptr) (*(const bf16x8*)(ptr))
 #endif
-template <int MODE, bool GENERAL = false>
+// CM (round 5): the channel-chunk-major K order of the stride-1 3x3 convs is a compile-time property of the instantiation, and the K loop
+// runs its steady state — every quarter issue unconditional — apart from the last tiles.  As a runtime flag (round 3) both walks lived in
+// every phase: a branch on the flag per DMA issue, the tap-major offsets kept alive next to the channel-major ones (the wave-uniform
+// A offset was parked in a VGPR and fetched back with v_readfirstlane per issue), and the "is there a tile left to stage" compare /
+// select / branch chain in every phase: ~9 of the ~24 scalar instructions per 8-MFMA phase (ISA, profiles/r05_isa_pp_loop.txt).
+template <int MODE, bool GENERAL = false, bool CM = false>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, HK = 32;
   constexpr int QUART = 256 * HK;                        // elements per quarter
@@ -597,10 +602,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   // when the conv tap / concat source changes, plus a wave-uniform SGPR offset that walks K (+64 B per quarter).  Issuing a
   // quarter costs no VALU at all, and out-of-range rows / conv padding simply carry an out-of-range offset (the hardware
   // returns zeros) instead of a redirected pointer.
-  const bool cm = MODE != 0 && p.chan_major;          // channel-chunk-major K order (gemm_common.h, cm_step)
-  const __amdgpu_buffer_rsrc_t rs_a = cm ? cm_rsrc(p) : __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : p.a_bytes), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+  constexpr bool cm = MODE != 0 && CM;               // channel-chunk-major K order (gemm_common.h, cm_step): launch_gemm picks the instantiation
+  const __amdgpu_buffer_rsrc_t rs_a = cm ? cm_rsrc(p) : uniform_rsrc(p.A, p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rs_a2 = uniform_rsrc(p.A2 ? p.A2 : p.A, p.A2 ? p.a2_bytes : p.a_bytes);
+  const __amdgpu_buffer_rsrc_t rs_b = uniform_rsrc(p.B, p.b_bytes);
   constexpr unsigned OOB = 0xFFFF0000u;          // >= every extent the launcher accepts
   // DMA: one wave-instruction = 16 rows x 64 B; wave w feeds quarter rows 32w + 16j + (lane >> 2), j = 0, 1
   const int drow = lane >> 2, dslot = lane & 3;
@@ -753,8 +758,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
   __builtin_amdgcn_s_barrier();
 
   bf16x8 af[2][2], bfr[2][2];
-  auto phase = [&](auto Bc, auto Pc, int kt) {
+  auto phase = [&](auto Bc, auto Pc, auto ALLc, int kt) {
     constexpr int b = decltype(Bc)::value, ph = decltype(Pc)::value;
+    constexpr bool ALL = decltype(ALLc)::value;      // steady state: every quarter this phase stages exists
     constexpr int kh = ph >> 1, mh = ph & 1;
     bf16_t* const buf = smem + b * 4 * QUART;
     bf16_t* const other = smem + (b ^ 1) * 4 * QUART;
@@ -773,13 +779,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
         for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = PP_LDSREAD(qb + b_off[j][ks]);
     }
     bool staged;
-    if (ph == 0)      { staged = kt + 1 < kt_end; if (staged) issue_b(kt + 1, true, other + 3 * QUART); }
-    else if (ph == 1) { staged = kt + 1 < kt_end; if (staged) issue_a(kt + 1, true, other + 2 * QUART); }
-    else if (ph == 2) { staged = kt + 2 < kt_end; if (staged) issue_b(kt + 2, false, buf + 1 * QUART); }
-    else              { staged = kt + 2 < kt_end; if (staged) issue_a(kt + 2, false, buf + 0 * QUART); }
+    if (ph == 0)      { staged = ALL || kt + 1 < kt_end; if (staged) issue_b(kt + 1, true, other + 3 * QUART); }
+    else if (ph == 1) { staged = ALL || kt + 1 < kt_end; if (staged) issue_a(kt + 1, true, other + 2 * QUART); }
+    else if (ph == 2) { staged = ALL || kt + 2 < kt_end; if (staged) issue_b(kt + 2, false, buf + 1 * QUART); }
+    else              { staged = ALL || kt + 2 < kt_end; if (staged) issue_a(kt + 2, false, buf + 0 * QUART); }
     PP_STAMP(1);
 #ifndef PP_NOWAIT
-    if (staged) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    if (ALL || staged) wait_vmcnt<8>(); else wait_vmcnt<0>();
 #endif
     PP_STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
@@ -810,12 +816,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 
   if (wr == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier interval behind group 0
   {
+    using YES = std::true_type; using NO = std::false_type;
     int kt = kt_begin;
-    for (; kt + 2 <= kt_end; kt += 2) {
-      phase(I0{}, I0{}, kt); phase(I0{}, I1{}, kt); phase(I0{}, I2{}, kt); phase(I0{}, I3{}, kt);
-      phase(I1{}, I0{}, kt + 1); phase(I1{}, I1{}, kt + 1); phase(I1{}, I2{}, kt + 1); phase(I1{}, I3{}, kt + 1);
+    for (; kt + 4 <= kt_end; kt += 2) {       // steady state: tiles kt + 2 and kt + 3 exist, nothing to decide
+      phase(I0{}, I0{}, YES{}, kt); phase(I0{}, I1{}, YES{}, kt); phase(I0{}, I2{}, YES{}, kt); phase(I0{}, I3{}, YES{}, kt);
+      phase(I1{}, I0{}, YES{}, kt + 1); phase(I1{}, I1{}, YES{}, kt + 1); phase(I1{}, I2{}, YES{}, kt + 1); phase(I1{}, I3{}, YES{}, kt + 1);
     }
-    if (kt < kt_end) { phase(I0{}, I0{}, kt); phase(I0{}, I1{}, kt); phase(I0{}, I2{}, kt); phase(I0{}, I3{}, kt); }
+    for (; kt + 2 <= kt_end; kt += 2) {
+      phase(I0{}, I0{}, NO{}, kt); phase(I0{}, I1{}, NO{}, kt); phase(I0{}, I2{}, NO{}, kt); phase(I0{}, I3{}, NO{}, kt);
+      phase(I1{}, I0{}, NO{}, kt + 1); phase(I1{}, I1{}, NO{}, kt + 1); phase(I1{}, I2{}, NO{}, kt + 1); phase(I1{}, I3{}, NO{}, kt + 1);
+    }
+    if (kt < kt_end) { phase(I0{}, I0{}, NO{}, kt); phase(I0{}, I1{}, NO{}, kt); phase(I0{}, I2{}, NO{}, kt); phase(I0{}, I3{}, NO{}, kt); }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   __syncthreads();   // every fragment read and every DMA is done before the epilogue reuses the LDS
@@ -1933,7 +1944,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     if (p.residual) by += ((p.flags & E4T_RES_F32) ? 4.0 : 2.0) * (double)p.M * p.N;
     if (p.flags & E4T_ACCUM) by += osz * (double)p.M * p.N;
     const char* sym = !(use_dma && buf_ok) ? "gemm_kernel"
-                      : tile == 512 ? (general_epi ? (conv ? "gemm_pp_kernel<1, true>" : "gemm_pp_kernel<0, true>") : (conv ? "gemm_pp_kernel<1, false>" : "gemm_pp_kernel<0, false>"))
+                      : tile == 512 ? (general_epi ? (conv ? (p.chan_major ? "gemm_pp_kernel<1, true, true>" : "gemm_pp_kernel<1, true, false>") : "gemm_pp_kernel<0, true, false>")
+                                                   : (conv ? (p.chan_major ? "gemm_pp_kernel<1, false, true>" : "gemm_pp_kernel<1, false, false>") : "gemm_pp_kernel<0, false, false>"))
                       : tile == 640 ? (conv ? "gemm_pt_kernel<1>" : "gemm_pt_kernel<0>")
                       : tile == 256 && !kt32 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 64>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 64>")
                       : tile == 256 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>")
@@ -1977,10 +1989,12 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     } else if (tile == 512) {
       block = dim3(512);
       if (general_epi) {
-        if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1, true>), grid, block, 0, st, p);
+        if (conv && p.chan_major) hipLaunchKernelGGL((gemm_pp_kernel<1, true, true>), grid, block, 0, st, p);
+        else if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_pp_kernel<0, true>), grid, block, 0, st, p);
       } else {
-        if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1>), grid, block, 0, st, p);
+        if (conv && p.chan_major) hipLaunchKernelGGL((gemm_pp_kernel<1, false, true>), grid, block, 0, st, p);
+        else if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_pp_kernel<0>), grid, block, 0, st, p);
       }
 #ifdef E4T_EXPERIMENTAL

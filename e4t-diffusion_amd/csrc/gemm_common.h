@@ -400,9 +400,17 @@ __device__ __forceinline__ unsigned cm_center(const GemmArgs& p, long long img_p
   return (unsigned)(((img_px + (long long)oy * p.Win + ox) * p.Cin + kc) * 2);
 }
 __device__ __forceinline__ unsigned cm_shift_bytes(const GemmArgs& p) { return (unsigned)((p.Win + 1) * p.Cin * 2); }
+// (every input of the descriptor goes through readfirstlane: all of them ARE wave-uniform, but a descriptor the compiler cannot PROVE
+// uniform is kept in VGPRs and every buffer_load ... lds that uses it is wrapped in a waterfall loop — 4 v_readfirstlane + compare +
+// s_and_saveexec + loop per DMA instruction, seen when the channel-major walk became a template parameter in round 5)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t cm_rsrc(const GemmArgs& p) {
   const unsigned sh = cm_shift_bytes(p);
-  return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - sh), 0, (int)(p.a_bytes + sh), 0x00020000);
+  return uniform_rsrc((const char*)p.A - sh, p.a_bytes + sh);
 }
 
 // ---- tail rows of a dense GEMM -------------------------------------------------------------------------------------------------
