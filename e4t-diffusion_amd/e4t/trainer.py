@@ -278,10 +278,10 @@ class E4TTrainer:
 
     def _new_side_stream(self, device):
         """(HIP offers two stream priorities here, -1 and 0; running the step at -1 or the side stream "low" measured no difference:
-        101.3 vs 101.1-101.5 ms, profiles/r04_ab.  A side stream confined to 64 / 128 of the 256 CUs with hipExtStreamCreateWithCUMask —
+        101.3 vs 101.1-101.5 ms, profiles/r04_ab; the side stream at HIGH priority: 103.05 / 103.51 vs 102.53 / 102.56 ms, round 5.  A side stream confined to 64 / 128 of the 256 CUs with hipExtStreamCreateWithCUMask —
         round-4 review item 7 — measured 177.4 / 137.9 ms per step against 104.8: the side work is ~35 ms of full-chip time and a slice of
         the chip stretches it past the backward it hides under; profiles/r05_ab/r05a_side_cus*.json.)"""
-        return torch.cuda.Stream(device=device, priority=int(os.environ.get("E4T_SIDE_PRIO", "0")))
+        return torch.cuda.Stream(device=device)
 
     # ---- next-batch prefetch of the frozen front ends ---------------------------------------------------------------------
     # The CLIP-ViT tower (and the VAE encoder) of a step depend on the step's IMAGES only — not on any weight the optimiser
