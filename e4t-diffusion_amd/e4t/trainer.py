@@ -123,6 +123,9 @@ class E4TTrainer:
             st = lambda buf, o, shape: buf[o:o + math.prod(shape)].view(shape)
             e4t_encoder.adopt_stacks(st(self.flat.data, o_w, (n, hid, hid)), st(self.flat.data, o_b, (n, hid)),
                                      st(self.flat.grad, o_w, (n, hid, hid)), st(self.flat.grad, o_b, (n, hid)))
+            self._stack_grad_off = o_w
+        if not n:
+            self._stack_grad_off = -1
         self._setup_overlap(named, n)
         self.exp_avg = torch.zeros_like(self.flat.data)
         self.exp_avg_sq = torch.zeros_like(self.flat.data)
@@ -562,6 +565,7 @@ class E4TTrainer:
 
     def zero_grad(self):
         self.flat.grad.zero_()
+        self.encoder._stack_grad_is_zero = self.encoder._gW is not None and self.encoder._gW.data_ptr() == self.flat.grad.data_ptr() + 4 * self._stack_grad_off
 
     # ---- training state (accelerator.save_state / load_state of the reference, pretrain_e4t.py:536-558,659-663) ----------
     def state_dict(self):
