@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] block (tuning step, SD-2.x @768)")
+    ap.add_argument("--head-allreduce", action="store_true", help="N > 1: all-reduce the E4T head's 845 MB stacked weight gradient instead of gathering its factors (A/B)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,7 +179,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_comm = world == 1 and os.environ.get("E4T_FORCE_COMM") == "1"     # one GPU, the collective path on (1-rank RCCL group): a code-path check
+    if force_comm:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_comm:
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -188,7 +193,8 @@ def main():
     unet, enc, text, vae = build_models(dev, args.model, seed=0)
     # tokenizer("") of CLIP: BOS + EOS padding (pretrain_e4t.py:565-583); class token "art" = one id of the table
     empty_ids = torch.tensor([[49406] + [49407] * 76], device=dev)
-    tr = E4TTrainer(unet, enc, text, vae, lr=1e-6 * args.batch * world, class_token_id=1125, empty_prompt_ids=empty_ids, device=dev)
+    tr = E4TTrainer(unet, enc, text, vae, lr=1e-6 * args.batch * world, class_token_id=1125, empty_prompt_ids=empty_ids, device=dev,
+                    head_factor_exchange=not args.head_allreduce)
     tr_prefetch = tr.prefetch_mode
 
     B = args.batch
@@ -237,7 +243,7 @@ def main():
         # rank 0 must not enter alone — and rank 0 records and reports.
         if rank == 0:
             hip.prof = []
-        tr.comm_timing = {} if world > 1 else None      # per-region all-reduce enqueue times + exposed wait of this step (N > 1)
+        tr.comm_timing = {} if (world > 1 or force_comm) else None      # per-region all-reduce enqueue times + exposed wait of this step (N > 1)
         # a steady-state step: it consumes what the last timed step prefetched for it and prefetches the batch after it
         nxt = (args.warmup + args.steps) % len(pool)
         tr.prefetch(pool[(nxt + 1) % len(pool)][0])
@@ -252,7 +258,7 @@ def main():
         torch.cuda.synchronize()
         tr.prefetch_mode = mode
         prof_alone, hip.prof = hip.prof, prof_steady
-    comm = tr.comm_report() if (world > 1 and not args.no_kernel_roofline) else None
+    comm = tr.comm_report() if ((world > 1 or force_comm) and not args.no_kernel_roofline) else None
     if rank == 0 and not args.no_kernel_roofline:
         def aggregate(prof):
             agg = {}
@@ -411,7 +417,7 @@ def main():
             out["details"] = None
         print(json.dumps(details), file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_comm:
         dist.destroy_process_group()
     if rank == 0 and parity is not None and parity["n_bad"]:
         sys.exit(3)                                  # the run's own parity block failed: not a valid measurement

@@ -195,12 +195,22 @@ class _HeadFn(torch.autograd.Function):
         be.gemm(gb.unsqueeze(0).expand(n, B, w), WsT, out=dZ.permute(1, 0, 2))
         # first_linears grads: dW_i = gb^T z_i (contraction over the B images, zero-padded to a 64-wide K tile); db_i = sum_b gs
         gW, gB, gWf, gbf = enc._grad_storage()
-        bp = (B + 7) // 8 * 8
-        gbT = be.transpose(gb, pad_to=bp)                                                         # [w, bp]
-        ZT = be.transpose(Z.view(B, n * w), pad_to=bp)                                            # [n*w, bp]
         # (129 x [1280 x 1280] fp32 = 845 MB of gradient: the first write after the trainer zeroed it overwrites instead of accumulating —
         # half the traffic of this launch, 0.65 -> ~0.35 ms per step; a micro-batch accumulation step or plain autograd use accumulates)
         fresh, enc._stack_grad_is_zero = getattr(enc, "_stack_grad_is_zero", False), False
+        # Data parallel: dW_i is a rank-B product of two SMALL factors (gb: B x w, z_i: B x w), so the sum over the ranks of the 845 MB
+        # stack equals ONE product over all ranks' rows.  The trainer's exchange gathers the factors (5 MB per rank) instead of
+        # all-reducing the stack; it answers None (local product, the stack goes through the all-reduce) outside a synchronising
+        # step or when it is switched off.  Only on the first write: an accumulated stack holds earlier micro-batches' LOCAL sums.
+        gbx, Zx = gb, Z.view(B, n * w)
+        ex = enc.exchange_head_factors
+        if ex is not None and fresh:
+            got = ex(gbx, Zx)
+            if got is not None:
+                gbx, Zx = got                                                                     # [world * B, w], [world * B, n * w]
+        bp = (gbx.shape[0] + 7) // 8 * 8
+        gbT = be.transpose(gbx, pad_to=bp)                                                        # [w, bp]
+        ZT = be.transpose(Zx, pad_to=bp)                                                          # [n*w, bp]
         be.gemm(gbT.unsqueeze(0).expand(n, w, bp), ZT.view(n, w, bp), out=gW, accum=not fresh)
         gB.add_(gs.sum(0)[None, :])
         # feature_linear: Z = hs W_fh^T + rowbias(c),  c = u W_fu^T + b_f
@@ -254,6 +264,7 @@ class E4TEncoder(nn.Module):
         self._stack_key = None
         self._gW = self._gB = None
         self.on_backward_done = None      # trainer hook: every encoder gradient is final (starts the head's all-reduce)
+        self.exchange_head_factors = None     # trainer hook (data parallel): (gb, Z) -> every rank's rows of both, or None (_HeadFn.backward)
 
     @property
     def dtype(self):

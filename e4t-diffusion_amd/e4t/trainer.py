@@ -18,6 +18,7 @@ from typing import Optional, Sequence
 
 import contextlib
 import os
+import warnings
 
 import torch
 import torch.nn.functional as F
@@ -71,12 +72,35 @@ class FlatParams:
         return buf[o:o + p.numel()].view(p.shape)
 
 
+def _runs_beside(main, side, device) -> bool:
+    """does a kernel launched on `side` execute while `main` is busy?  (False: the two streams share a hardware queue)"""
+    x = torch.zeros(64, device=device)
+    e_main, e_side = torch.cuda.Event(), torch.cuda.Event()
+    torch.cuda.synchronize(device)
+    with torch.cuda.stream(main):
+        torch.cuda._sleep(20_000_000)          # a spin kernel: tens of ms at any counter rate the runtime uses; the probe leaves as soon as it knows
+        e_main.record(main)
+    with torch.cuda.stream(side):
+        x.add_(1)
+        e_side.record(side)
+    ok = False
+    while not e_main.query():
+        if e_side.query():
+            ok = True
+            break
+    torch.cuda.synchronize(device)
+    return ok
+
+
 class E4TTrainer:
     def __init__(self, unet, e4t_encoder, text_encoder, vae, *, lr=1e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                  domain_embed_scale=0.1, reg_lambda=0.01, prediction_type="epsilon", class_token_id=0,
                  empty_prompt_ids: Optional[torch.Tensor] = None, process_group=None, device=None, tuning=False,
-                 max_grad_norm: Optional[float] = None):
+                 max_grad_norm: Optional[float] = None, head_factor_exchange=True):
         self.unet, self.encoder, self.text_encoder, self.vae = unet, e4t_encoder, text_encoder, vae
+        # data parallel: all-gather the two small factors of the 129-slot head's weight gradient instead of all-reducing the 845 MB
+        # stack (_exchange_head_factors); needs the same per-rank batch size on every rank.  False = the stack rides the all-reduce.
+        self.head_factor_exchange = bool(head_factor_exchange)
         self.device = device or next(unet.parameters()).device
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.scale, self.reg_lambda, self.pred_type = domain_embed_scale, reg_lambda, prediction_type
@@ -124,6 +148,7 @@ class E4TTrainer:
             e4t_encoder.adopt_stacks(st(self.flat.data, o_w, (n, hid, hid)), st(self.flat.data, o_b, (n, hid)),
                                      st(self.flat.grad, o_w, (n, hid, hid)), st(self.flat.grad, o_b, (n, hid)))
             self._stack_grad_off = o_w
+            e4t_encoder._stack_grad_is_zero = True          # the flat gradient starts as zeros (zero_grad keeps the mark up to date)
         if not n:
             self._stack_grad_off = -1
         self._setup_overlap(named, n)
@@ -144,7 +169,6 @@ class E4TTrainer:
         self.class_token_id = class_token_id
         self.empty_prompt_ids = (empty_prompt_ids if empty_prompt_ids is not None else torch.zeros((1, 77), dtype=torch.long)).to(self.device)
         self._refresh_text_constants()
-        self.comm_stream = torch.cuda.Stream(device=self.device) if (self._comm and self.device.type == "cuda") else None
 
     # ---- replica consistency -----------------------------------------------------------------------------------------------
     def sync_replicas(self, include_frozen=False, include_moments=False):
@@ -283,8 +307,25 @@ class E4TTrainer:
         """(HIP offers two stream priorities here, -1 and 0; running the step at -1 or the side stream "low" measured no difference:
         101.3 vs 101.1-101.5 ms, profiles/r04_ab; the side stream at HIGH priority: 103.05 / 103.51 vs 102.53 / 102.56 ms, round 5.  A side stream confined to 64 / 128 of the 256 CUs with hipExtStreamCreateWithCUMask —
         round-4 review item 7 — measured 177.4 / 137.9 ms per step against 104.8: the side work is ~35 ms of full-chip time and a slice of
-        the chip stretches it past the backward it hides under; profiles/r05_ab/r05a_side_cus*.json.)"""
-        return torch.cuda.Stream(device=device)
+        the chip stretches it past the backward it hides under; profiles/r05_ab/r05a_side_cus*.json.)
+
+        A new HIP stream is NOT guaranteed to run beside the current one: the runtime maps streams onto a handful of hardware queues, and
+        two streams that land on the same queue serialise.  Which stream objects share the current stream's queue depends on how many
+        streams the process created before — with an initialised RCCL process group the stream this function used to return shared it:
+        no overlap at all, 105.0 against 100.3 ms per step on one GPU (profiles/r05_ab/comm_path_one_gpu.txt).  So candidates are
+        PROBED: a spin kernel on the current stream, a one-element kernel on the candidate, and the candidate is taken when its kernel
+        finishes while the spin is still running (tools/probe/stream_queues.py prints the pattern)."""
+        if torch.cuda.is_current_stream_capturing():
+            return torch.cuda.Stream(device=device)
+        main = torch.cuda.current_stream(device)
+        rejected = []          # kept alive until the choice is made, so the next candidate is a different stream
+        for _ in range(8):
+            s = torch.cuda.Stream(device=device)
+            if _runs_beside(main, s, device):
+                return s
+            rejected.append(s)
+        warnings.warn("no HIP stream that runs beside the training stream was found: the next-batch prefetch will not overlap with the step")
+        return rejected[0]
 
     # ---- next-batch prefetch of the frozen front ends ---------------------------------------------------------------------
     # The CLIP-ViT tower (and the VAE encoder) of a step depend on the step's IMAGES only — not on any weight the optimiser
@@ -365,6 +406,9 @@ class E4TTrainer:
     #      blocks, so autograd — youngest ready node first — runs it before any mid-block node);
     #   H  when the encoder's backward is complete (hook on the gradient of its pooled-UNet-feature input; a trainable ViT is
     #      younger than that node and therefore done): before the whole encoder-pass UNet backward;
+    #   W  the stacked weights of the head's 129 linears, the front of the encoder's part (845 of its 920 MB at SD sizes): final with H,
+    #      and normally NOT reduced at all — the head's backward gathers every rank's factors and writes the global sum itself
+    #      (_exchange_head_factors); reduced with H when that did not happen (accumulated micro-batches, exchange switched off);
     #   D  at the very end (the mid/down parameters are shared by both UNet passes).
     # Each region's all-reduce is enqueued on RCCL's stream the moment it is final (async_op), in 256 MB buckets; the step only
     # waits for the handles before the gradient clip / AdamW.
@@ -375,6 +419,7 @@ class E4TTrainer:
         up_bank.on_backward_done = md_bank.on_backward_done = None          # a previous trainer's announcements, if any
         self.unet.on_up_backward_done = None
         self.encoder.on_backward_done = None
+        self.encoder.exchange_head_factors = None
         if not self._comm:
             return
         params = self.flat.params
@@ -391,7 +436,9 @@ class E4TTrainer:
         # T (trainable text encoder, tuning_e4t.py --train_text_encoder): its token embedding is the OLDEST autograd node of the step
         # (inputs_embeds = embedding(input_ids) is evaluated first), so its gradient is final only when the backward ends — T has
         # no hook and is reduced by the sweep after the backward, never together with H
-        self.regions = dict(H=(0, o[first_text]), T=(o[first_text], o[first_unet]), D=(o[first_unet], o[first_up]), U=(o[first_up], self.flat.numel))
+        w_end = o[n_first] if n_first else 0          # the first_linears weight stack leads the flat buffer (constructor)
+        self.regions = dict(W=(0, w_end), H=(w_end, o[first_text]), T=(o[first_text], o[first_unet]), D=(o[first_unet], o[first_up]),
+                            U=(o[first_up], self.flat.numel))
         self._up_events = 0
 
         def up_event(*_):
@@ -402,7 +449,28 @@ class E4TTrainer:
         up_bank.on_backward_done = up_event
         self.unet.on_up_backward_done = up_event
         md_bank.on_backward_done = lambda b: self._reduce_region("D")
-        self.encoder.on_backward_done = lambda: self._reduce_region("H")
+        self.encoder.on_backward_done = lambda: (self._reduce_region("W"), self._reduce_region("H"))
+        if n_first and self.head_factor_exchange:
+            self.encoder.exchange_head_factors = self._exchange_head_factors
+
+    def _exchange_head_factors(self, gb, Z):
+        """dW_i = gb^T z_i summed over the ranks = one product over all ranks' rows: gather [gb | Z] (B x (1 + 129) x 1280 bf16, 5.3 MB per
+        rank at B = 16) instead of all-reducing the 845 MB fp32 stack — 56 % of the step's all-reduce bytes, and every rank forms the
+        sum from the same gathered rows in the same order (bitwise-equal replicas).  Called by the head's backward on the first write
+        of the stack in a synchronising step; returns every rank's rows (rank order) and marks region W as already global, or None."""
+        if not self._armed or self.regions is None or "W" in self._done:
+            return None
+        w = gb.shape[1]
+        mine = torch.cat([gb, Z], dim=1)
+        rows = torch.empty((self.world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=mine.device)
+        if self.comm_timing is not None and mine.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.comm_timing.setdefault("enqueue", {})["W(factors)"] = ev
+        torch.distributed.all_gather_into_tensor(rows, mine, group=self.pg)
+        self._done.add("W")
+        self._factor_bytes = mine.numel() * mine.element_size()
+        return rows[:, :w], rows[:, w:]
 
     def _reduce_region(self, key, force=False):
         """enqueue the all-reduce of one region; during the backward only while a synchronising step is armed, `force` for the
@@ -431,7 +499,7 @@ class E4TTrainer:
             for o in range(0, g.numel(), bucket):
                 torch.distributed.all_reduce(g[o:o + bucket], group=self.pg)
             return
-        for key in ("U", "H", "D", "T"):      # whatever was not triggered during the backward
+        for key in ("U", "W", "H", "D", "T"):      # whatever was not triggered during the backward
             if self.regions[key][1] > self.regions[key][0]:
                 self._reduce_region(key, force=True)
         timing = self.comm_timing is not None and self.flat.grad.is_cuda
@@ -542,7 +610,6 @@ class E4TTrainer:
             except Exception as e:                    # e.g. a collective the RCCL build will not capture: eager from here on
                 if not self._comm:
                     raise
-                import warnings
                 warnings.warn(f"E4TTrainer: capturing the step with its collectives failed ({type(e).__name__}: {e}); running eagerly")
                 self._capturing, self._step_graph_on, self._graph_failed = False, False, True
                 self._works, self._done = [], set()
@@ -648,4 +715,5 @@ class E4TTrainer:
         b = t["backward_begin"]
         return dict(enqueue_ms_after_backward_start={k: b.elapsed_time(e) for k, e in t.get("enqueue", {}).items()},
                     wait_begin_ms=b.elapsed_time(t["wait_begin"]), exposed_wait_ms=t["wait_begin"].elapsed_time(t["wait_end"]),
-                    region_bytes={k: 4 * (hi - lo) for k, (lo, hi) in (self.regions or {}).items()})
+                    region_bytes={k: 4 * (hi - lo) for k, (lo, hi) in (self.regions or {}).items()},
+                    head_factor_bytes_per_rank=getattr(self, "_factor_bytes", 0))     # > 0: region W was exchanged as factors, not all-reduced

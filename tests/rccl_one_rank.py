@@ -92,8 +92,10 @@ def main():
         l1, p1, log = run(dev, comm=True, tuning=tuning)
         assert torch.equal(l0, l1), (tuning, l0, l1)
         assert torch.equal(p0, p1), (tuning, float((p0 - p1).abs().max()))
-        # two synchronising steps, each: U, H announced by the backward hooks, D by the mid/down bank — none by the sweep
-        assert log == [("U", False), ("H", False), ("D", False)] * 2, log
+        # two synchronising steps, each: U, H announced by the backward hooks, D by the mid/down bank — none by the sweep.  W (the head's
+        # stacked weight gradient) crosses as gathered factors in the first (RCCL all-gather, no all-reduce) and rides the all-reduce in
+        # the second, whose stack already holds the accumulated micro-batch
+        assert log == [("U", False), ("H", False), ("D", False), ("U", False), ("W", False), ("H", False), ("D", False)], log
         print(f"rccl one-rank {'tuning' if tuning else 'pretrain'}: {p0.numel()} parameters bit-identical with / without the collective path; regions {log[:3]}")
     # the step graph under a communicator (BASELINE configs[4] is one image per GPU on eight GPUs): collectives captured with the step
     l0, p0, _ = run_graph(dev, comm=False, graph=False)

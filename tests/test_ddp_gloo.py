@@ -70,17 +70,26 @@ def _worker(rank, world, port, out_dir, unfreeze):
     tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"),
                     **_MODE_KW[unfreeze])
     assert tr.world == world
+    if unfreeze == "accum":          # a micro-batch that only accumulates, then the synchronising one
+        b = _batch(rank + 10)
+        tr.train_step(b["pixels"], b["ids"], b["pidx"], noise=b["noise"], timesteps=b["t"], latents=b["latents"], sync=False)
     b = _batch(rank)
     tr.train_step(b["pixels"], b["ids"], b["pidx"], noise=b["noise"], timesteps=b["t"], latents=b["latents"])
     torch.save(tr.flat.data.clone(), os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save(int(getattr(tr, "_factor_bytes", 0)), os.path.join(out_dir, f"factor_bytes{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-_MODE_KW = {"": {}, "vit": {}, "tuning": dict(tuning=True, max_grad_norm=1.0), "seeds": {}, "text": dict(tuning=True, max_grad_norm=1.0)}
+_MODE_KW = {"": {}, "vit": {}, "tuning": dict(tuning=True, max_grad_norm=1.0), "seeds": {}, "text": dict(tuning=True, max_grad_norm=1.0),
+            "allreduce_head": dict(head_factor_exchange=False), "accum": {}}
+# the head's stacked weight gradient crosses the ranks as gathered factors (trainer._exchange_head_factors): everywhere except when it
+# is switched off and when the stack already holds a micro-batch's local sum
+_FACTORS = {"": True, "vit": True, "tuning": True, "seeds": True, "text": True, "allreduce_head": False, "accum": False}
 
 
-@pytest.mark.parametrize("unfreeze", ["", "vit", "tuning", "seeds", "text"], ids=["vit_frozen", "vit_trainable", "tuning", "different_seeds", "text_trainable"])
+@pytest.mark.parametrize("unfreeze", ["", "vit", "tuning", "seeds", "text", "allreduce_head", "accum"],
+                         ids=["vit_frozen", "vit_trainable", "tuning", "different_seeds", "text_trainable", "head_stack_all_reduced", "micro_batches"])
 def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
     """vit_trainable: no hook announces the head region during the backward, the post-backward sweep must reduce it.
     tuning: the whole UNet is in the U / D regions and the gradient-norm clip runs on the AVERAGED gradient (tuning_e4t.py:329-335
@@ -89,11 +98,15 @@ def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
     constructor's, pretrain_e4t.py:410-412) makes it rank 0's replica — the ranks end identical AND equal to the single-process step
     from rank 0's weights; the per-step replica checksum (E4T_REPLICA_CHECK_EVERY=1) passes.
     text_trainable: tuning_e4t.py --train_text_encoder.  The token-embedding gradient is complete only at the END of the backward
-    (region T, reduced by the sweep): reducing it with the E4T head's region from the head's hook dropped the late part."""
+    (region T, reduced by the sweep): reducing it with the E4T head's region from the head's hook dropped the late part.
+    head_stack_all_reduced / micro_batches: the head's stacked weight gradient (region W) goes through the all-reduce — because the
+    factor exchange is switched off, or because the stack already holds the first micro-batch's LOCAL sum; in every other mode the
+    head's backward gathers both ranks' factors and writes the global sum itself (no all-reduce of W)."""
     world, port = 2, _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), unfreeze), nprocs=world, join=True)
     p0, p1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(p0, p1), "ranks diverged after the all-reduced step"
+    assert all((torch.load(tmp_path / f"factor_bytes{r}.pt") > 0) == _FACTORS[unfreeze] for r in range(world))
     # single process: accumulate both batches' gradients, average inside AdamW
     _setup_paths()
     from e4t import ops
@@ -108,7 +121,7 @@ def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
             text.requires_grad_(True)
         tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long), device=torch.device("cpu"),
                         **_MODE_KW[unfreeze])
-        for r in range(world):
+        for r in ([10, 11, 0, 1] if unfreeze == "accum" else range(world)):
             b = _batch(r)
             loss, _, _ = tr.losses(b["pixels"], b["latents"], b["noise"], b["t"], b["ids"], b["pidx"])
             loss.backward()
@@ -168,12 +181,12 @@ def test_gradient_regions_are_reduced_as_soon_as_they_are_final(tmp_path, tuning
     mp.spawn(_order_worker, args=(1, _free_port(), str(tmp_path), tuning), nprocs=1, join=True)
     r = torch.load(tmp_path / "order.pt")
     keys = [k for k, _, _ in r["log"]]
-    assert keys == ["U", "H", "D"], r["log"]
+    assert keys == ["U", "H", "D"], r["log"]          # W (the head's stacked weights) is exchanged as factors by the head's backward: no all-reduce
     assert not any(forced for _, forced, _ in r["log"]), r["log"]
     by = {k: m for k, _, m in r["log"]}
     assert by["U"] == 0 and by["H"] == 0 and by["D"] == 1, r["log"]       # U and H before the encoder-pass backward, D after
-    (h0, h1), (d0, d1), (u0, u1) = r["regions"]["H"], r["regions"]["D"], r["regions"]["U"]
-    assert h0 == 0 and h1 == d0 and d1 == u0 and u1 == r["numel"] and u1 > u0 > d0 > 0
+    (w0, w1), (h0, h1), (d0, d1), (u0, u1) = r["regions"]["W"], r["regions"]["H"], r["regions"]["D"], r["regions"]["U"]
+    assert w0 == 0 and w1 == h0 and h1 == d0 and d1 == u0 and u1 == r["numel"] and u1 > u0 > d0 > h0 > 0
 
 
 def _diverge_worker(rank, world, port, out_dir):
