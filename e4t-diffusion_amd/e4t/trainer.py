@@ -122,6 +122,7 @@ class E4TTrainer:
         self._step_graphs, self._seen_sigs = {}, set()
         self._hyper, self._hyper_ring, self._hyper_i = None, [], 0
         self._capturing = self._graph_failed = False
+        self._train_stream, self._train_stream_probed = None, False      # _training_stream()
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         # E4T_FORCE_COMM=1: run the collective path even in a 1-rank group (exercises the RCCL calls / stream ordering on one GPU)
@@ -654,9 +655,68 @@ class E4TTrainer:
                    sync=True, loss_scale=1.0):
         """One training step (see _train_step); replayed from the step's HIP graph when enable_step_graph() is on and the call is a plain
         synchronising step."""
-        if self._step_graph_on and sync and loss_scale == 1.0 and self._next_px is None and not self._pref:
-            return self._graphed_step(pixel_values, input_ids, placeholder_idx, noise, timesteps, vae_eps, latents)
-        return self._train_step(pixel_values, input_ids, placeholder_idx, noise, timesteps, vae_eps, latents, sync, loss_scale)
+        def run():
+            if self._step_graph_on and sync and loss_scale == 1.0 and self._next_px is None and not self._pref:
+                return self._graphed_step(pixel_values, input_ids, placeholder_idx, noise, timesteps, vae_eps, latents)
+            return self._train_step(pixel_values, input_ids, placeholder_idx, noise, timesteps, vae_eps, latents, sync, loss_scale)
+        ts = self._training_stream()
+        if ts is None or self._step_graph_on:          # (a replayed graph's branches run on the graph executor's own streams, wherever it is launched)
+            return run()
+        # data parallel, and the caller's stream shares RCCL's hardware queue: the step runs on a stream of the trainer's that does not
+        cur = torch.cuda.current_stream(self.device)
+        ts.wait_stream(cur)
+        with torch.cuda.stream(ts):
+            out = run()
+        cur.wait_stream(ts)
+        for t in out:
+            t.record_stream(cur)
+        return out
+
+    def _training_stream(self):
+        """Under a communicator on a GPU: the stream the step must run on for its all-reduces to OVERLAP with it, or None (the caller's).
+        ROCm maps streams onto a handful of hardware queues and two streams on one queue serialise (_new_side_stream); RCCL launches on a
+        stream of ProcessGroupNCCL's choosing, and in a fresh process that stream shared the default stream's queue (tools/probe/
+        stream_queues.py) — every region's all-reduce would then sit IN the backward's kernel sequence instead of beside it.  Chosen
+        once, at the first step, by probing: a spin kernel on the candidate, a small all-gather issued from an idle stream, taken when the
+        collective completes while the spin still runs.  The probe is a collective, so every rank probes every candidate (the caller's
+        stream, then five new ones) whatever it found; which candidate a rank takes is its own business."""
+        if self._train_stream_probed:
+            return self._train_stream
+        self._train_stream_probed = True
+        if not self._comm or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return None
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        cands = [cur] + [torch.cuda.Stream(device=dev) for _ in range(5)]
+        src = torch.ones(1024, device=dev)
+        dst = torch.empty(self.world * 1024, device=dev)
+        torch.distributed.all_gather_into_tensor(dst, src, group=self.pg)          # the communicator's lazy set-up is not part of the probe
+        found = []
+        for c in cands:
+            idle = next((x for x in cands if x is not c and _runs_beside(c, x, dev)), cands[-1] if c is not cands[-1] else cands[0])
+            torch.distributed.barrier(group=self.pg)
+            torch.cuda.synchronize(dev)
+            e = torch.cuda.Event()
+            with torch.cuda.stream(c):
+                torch.cuda._sleep(20_000_000)
+                e.record(c)
+            with torch.cuda.stream(idle):
+                w = torch.distributed.all_gather_into_tensor(dst, src, group=self.pg, async_op=True)
+            ok = False
+            while not e.query():
+                if w.is_completed():
+                    ok = True
+                    break
+            w.wait()
+            torch.cuda.synchronize(dev)
+            found.append(ok)
+        self.stream_probe = found          # diagnostics: per candidate, did a collective run beside it (index 0 = the caller's stream)
+        if found[0] or not any(found):
+            if not any(found):
+                warnings.warn("E4TTrainer: no stream on which RCCL's collectives overlap with the step was found; the all-reduces will serialise with the backward")
+            return None
+        self._train_stream = cands[found.index(True)]
+        return self._train_stream
 
     def _train_step(self, pixel_values, input_ids, placeholder_idx, noise=None, timesteps=None, vae_eps=None, latents=None,
                     sync=True, loss_scale=1.0):
@@ -716,4 +776,6 @@ class E4TTrainer:
         return dict(enqueue_ms_after_backward_start={k: b.elapsed_time(e) for k, e in t.get("enqueue", {}).items()},
                     wait_begin_ms=b.elapsed_time(t["wait_begin"]), exposed_wait_ms=t["wait_begin"].elapsed_time(t["wait_end"]),
                     region_bytes={k: 4 * (hi - lo) for k, (lo, hi) in (self.regions or {}).items()},
-                    head_factor_bytes_per_rank=getattr(self, "_factor_bytes", 0))     # > 0: region W was exchanged as factors, not all-reduced
+                    head_factor_bytes_per_rank=getattr(self, "_factor_bytes", 0),     # > 0: region W was exchanged as factors, not all-reduced
+                    # _training_stream(): did a collective overlap with [the caller's stream, five new ones]; did the step move off the caller's
+                    collectives_run_beside=getattr(self, "stream_probe", None), step_on_own_stream=self._train_stream is not None)

@@ -51,10 +51,15 @@ def run(dev, comm, tuning, steps=3):
             out = tr.train_step(px.to(dev), ids.to(dev), pidx, loss_scale=0.5 if s == 2 else 1.0, **kw)
         losses.append(torch.stack([o.detach().float() for o in out]).cpu())
     torch.cuda.synchronize()
+    if comm:        # the trainer probed which stream RCCL's collectives overlap with and moved the step there if the caller's does not
+        probe = tr.stream_probe
+        assert len(probe) == 6 and (tr._train_stream is None) == (probe[0] or not any(probe)), (probe, tr._train_stream)
+        where = "the caller's stream" if tr._train_stream is None else "a stream of the trainer's"
+        print(f"rccl one-rank: collectives run beside [caller's stream, 5 new streams] = {probe}; the step ran on {where}")
     return torch.stack(losses), tr.flat.data.detach().cpu().clone(), log
 
 
-def run_graph(dev, comm, graph, steps=4):
+def run_graph(dev, comm, graph, steps=4, hop=False):
     """plain synchronising steps; graph=True: the whole step INCLUDING the regions' all-reduces replayed from one HIP graph"""
     from test_train_step_host_logic import TEXT_CFG, build
     from e4t.text import CLIPTextModel
@@ -66,6 +71,8 @@ def run_graph(dev, comm, graph, steps=4):
     n_unet.to(dev), n_enc.to(dev), text.to(dev)
     tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev), device=dev)
     assert tr._comm == comm
+    if hop:         # as if the probe had found the caller's stream on RCCL's hardware queue: the step runs on a stream of the trainer's
+        tr._train_stream, tr._train_stream_probed = torch.cuda.Stream(device=dev), True
     if graph:
         assert tr.enable_step_graph(True)
     g = torch.Generator().manual_seed(5)
@@ -104,6 +111,10 @@ def main():
     assert torch.equal(p0, p1), float((p0 - p1).abs().max())
     assert (n_graphs == 1) != failed, (n_graphs, failed)
     print(f"rccl one-rank step graph with the collectives inside: {'replayed, ' if n_graphs else 'capture refused -> eager fallback, '}bit-identical to the eager no-comm run")
+    l1, p1, _ = run_graph(dev, comm=True, graph=False, hop=True)
+    assert torch.equal(l0, l1), (l0, l1)
+    assert torch.equal(p0, p1), float((p0 - p1).abs().max())
+    print("rccl one-rank, the step on a stream of the trainer's: bit-identical to the eager no-comm run")
     dist.barrier()
     dist.destroy_process_group()
     print("RCCL_ONE_RANK_OK")

@@ -43,3 +43,25 @@ for i in range(10):
     s = torch.cuda.Stream(device=dev)
     keep.append(s)
     print(f"{'pg ' if len(sys.argv) > 1 else 'plain '}stream #{i} ({s.stream_id}): runs beside the current stream: {beside(main, s)}", flush=True)
+
+if len(sys.argv) > 1:
+    # ... and RCCL's own stream: does a collective run beside a busy training stream, for the current stream and for other candidates?
+    # (a collective waits for the stream it is called from, so it is called from an idle third stream)
+    src, dst = torch.ones(1 << 20, device=dev), torch.empty(1 << 20, device=dev)
+    for name, train in [("current", main)] + [(f"#{i}", s) for i, s in enumerate(keep[:8])]:
+        other = next(s for s in keep if s is not train and beside(train, s))
+        torch.cuda.synchronize()
+        e_train = torch.cuda.Event()
+        with torch.cuda.stream(train):
+            torch.cuda._sleep(int(5e7))
+            e_train.record(train)
+        with torch.cuda.stream(other):
+            w = dist.all_gather_into_tensor(dst, src, async_op=True)
+        ok = False
+        while not e_train.query():
+            if w.is_completed():
+                ok = True
+                break
+        torch.cuda.synchronize()
+        print(f"pg RCCL's stream: a collective runs beside training stream {name}: {ok}", flush=True)
+    dist.destroy_process_group()
