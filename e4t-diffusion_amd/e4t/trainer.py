@@ -18,6 +18,7 @@ from typing import Optional, Sequence
 
 import contextlib
 import os
+import time
 import warnings
 
 import torch
@@ -489,30 +490,36 @@ class E4TTrainer:
         g = self.flat.grad
         bucket = 64 << 20          # 256 MB fp32: xGMI rings are per-link bound, large buckets run them at rate
         for o in range(a, b, bucket):
-            self._works.append(torch.distributed.all_reduce(g[o:min(o + bucket, b)], group=self.pg, async_op=True))
+            self._works.append((key, torch.distributed.all_reduce(g[o:min(o + bucket, b)], group=self.pg, async_op=True)))
 
-    def all_reduce_grads(self):
+    def all_reduce_grads(self, defer=None):
+        """Wait for the regions' all-reduces (enqueueing whatever no hook announced).  `defer` names ONE region whose handles are not
+        waited for but returned, with its bounds: region D is final — and its all-reduce starts — only when the backward ends, so without a
+        gradient clip the step runs AdamW on everything else under it and on D afterwards (optimizer_step(deferred=...))."""
         if not self._comm:
-            return
+            return None
         if self.regions is None:
             g = self.flat.grad
             bucket = 64 << 20
             for o in range(0, g.numel(), bucket):
                 torch.distributed.all_reduce(g[o:o + bucket], group=self.pg)
-            return
+            return None
         for key in ("U", "W", "H", "D", "T"):      # whatever was not triggered during the backward
             if self.regions[key][1] > self.regions[key][0]:
                 self._reduce_region(key, force=True)
-        timing = self.comm_timing is not None and self.flat.grad.is_cuda
-        if timing:
-            self.comm_timing["wait_begin"] = torch.cuda.Event(enable_timing=True)
-            self.comm_timing["wait_begin"].record()
-        for w in self._works:
-            w.wait()
-        if timing:
-            self.comm_timing["wait_end"] = torch.cuda.Event(enable_timing=True)
-            self.comm_timing["wait_end"].record()
+        self._mark("wait_begin")
+        late = [w for k, w in self._works if k == defer]
+        for k, w in self._works:
+            if k != defer:
+                w.wait()
+        self._mark("wait_end")
         self._works, self._done = [], set()
+        return (self.regions[defer], late) if late else None
+
+    def _mark(self, name):
+        if self.comm_timing is not None and self.flat.grad.is_cuda:
+            self.comm_timing[name] = torch.cuda.Event(enable_timing=True)
+            self.comm_timing[name].record()
 
     def clip_grad_norm(self):
         """tuning_e4t.py:329-335 — global L2 norm over the flat gradient (one reduction kernel), scale folded on the device
@@ -522,19 +529,39 @@ class E4TTrainer:
         norm = ops.backend().sumsq(self.flat.grad).sqrt() / self.world
         self.flat.grad.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))
 
-    def optimizer_step(self):
+    def optimizer_step(self, deferred=None):
+        """AdamW over the flat buffers.  deferred = ((lo, hi), handles) from all_reduce_grads(defer=...): the elements outside [lo, hi)
+        are updated first, under that region's all-reduce, then the handles are waited for and [lo, hi) follows (element-wise update:
+        the split changes no bit)."""
         if self._hyper is not None:
             # step-graph mode: lr / bias corrections / gradient scale live in device memory (refreshed by the host before every step, eager
             # or replayed), so the captured launch is the same launch at every step
             if not self._capturing:
                 self.step_count += 1
                 self._write_hyper()
-            ops.backend().adamw_hyper(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self._hyper, self.betas[0], self.betas[1],
-                                      self.eps, self.wd)
+
+            def adamw(lo, hi):
+                ops.backend().adamw_hyper(self.flat.data[lo:hi], self.flat.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self._hyper,
+                                          self.betas[0], self.betas[1], self.eps, self.wd)
         else:
             self.step_count += 1
-            ops.backend().adamw(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                                self.eps, self.wd, self.step_count, 1.0 / self.world)
+
+            def adamw(lo, hi):
+                ops.backend().adamw(self.flat.data[lo:hi], self.flat.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
+                                    self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, 1.0 / self.world)
+        if deferred is None:
+            adamw(0, self.flat.numel)
+        else:
+            (lo, hi), handles = deferred
+            if lo > 0:
+                adamw(0, lo)
+            if hi < self.flat.numel:
+                adamw(hi, self.flat.numel)
+            self._mark("late_wait_begin")
+            for w in handles:
+                w.wait()
+            self._mark("late_wait_end")
+            adamw(lo, hi)
         ops.bump_weights_epoch()
 
     # ---- the whole step as ONE HIP graph ----------------------------------------------------------------------------------------
@@ -606,7 +633,13 @@ class E4TTrainer:
             try:
                 with ops.capture_guard():
                     torch.cuda.synchronize()
-                    with torch.cuda.graph(g):
+                    if self._comm:
+                        # ProcessGroupNCCL's watchdog thread polls the events of the eager steps' collectives (hipEventQuery every ~100 ms):
+                        # under the default GLOBAL capture mode such a call from another thread invalidates the capture or kills the watchdog
+                        # ("operation not permitted when stream is capturing", 4 of 12 runs of tests/rccl_one_rank.py).  Give it time to
+                        # retire the finished work, and capture thread-locally so that its remaining calls are none of the capture's business.
+                        time.sleep(0.5)
+                    with torch.cuda.graph(g, capture_error_mode="thread_local" if self._comm else "global"):
                         out = self._train_step(**{k: static.get(k) for k in ins})
             except Exception as e:                    # e.g. a collective the RCCL build will not capture: eager from here on
                 if not self._comm:
@@ -757,9 +790,11 @@ class E4TTrainer:
         self._armed = False
         if not sync:
             return loss.detach(), loss_diff.detach(), loss_reg.detach()
-        self.all_reduce_grads()
+        # (the gradient clip needs the norm of the WHOLE reduced gradient: with it every region is waited for first)
+        late = self.all_reduce_grads(defer="D" if self.max_grad_norm is None else None)
+        self.deferred_region = "D" if late else None          # diagnostics / tests
         self.clip_grad_norm()
-        self.optimizer_step()
+        self.optimizer_step(late)
         self.zero_grad()
         if self.world > 1 and self.replica_check_every > 0 and self.step_count % self.replica_check_every == 0 and not self._capturing:
             self.check_replicas()
@@ -774,7 +809,10 @@ class E4TTrainer:
         torch.cuda.synchronize()
         b = t["backward_begin"]
         return dict(enqueue_ms_after_backward_start={k: b.elapsed_time(e) for k, e in t.get("enqueue", {}).items()},
-                    wait_begin_ms=b.elapsed_time(t["wait_begin"]), exposed_wait_ms=t["wait_begin"].elapsed_time(t["wait_end"]),
+                    wait_begin_ms=b.elapsed_time(t["wait_begin"]),
+                    # the step's stream waiting for collectives: before AdamW, plus — when region D was deferred — between AdamW of the rest and of D
+                    exposed_wait_ms=t["wait_begin"].elapsed_time(t["wait_end"]) + (t["late_wait_begin"].elapsed_time(t["late_wait_end"]) if "late_wait_end" in t else 0.0),
+                    deferred_region="D" if "late_wait_end" in t else None,
                     region_bytes={k: 4 * (hi - lo) for k, (lo, hi) in (self.regions or {}).items()},
                     head_factor_bytes_per_rank=getattr(self, "_factor_bytes", 0),     # > 0: region W was exchanged as factors, not all-reduced
                     # _training_stream(): did a collective overlap with [the caller's stream, five new ones]; did the step move off the caller's

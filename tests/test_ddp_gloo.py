@@ -77,6 +77,7 @@ def _worker(rank, world, port, out_dir, unfreeze):
     tr.train_step(b["pixels"], b["ids"], b["pidx"], noise=b["noise"], timesteps=b["t"], latents=b["latents"])
     torch.save(tr.flat.data.clone(), os.path.join(out_dir, f"rank{rank}.pt"))
     torch.save(int(getattr(tr, "_factor_bytes", 0)), os.path.join(out_dir, f"factor_bytes{rank}.pt"))
+    torch.save(tr.deferred_region, os.path.join(out_dir, f"deferred{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -107,6 +108,8 @@ def test_two_rank_step_matches_accumulated_single_process(tmp_path, unfreeze):
     p0, p1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(p0, p1), "ranks diverged after the all-reduced step"
     assert all((torch.load(tmp_path / f"factor_bytes{r}.pt") > 0) == _FACTORS[unfreeze] for r in range(world))
+    # region D's all-reduce starts when the backward ends: AdamW of everything else runs under it — unless a gradient clip needs the whole norm first
+    assert all(torch.load(tmp_path / f"deferred{r}.pt") == (None if "max_grad_norm" in _MODE_KW[unfreeze] else "D") for r in range(world))
     # single process: accumulate both batches' gradients, average inside AdamW
     _setup_paths()
     from e4t import ops
