@@ -79,7 +79,7 @@ def _runs_beside(main, side, device) -> bool:
     e_main, e_side = torch.cuda.Event(), torch.cuda.Event()
     torch.cuda.synchronize(device)
     with torch.cuda.stream(main):
-        torch.cuda._sleep(20_000_000)          # a spin kernel: tens of ms at any counter rate the runtime uses; the probe leaves as soon as it knows
+        torch.cuda._sleep(20_000_000)          # a spin kernel, 9.6 ms on MI355X; the probe stops polling as soon as it knows
         e_main.record(main)
     with torch.cuda.stream(side):
         x.add_(1)
@@ -731,7 +731,7 @@ class E4TTrainer:
             torch.cuda.synchronize(dev)
             e = torch.cuda.Event()
             with torch.cuda.stream(c):
-                torch.cuda._sleep(20_000_000)
+                torch.cuda._sleep(60_000_000)          # ~29 ms (20 M cycles = 9.6 ms here): room for the ranks' skew behind the barrier
                 e.record(c)
             with torch.cuda.stream(idle):
                 w = torch.distributed.all_gather_into_tensor(dst, src, group=self.pg, async_op=True)
