@@ -198,6 +198,29 @@ def test_gradient_accumulation_matches_oracle(emu_fp32):
     assert checked == 96
 
 
+def test_adamw_in_two_parts_around_a_deferred_region_changes_no_bit(emu_fp32):
+    """Data parallel: AdamW of everything outside region D runs under D's all-reduce, D follows (optimizer_step(deferred=...)); the update
+    is element-wise, so the split must give the parameters and moments of the one-launch update bit for bit."""
+    class Handle:
+        waited = 0
+
+        def wait(self):
+            Handle.waited += 1
+    res = []
+    for split in (False, True):
+        tr, _ = _trainer()
+        loss, _, _ = tr.losses(*[_data(2, 31)[k] for k in ("px", "lat", "noise", "t", "ids", "pidx")])
+        loss.backward()
+        n = tr.flat.numel
+        lo, hi = (n // 3) // 64 * 64, (2 * n // 3) // 64 * 64
+        tr.optimizer_step(((lo, hi), [Handle(), Handle()]) if split else None)
+        res.append((tr.flat.data.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.step_count))
+    assert Handle.waited == 2 and res[0][3] == res[1][3] == 1
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a, b)
+    assert float((res[0][1] != 0).float().mean()) > 0.5         # (the gradients were there)
+
+
 def test_training_state_round_trip_resumes_bitwise(emu_fp32, tmp_path):
     batches = [_data(2, 31 + i) for i in range(3)]
     tr, _ = _trainer()
