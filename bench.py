@@ -420,9 +420,15 @@ def main():
         except OSError:
             out["details"] = None
         print(json.dumps(details), file=sys.stderr, flush=True)
-        print(json.dumps(out), flush=True)
     if world > 1 or force_comm:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; on a pipe that buffer is only flushed at exit, i.e. AFTER a line Python flushed.
+        # Push it out first so that the JSON line is the last line of rank 0's stdout.
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
     if rank == 0 and parity is not None and parity["n_bad"]:
         sys.exit(3)                                  # the run's own parity block failed: not a valid measurement
 
