@@ -186,6 +186,9 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_comm:
         dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # every rank: RCCL's start-up banner leaves the C-stdio buffer now, not at exit behind rank 0's JSON line
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from e4t import ops
