@@ -45,7 +45,6 @@ for name, N, K, kind in CASES:
         else:
             outs = [torch.empty((M, N), dtype=bf16, device=dev) for _ in range(nset)]
             fns = [(lambda a=a, o=o: hip.gemm(a, b, bias=bias, out=o, gelu=(kind == "gelu"))) for a, o in zip(As, outs)]
-        pl = hip.gemm_plan(M, N, K, gelu=(kind == "gelu"), out_f32=(kind == "res"), res_f32=(kind == "res"), bias=True) if hasattr(hip, "gemm_plan") else None
         t = graph_time(fns, 4 * nset)
-        print(f"[{label}] {name:9s} M{M} N{N} K{K}: {t:8.1f} us {2.0 * M * N * K / t / 1e6:7.1f} TF" + (f"  plan {pl}" if pl else ""), flush=True)
+        print(f"[{label}] {name:9s} M{M} N{N} K{K}: {t:8.1f} us {2.0 * M * N * K / t / 1e6:7.1f} TF", flush=True)
         del As, outs
