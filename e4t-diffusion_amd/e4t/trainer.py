@@ -124,6 +124,7 @@ class E4TTrainer:
         self._hyper, self._hyper_ring, self._hyper_i = None, [], 0
         self._capturing = self._graph_failed = False
         self._train_stream, self._train_stream_probed = None, False      # _training_stream()
+        self.deferred_region = None          # the region whose all-reduce the last synchronising step ran AdamW of the others under ("D" / None)
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         # E4T_FORCE_COMM=1: run the collective path even in a 1-rank group (exercises the RCCL calls / stream ordering on one GPU)
