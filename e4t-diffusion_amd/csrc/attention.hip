@@ -451,6 +451,299 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
 }
 
 // ================================================================================================
+// forward, long key ranges with a spare contraction slot (dh = 40), round 6: one wave = 64 queries, phased software pipeline
+// ================================================================================================
+// The kernel above runs, per wave and 32 x 32 score sub-tile, a strict chain  3 MFMA -> ~46 VALU (16 of them v_exp_f32) -> 4 MFMA:
+// MFMA and VALU of ONE wave never overlap, and four waves per SIMD at random phases recover only part of it (the
+// measured time is close to the SUM of the MFMA and the VALU issue time, 600 clk per sub-tile against 224 clk of matrix pipe).
+// tools/probe/mfma_rate.hip: a SIMD hides ~18 clk (4 plain VALU) under every 32-clk MFMA when the VALU work is independent of it
+// and sits next to it in program order.  This kernel arranges exactly that:
+//  * a wave owns TWO 32-query blocks a, b.  Every K fragment (ds_read_b128) and every V^T fragment (ds_read_b64_tr_b16 pair)
+//    read from LDS feeds two MFMAs, and a staged 64-key tile serves 256 queries instead of 128;
+//  * the loop is a sequence of PHASES, each = the softmax VALU of one block on scores that are already complete, beside the
+//    seven MFMAs of the OTHER block (its P.V of the previous sub-tile, then its scores of the next one), one MFMA in front of
+//    every 4-instruction softmax chunk (pk_fma, 2 exp, cvt_pk), pinned with sched_barrier:
+//        Y(j): softmax a(j)  ||  P.V b(j-1), then V^T(j) fragments, S b(j), then K(j+1) fragments
+//        X(j): softmax b(j)  ||  P.V a(j),  S a(j+1)             (odd j: + the staged registers -> LDS, next global loads)
+//  * a phase body has NO branch: no running-max pass in front of the exponentials.  P = exp2(s * scale2 - m) is formed with the
+//    row's current m; the eight packed bf16 P words are OR-ed and bit 14 (exponent >= 128: p >= 2, inf, NaN) ballot-tested at the
+//    end of the phase.  Only then (first tile of a row, a key that beats the running max by more than 2x) the slow path takes the
+//    true row max, raises m, rescales O^T and recomputes the sub-tile's P — before any MFMA has consumed it (P.V of a sub-tile is
+//    issued in the NEXT phase).  m, l and LSE = m + log2 l stay consistent, the result is the exact softmax;
+//  * keys beyond S need no VALU mask: the K image's first pad column (d = DH) holds -29952 for such rows against 1.0 in the Q
+//    fragment, so their scores come out of the MFMA as -29952 and p = 0; row sums ride in the spare O^T row (ones column of the
+//    V image) as in the kernel above;
+//  * two LDS tile buffers, ONE barrier per 64-key tile (in the odd Y phase, between the last read of the old tile and the first
+//    read of the next one); tiles are fetched with the row offset in the bounds-checked VGPR offset, so rows beyond S are zeros.
+#ifndef ATTN_FWD64
+#define ATTN_FWD64 1
+#endif
+#ifndef ATTN_FWD64_OCC
+#define ATTN_FWD64_OCC 2
+#endif
+#ifndef ATTN_FWD64_FENCE
+#define ATTN_FWD64_FENCE 1
+#endif
+#ifndef ATTN_FWD64_MIN_S
+#define ATTN_FWD64_MIN_S 512
+#endif
+#define A64_FENCE() do { if (ATTN_FWD64_FENCE) __builtin_amdgcn_sched_barrier(0); } while (0)
+// timing variants (results wrong in every variant but 0; tools/gpu_r06_b.sh): 1 exp2 -> plain add   2 no softmax VALU   3 no MFMA
+//   4 no LDS fragment reads (8: V^T only, 9: K only)   5 no tile staging (LDS stores, global loads)   6 no tile barrier   7 = 2 + 4 + 5 + 6 (MFMA stream only)
+#ifndef ATTN64_PROBE
+#define ATTN64_PROBE 0
+#endif
+__device__ __forceinline__ f32x16 a64_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  if (ATTN64_PROBE == 3) { Frag fa, fb; fa.v = a; fb.v = b; c[0] += __builtin_bit_cast(float, fa.w[0] ^ fb.w[1]); return c; }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float a64_exp2(float x) { return ATTN64_PROBE == 1 ? x + 1.f : fast_exp2(x); }
+
+// TileRegs with the tile row offset in the per-lane (bounds-checked) offset: rows at or beyond the resource's extent read as zeros
+template <int DH>
+struct TileRegsV {
+  using C = Cfg<DH>;
+  uint4 v[C::NIT][2];
+  unsigned vo[C::NIT], step[C::NIT];
+  unsigned ldb;
+  __device__ __forceinline__ void init(int ld) {
+    ldb = ld * 2;
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int item = threadIdx.x + it * 256;
+      const int ch = item >> 5, kp = item & 31;
+      const bool on = item < 32 * C::NCH;
+      vo[it] = on ? (unsigned)((2 * kp * ld + ch * 8) * 2) : 0xFFFF0000u;
+      step[it] = on ? 64u * ldb : 0u;
+    }
+  }
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs) {      // the next 64-row tile
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      v[it][0] = buf_load16(rs, vo[it], 0);
+      v[it][1] = buf_load16(rs, vo[it] + ldb, 0);
+      vo[it] += step[it];
+    }
+  }
+  // no divergent branch (a phase must stay ONE basic block): threads without an item store their (zero) registers into row
+  // slots 8.. of the 256-byte image rows, which no fragment read of a head dim <= 56 touches
+  __device__ __forceinline__ void store_rows(bf16_t* lds) const {
+    static_assert(C::NCH + 1 <= 8 && C::LDE == 128 && 32 * C::NCH + 96 >= 256 * C::NIT, "idle threads need free slots 8..10");
+#pragma unroll
+    for (int it = 0; it < C::NIT; ++it) {
+      const int item = threadIdx.x + it * 256;
+      const int ch = item >> 5, kp = item & 31;
+      const int slot = item < 32 * C::NCH ? ch : ch + (8 - C::NCH);
+      *(uint4*)(lds + img_off<C::LDE>(2 * kp, slot)) = v[it][0];
+      *(uint4*)(lds + img_off<C::LDE>(2 * kp + 1, slot)) = v[it][1];
+    }
+  }
+};
+
+// s * sc - mm on two adjacent score elements as ONE packed VALU instruction (the compiler scalarises the builtin form in most
+// chunks of the phase below: +1 VALU and a hazard nop each)
+__device__ __forceinline__ f32x2 pk_fms(f32x2 s, f32x2 sc, f32x2 mm) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(s), "s"(sc), "v"(mm));
+  return d;
+}
+
+// key-validity column of a K image: pad slot (d = DH .. DH + 7) of row r = {valid ? 0 : -29952, 0, ...}; four threads per row
+// write the same value (no divergent branch inside a phase)
+template <int DH>
+__device__ __forceinline__ void write_key_mask(bf16_t* kimg, int row0, int S) {
+  const int r = threadIdx.x & 63;
+  *(uint4*)(kimg + img_off<Cfg<DH>::LDE>(r, Cfg<DH>::NCH)) = make_uint4(row0 + r < S ? 0u : 0xC6EAu, 0u, 0u, 0u);
+}
+
+// One phase (see above).  x = the block whose scores sx become P (px); y = the other block: its pending P.V and its next scores.
+//   LOADS: Y phase — reload the V^T fragments from lds + VOFF after the P.V MFMAs and the K fragments from lds + KOFF after the
+//          score MFMAs (BAR: the tile barrier in front of the K reload);  STAGE >= 0: X phase that writes the staged registers
+//          into the images at lds + STAGE (K) / + STAGE + TILE (V) and issues the next tile's global loads.
+template <int DH, bool LOADS, int VOFF, int KOFF, bool BAR, int STAGE>
+__device__ __forceinline__ void fwd64_phase(const float scale2, const FragOff<DH>& fo, bf16_t* lds,
+                                            const f32x16& sx, f32x2& mm, Frag (&px)[2], f32x16 (&ox)[Cfg<DH>::NDT],
+                                            f32x16& sy, const Frag (&py)[2], f32x16 (&oy)[Cfg<DH>::NDT], const bf16x8 (&qfy)[Cfg<DH>::NKS],
+                                            bf16x8 (&vfr)[Cfg<DH>::NDT][2], bf16x8 (&kfr)[Cfg<DH>::NKS],
+                                            TileRegsV<DH>& kr, TileRegsV<DH>& vr, const __amdgpu_buffer_rsrc_t rsK,
+                                            const __amdgpu_buffer_rsrc_t rsV, const int stage_row0, const int S) {
+  using C = Cfg<DH>;
+  constexpr int NPV = 2 * C::NDT, NM = NPV + C::NKS, TILE = 64 * C::LDE;
+  const f32x2 sc = {scale2, scale2};
+  f32x2 t = pk_fms(f32x2{sx[0], sx[1]}, sc, mm);   // the exp argument of chunk c is formed in chunk c - 1 (no dependent back-to-back VALU)
+  float pe0 = 0.f, pe1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+#pragma unroll
+    for (int i = (c * NM + 7) / 8; i < ((c + 1) * NM + 7) / 8; ++i) {
+      if (i < NPV) {                               // k-step outer: neighbouring MFMAs accumulate into different O^T blocks
+        const int k2 = i / C::NDT, dt = i % C::NDT;
+        oy[dt] = a64_mfma(vfr[dt][k2], py[k2].v, oy[dt]);
+      } else {
+        const int ks = i - NPV;
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        sy = a64_mfma(kfr[ks], qfy[ks], ks == 0 ? z : sy);
+      }
+      A64_FENCE();
+      if (LOADS && i == NPV - 1 && ATTN64_PROBE != 4 && ATTN64_PROBE != 7 && ATTN64_PROBE != 8) {                 // every V^T fragment has been consumed: fetch the next sub-tile's
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int dt = 0; dt < C::NDT; ++dt) {
+            const bf16_t* vb = lds + VOFF + k2 * 16 * C::LDE;
+            vfr[dt][k2] = tr_frag(vb + fo.tr_lo[dt], vb + fo.tr_hi[dt]);
+          }
+        A64_FENCE();
+      }
+      if (LOADS && i == NM - 1 && BAR && ATTN64_PROBE != 6 && ATTN64_PROBE != 7) __syncthreads();
+      if (LOADS && i == NM - 1 && (ATTN64_PROBE == 4 || ATTN64_PROBE == 7 || ATTN64_PROBE == 9)) {      // (opaque: the score MFMAs must not become loop-invariant)
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) asm volatile("" : "+v"(kfr[ks]));
+      }
+      if (LOADS && i == NM - 1 && ATTN64_PROBE != 4 && ATTN64_PROBE != 7 && ATTN64_PROBE != 9) {                  // the next tile's image is complete; nobody reads the old tile any more
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) kfr[ks] = *(const bf16x8*)(lds + KOFF + fo.row[ks]);
+        A64_FENCE();
+      }
+    }
+    if (ATTN64_PROBE == 2 || ATTN64_PROBE == 7) {
+      px[c >> 2].w[c & 3] = __builtin_bit_cast(uint32_t, sx[2 * c]);
+    } else {                                       // softmax chunk c: score elements 2c, 2c + 1 of this lane's query
+      const float e0 = a64_exp2(t.x), e1 = a64_exp2(t.y);
+      if (c < 7) t = pk_fms(f32x2{sx[2 * c + 2], sx[2 * c + 3]}, sc, mm);
+      if (c > 0) px[(c - 1) >> 2].w[(c - 1) & 3] = pack2bf(pe0, pe1);      // the previous chunk's pair: no trans -> VALU hazard nop
+      pe0 = e0; pe1 = e1;
+    }
+    A64_FENCE();
+    if (STAGE >= 0 && ATTN64_PROBE != 5 && ATTN64_PROBE != 7) {
+      if (c == 0) { kr.store_rows(lds + STAGE); write_key_mask<DH>(lds + STAGE, stage_row0, S); A64_FENCE(); }
+      if (c == 1) { vr.store_rows(lds + STAGE + TILE); A64_FENCE(); }
+      if (c == 2) { kr.load(rsK); A64_FENCE(); }
+      if (c == 3) { vr.load(rsV); A64_FENCE(); }
+    }
+  }
+  if (ATTN64_PROBE != 2 && ATTN64_PROBE != 7) px[1].w[3] = pack2bf(pe0, pe1);
+  const uint32_t orv = (px[0].w[0] | px[0].w[1] | px[0].w[2]) | (px[0].w[3] | px[1].w[0] | px[1].w[1]) | (px[1].w[2] | px[1].w[3]);
+  if (ATTN64_PROBE == 0 && __builtin_amdgcn_ballot_w64((orv & 0x40004000u) != 0u) != 0) {      // some p >= 2 (or inf / NaN): raise the running max
+    float mv = sx[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mv = fmaxf(mv, sx[r]);
+    mv = xhalf_max(mv) * scale2;                   // scale2 > 0
+    const float mn = fmaxf(mm.x, mv);
+    const float alpha = fast_exp2(mm.x - mn);
+    mm = f32x2{mn, mn};
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ox[dt][r] *= alpha;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f32x2 u = pk_fma(f32x2{sx[2 * c], sx[2 * c + 1]}, sc, -mm);
+      px[c >> 2].w[c & 3] = pack2bf(fast_exp2(u.x), fast_exp2(u.y));
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArgs p) {
+  using C = Cfg<DH>;
+  static_assert(DH % 16 == 8 && C::DV > DH, "needs a spare contraction slot (key mask) and a spare O^T row (row sum)");
+  constexpr int TILE = 64 * C::LDE;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE];       // [K image 0][V image 0][K image 1][V image 1]
+  const FragOff<DH> fo;
+  const Blk blk = xcd_block(p.xcd_raster);
+  const int b = blk.b, h = blk.h;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int q0 = blk.x * 256 + wave * 64 + li;                         // block a: row q0, block b: row q0 + 32
+  const bf16_t* Qb = p.Q + b * p.bq + h * DH;
+  const bf16_t* Kb = p.K + b * p.bk + h * DH;
+  const bf16_t* Vb = p.V + b * p.bv + h * DH;
+
+  bf16x8 qf[2][C::NKS];
+  load_row_frags<DH>(Qb, p.ldq, q0, p.T, hi, qf[0]);
+  load_row_frags<DH>(Qb, p.ldq, q0 + 32, p.T, hi, qf[1]);
+  if (hi == 1) {                                   // d = DH (first pad slot of k-step DH / 16) = 1.0: picks up the key-validity column
+    Frag t;
+    t.q = make_uint4(0x3F80u, 0u, 0u, 0u);
+    qf[0][DH / 16] = t.v; qf[1][DH / 16] = t.v;
+  }
+
+  TileRegsV<DH> kr, vr;
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(Kb, (unsigned)(((long long)(p.S - 1) * p.ldk + DH) * 2));
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(Vb, (unsigned)(((long long)(p.S - 1) * p.ldv + DH) * 2));
+  kr.init(p.ldk); vr.init(p.ldv);
+  kr.load(rsK); vr.load(rsV);                      // tile 0
+  if (threadIdx.x < 128) {                         // V images: element d = DH of every key row = 1.0, the rest of that slot 0; never overwritten
+    bf16_t* vimg = lds + ((threadIdx.x >> 6) * 2 + 1) * TILE;
+    *(uint4*)(vimg + img_off<C::LDE>(threadIdx.x & 63, C::NCH)) = make_uint4(0x3F80u, 0u, 0u, 0u);
+  }
+  write_key_mask<DH>(lds, 0, p.S);
+  write_key_mask<DH>(lds + 2 * TILE, 64, p.S);
+  kr.store_rows(lds); vr.store_rows(lds + TILE);
+  kr.load(rsK); vr.load(rsV);                      // tile 1
+  kr.store_rows(lds + 2 * TILE); vr.store_rows(lds + 3 * TILE);
+  kr.load(rsK); vr.load(rsV);                      // tile 2 waits in registers for the first odd X phase
+
+  f32x16 oa[C::NDT], ob[C::NDT], sa, sb;
+  Frag pa[2], pb[2];
+  bf16x8 vfr[C::NDT][2], kfr[C::NKS];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oa[dt][r] = 0.f; ob[dt][r] = 0.f; }
+  {
+    Frag z;
+    z.q = make_uint4(0u, 0u, 0u, 0u);
+    pa[0] = z; pa[1] = z; pb[0] = z; pb[1] = z;
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) { vfr[dt][0] = z.v; vfr[dt][1] = z.v; }
+  }
+  f32x2 ma = {-1e30f, -1e30f}, mb = ma;      // running row max (log2 units), duplicated for the packed fma
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < C::NKS; ++ks) kfr[ks] = *(const bf16x8*)(lds + fo.row[ks]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < C::NKS; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[0][ks], sa, 0, 0, 0);
+
+  const int ntiles = (p.S + 63) >> 6;
+  // one 64-key tile in buffer TB: sub-tiles 2t, 2t + 1 (a ragged last tile is processed whole: its absent keys are masked)
+  auto tile = [&](auto tb_, int t) __attribute__((always_inline)) {
+    constexpr int TB = decltype(tb_)::value;
+    constexpr int KI = TB * 2 * TILE, VI = KI + TILE, KN = (1 - TB) * 2 * TILE;
+    fwd64_phase<DH, true, VI, KI + 32 * C::LDE, false, -1>(p.scale2, fo, lds, sa, ma, pa, oa, sb, pb, ob, qf[1], vfr, kfr, kr, vr, rsK, rsV, 0, p.S);
+    fwd64_phase<DH, false, 0, 0, false, -1>(p.scale2, fo, lds, sb, mb, pb, ob, sa, pa, oa, qf[0], vfr, kfr, kr, vr, rsK, rsV, 0, p.S);
+    fwd64_phase<DH, true, VI + 32 * C::LDE, KN, true, -1>(p.scale2, fo, lds, sa, ma, pa, oa, sb, pb, ob, qf[1], vfr, kfr, kr, vr, rsK, rsV, 0, p.S);
+    fwd64_phase<DH, false, 0, 0, false, KI>(p.scale2, fo, lds, sb, mb, pb, ob, sa, pa, oa, qf[0], vfr, kfr, kr, vr, rsK, rsV, (t + 2) * 64, p.S);
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
+  }
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2)                   // the last sub-tile's P.V of block b
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) ob[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[dt][k2], pb[k2].v, ob[dt], 0, 0, 0);
+
+  constexpr int sblk = DH / 32, sreg = (DH % 32) / 8 * 4;              // O^T row d = DH: the row sum (hi = 0 lanes)
+  float la = __shfl(oa[sblk][sreg], li, 64), lb = __shfl(ob[sblk][sreg], li, 64);
+  bf16_t* Ob = p.Out + b * p.bo + h * DH;
+  int qrow = q0;
+  asm volatile("" : "+v"(qrow));
+  store_T_acc<DH>(oa, 1.f / la, Ob, p.ldo, qrow, p.T, hi);
+  store_T_acc<DH>(ob, 1.f / lb, Ob, p.ldo, qrow + 32, p.T, hi);
+  if (p.L && hi == 0) {
+    float* Lb = p.L + ((long long)b * p.H + h) * p.T;
+    if (qrow < p.T) Lb[qrow] = ma.x + log2f(la);
+    if (qrow + 32 < p.T) Lb[qrow + 32] = mb.x + log2f(lb);
+  }
+}
+
+// ================================================================================================
 // backward: Delta[b][h][q] = sum_d dO * O — computed in the PROLOGUE of the dQ kernel (round 5; was a kernel of its own: 13 launches
 // per step that read O and dO once more).  The dQ kernel holds its 32 queries' dO rows as MFMA fragments anyway — lane (li, hi) owns
 // the 8-element slices [16 ks + 8 hi, +8) of row q = li — so Delta is the same slices of O multiplied in, summed per lane and across
@@ -811,8 +1104,16 @@ inline void dkv_tsplit(int Bn, int H, int T, int S, int* tsplit, int* tchunk) {
 template <int DH>
 int launch_fwd(const AttnArgs& p, int Bn, hipStream_t st) {
   // algorithmic bytes: Q, K, V read once, O written once (bf16) + the fp32 log-sum-exp
-  E4T_LOG_LAUNCH("attn_fwd_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
+  const bool fwd64 = DH == 40 && ATTN_FWD64 && !p.causal && p.S >= ATTN_FWD64_MIN_S;
+  E4T_LOG_LAUNCH("%s<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", fwd64 ? "attn_fwd64_kernel" : "attn_fwd_kernel", DH, Bn, p.H, p.T, p.S, p.causal,
                  2.0 * Bn * p.H * DH * (2.0 * p.T + 2.0 * p.S) + 4.0 * Bn * p.H * p.T, 4.0 * Bn * p.H * (double)p.T * p.S * DH);
+  if constexpr (DH == 40) {
+    if (fwd64) {
+      hipLaunchKernelGGL((attn_fwd64_kernel<DH>), dim3(cdiv(p.T, 256), p.H, Bn), dim3(256), 0, st, p);
+      E4T_CHECK_LAUNCH("attn_fwd64_kernel");
+      return 0;
+    }
+  }
   const int probe_lds = 0;
   hipLaunchKernelGGL((attn_fwd_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), probe_lds, st, p);
   E4T_CHECK_LAUNCH("attn_fwd_kernel");

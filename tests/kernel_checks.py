@@ -262,6 +262,9 @@ def check_attention(hip, emu, dev):
         # few key blocks, long query range: the dK/dV kernel cuts T into chunks + fp32 partial reduce (round 4) — the step's own
         # cross-attention shape at a smaller batch, a ragged T (3 chunks of 384 / 384 / 232), dh 80 / 64, a short self-attention
         (2, 8, 4096, 77, 40), (1, 2, 1000, 77, 40), (2, 2, 1024, 77, 80), (1, 2, 600, 33, 64), (1, 4, 1024, 1024, 40),
+        # round 6: the 64-queries-per-wave forward (dh 40, S >= 512): last tile of 8 keys (its second sub-tile fully masked), of 33
+        # keys, ragged T inside a 256-query block, exactly one tile pair
+        (1, 2, 520, 520, 40), (2, 3, 700, 545, 40), (1, 1, 40, 512, 40), (2, 2, 256, 640, 40),
     ]
     for i, case in enumerate(cases):
         (B, H, T, S, DH), causal = case[:5], (len(case) > 5 and case[5])
@@ -300,6 +303,17 @@ def check_attention(hip, emu, dev):
     o, lse = hip.attention_fwd(q, k, v, B, H, T, S, DH, 1.0)
     o_r, lse_r = emu.attention_fwd(q, k, v, B, H, T, S, DH, 1.0)
     out.append(("attn peaked-score fwd", rel(o, o_r), TOL2))
+    # the same on the dh-40 long-key kernel: keys that beat the running max by far in the first, a middle and the last tile (its slow
+    # path: P recomputed after the row max is raised), a row whose best key comes first, and a huge negative score
+    g = gen(121, dev)
+    B, H, T, S, DH = 1, 1, 96, 840, 40
+    q, k, v = rnd(g, T, DH, dev=dev), rnd(g, S, DH, dev=dev), rnd(g, S, DH, dev=dev)
+    for key, row, mul in ((3, 7, 8.0), (333, 40, 12.0), (834, 5, 20.0), (0, 70, 30.0), (500, 9, -30.0)):
+        k[key] = (q[row].float() * mul).to(bf16)
+    o, lse = hip.attention_fwd(q, k, v, B, H, T, S, DH, 1.0)
+    o_r, lse_r = emu.attention_fwd(q, k, v, B, H, T, S, DH, 1.0)
+    out.append(("attn peaked-score dh40 long-key fwd O", rel(o, o_r), TOL2))
+    out.append(("attn peaked-score dh40 long-key fwd LSE", rel(lse, lse_r), 1e-3))
     return out
 
 
