@@ -478,6 +478,13 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
 #ifndef ATTN_FWD64
 #define ATTN_FWD64 1
 #endif
+// attn_bwd_dkv64_kernel below is NOT the product path (0): measured on B16 H8 T = S = 4096 it takes ~1000 us against the ~880 us of
+// attn_bwd_dkv_kernel<40, 3> (tools/ab_attn_bwd.py, profiles/r06_ab/attention_bwd64.txt).  It needs 365 registers, i.e. ONE wave per
+// SIMD, and with one wave per SIMD nothing covers its LDS reads, tile staging and barrier skew (knock-out timings: MFMA stream alone
+// 424 us, + VALU 570, staging 221, barrier 176): three resident waves of the old kernel hide exactly those.  Kept for -DATTN_BWD64=1 A/B.
+#ifndef ATTN_BWD64
+#define ATTN_BWD64 0
+#endif
 #ifndef ATTN_FWD64_OCC
 #define ATTN_FWD64_OCC 2
 #endif
@@ -1054,6 +1061,245 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
   store_T_acc<DH>(dkt, p.scale, p.dK + b * p.bk + h * DH, p.ldk, krow, p.S, hi);
 }
 
+// ================================================================================================
+// backward dK, dV for long query ranges with spare contraction slots (dh = 40), round 6: one wave = 64 keys, one wave per SIMD
+// ================================================================================================
+// The phased structure of attn_fwd64_kernel applied to the dK/dV kernel (same arithmetic as attn_bwd_dkv_kernel's FOLD path):
+// a wave owns TWO 32-key blocks (K, V fragments in registers), so every Q / dO row fragment and every Q^T / dO^T transposed
+// fragment read from LDS feeds two MFMAs, and a staged 64-query tile serves 256 keys.  A phase = the exp / dS VALU of one block
+// (16 half-chunks of 3 instructions) with ONE of the other block's 14 MFMAs in front of each (its dV^T / dK^T updates of the
+// previous sub-tile, then its S^T / dP^T of the next one).  14 MFMAs (448 clk) against ~270 clk of VALU: the phase is MFMA-bound.
+// No branch inside the loop: padded query rows carry L = +inf in the folded column (p = 0), padded key lanes only pollute their own
+// never-stored accumulator columns.  512 registers per lane (one workgroup per CU): 128 accumulators + 48 K/V fragments + 64
+// score registers + the fragment sets of two sub-tiles.
+__device__ __forceinline__ f32x2 pk_mul_s(f32x2 a, f32x2 sc) {
+  f32x2 d;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "s"(sc));
+  return d;
+}
+// Score MFMAs of the one-wave-per-SIMD kernels: D in ARCH VGPRs (the softmax VALU reads it; left to the allocator under 400+
+// live registers it lands in the accumulator file and comes back through 64 v_accvgpr_read per phase), B operand = a K / V / Q / dO
+// fragment that lives in the ACCUMULATOR file for the whole kernel (MFMA reads A / B from either file).  Inline asm: the compiler
+// pads no hazard here — every reader of D sits a whole phase (> 100 instructions) later, A comes from ds_read (counted by the
+// compiler in front of the statement), B is written once in the prologue.
+__device__ __forceinline__ void mfma_vab0(f32x16& d, bf16x8 a, bf16x8 b_acc) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b_acc));
+}
+__device__ __forceinline__ void mfma_vab(f32x16& d, bf16x8 a, bf16x8 b_acc) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b_acc));
+}
+__device__ __forceinline__ uint4 split3_bf16(float x) {          // x ~ hi + mid + lo, each a bf16 (24 bits): {hi | mid << 16, lo, 0, 0}
+  const bf16_t h0 = f2bf(x);
+  const float r1 = x - bf2f(h0);
+  const bf16_t h1 = f2bf(r1);
+  const bf16_t h2 = f2bf(r1 - bf2f(h1));
+  return make_uint4((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2, 0u, 0u);
+}
+
+// per-tile query statistics of the dK/dV kernel, one tile ahead in registers like the tile itself (row = thread & 63)
+struct StatRegs {
+  float lraw, draw;        // as loaded (row clamped to T - 1); the padded-row select happens at the point of USE, a tile later — applied
+  int q;                   // at the load it would put the global-load latency of every tile in front of the next instruction
+  __device__ __forceinline__ void load(const float* L, const float* Dl, int T) {      // q = this thread's query row of the tile being loaded
+    const int qc = min(q, T - 1);
+    lraw = L[qc]; draw = Dl[qc];
+    q += 64;
+  }
+  __device__ __forceinline__ float l(int T) const { return q - 64 < T ? lraw : INFINITY; }
+  __device__ __forceinline__ float d(int T) const { return q - 64 < T ? draw : 0.f; }
+};
+
+template <int DH, bool LOADS, int TOFF, int ROFF, bool BAR, int STAGE>
+__device__ __forceinline__ void dkv64_phase(const float scale2, const float inv_scale2, const FragOff<DH>& fo, bf16_t* lds,
+                                            const f32x16& sx, const f32x16& dpx, Frag (&pfx)[2], Frag (&sfx)[2],
+                                            f32x16& sy, f32x16& dpy, const Frag (&pfy)[2], const Frag (&sfy)[2],
+                                            f32x16 (&dvy)[Cfg<DH>::NDT], f32x16 (&dky)[Cfg<DH>::NDT],
+                                            const bf16x8 (&kfy)[Cfg<DH>::NKS], const bf16x8 (&vfy)[Cfg<DH>::NKS],
+                                            bf16x8 (&qT)[Cfg<DH>::NDT][2], bf16x8 (&doT)[Cfg<DH>::NDT][2],
+                                            bf16x8 (&qrow)[Cfg<DH>::NKS], bf16x8 (&dorow)[Cfg<DH>::NKS],
+                                            TileRegsV<DH>& qr, TileRegsV<DH>& dor, StatRegs& st, const __amdgpu_buffer_rsrc_t rsQ,
+                                            const __amdgpu_buffer_rsrc_t rsdO, const float* Lb, const float* Db, const int T) {
+  using C = Cfg<DH>;
+  constexpr int NG = 4 * C::NDT, NM = NG + 2 * C::NKS, TILE = 64 * C::LDE;      // gradient MFMAs, then score MFMAs
+  const f32x2 sc = {scale2, scale2};
+  float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+  for (int h = 0; h < 16; ++h) {
+#pragma unroll
+    for (int i = (h * NM + 15) / 16; i < ((h + 1) * NM + 15) / 16; ++i) {
+      if (i < NG) {                                // dV^T / dK^T alternate, k-step outer: neighbours hit different accumulators
+        const int w = i & 1, dt = (i >> 1) % C::NDT, k2 = (i >> 1) / C::NDT;
+        if (w == 0) dvy[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[dt][k2], pfy[k2].v, dvy[dt], 0, 0, 0);
+        else dky[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[dt][k2], sfy[k2].v, dky[dt], 0, 0, 0);
+      } else {
+        const int w = (i - NG) & 1, ks = (i - NG) >> 1;
+        if (w == 0) { if (ks == 0) mfma_vab0(sy, qrow[ks], kfy[ks]); else mfma_vab(sy, qrow[ks], kfy[ks]); }
+        else { if (ks == 0) mfma_vab0(dpy, dorow[ks], vfy[ks]); else mfma_vab(dpy, dorow[ks], vfy[ks]); }
+      }
+      A64_FENCE();
+      if (LOADS && i == NG - 1 && ATTN64_PROBE != 4 && ATTN64_PROBE != 7) {                  // every transposed fragment has been consumed: fetch this sub-tile's
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int dt = 0; dt < C::NDT; ++dt) {
+            const bf16_t* qb = lds + TOFF + k2 * 16 * C::LDE;
+            qT[dt][k2] = tr_frag(qb + fo.tr_lo[dt], qb + fo.tr_hi[dt]);
+            doT[dt][k2] = tr_frag(qb + TILE + fo.tr_lo[dt], qb + TILE + fo.tr_hi[dt]);
+          }
+        A64_FENCE();
+      }
+      if (LOADS && i == NM - 1 && BAR && ATTN64_PROBE != 6 && ATTN64_PROBE != 7) __syncthreads();
+      if (LOADS && i == NM - 1 && (ATTN64_PROBE == 4 || ATTN64_PROBE == 7)) {
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) { asm volatile("" : "+v"(qrow[ks])); asm volatile("" : "+v"(dorow[ks])); }
+      }
+      if (LOADS && i == NM - 1 && ATTN64_PROBE != 4 && ATTN64_PROBE != 7) {                  // the next tile's images are complete; nobody reads the old tile any more
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) {
+          qrow[ks] = *(const bf16x8*)(lds + ROFF + fo.row[ks]);
+          dorow[ks] = *(const bf16x8*)(lds + ROFF + TILE + fo.row[ks]);
+        }
+        A64_FENCE();
+      }
+    }
+    const int c = h >> 1;                          // score elements 2c, 2c + 1 of this lane's key
+    if (ATTN64_PROBE == 2 || ATTN64_PROBE == 7) {
+      if (h & 1) { pfx[c >> 2].w[c & 3] = __builtin_bit_cast(uint32_t, sx[2 * c]); sfx[c >> 2].w[c & 3] = __builtin_bit_cast(uint32_t, dpx[2 * c]); }
+    } else if ((h & 1) == 0) {
+      const f32x2 t = pk_mul_s(f32x2{sx[2 * c], sx[2 * c + 1]}, sc);
+      e0 = fast_exp2(t.x); e1 = fast_exp2(t.y);
+    } else {
+      const f32x2 d2 = f32x2{e0, e1} * f32x2{dpx[2 * c], dpx[2 * c + 1]};
+      pfx[c >> 2].w[c & 3] = pack2bf(e0, e1);
+      sfx[c >> 2].w[c & 3] = pack2bf(d2.x, d2.y);
+    }
+    A64_FENCE();
+    if (STAGE >= 0 && ATTN64_PROBE != 5 && ATTN64_PROBE != 7) {
+      if (h == 0) {
+        qr.store_rows(lds + STAGE);
+        *(uint4*)(lds + STAGE + img_off<C::LDE>(threadIdx.x & 63, C::NCH)) = split3_bf16(fmaxf(-st.l(T) * inv_scale2, -1e30f));
+        A64_FENCE();
+      }
+      if (h == 2) {
+        dor.store_rows(lds + STAGE + TILE);
+        *(uint4*)(lds + STAGE + TILE + img_off<C::LDE>(threadIdx.x & 63, C::NCH)) = split3_bf16(-st.d(T));
+        A64_FENCE();
+      }
+      if (h == 4) { qr.load(rsQ); A64_FENCE(); }
+      if (h == 6) { dor.load(rsdO); st.load(Lb, Db, T); A64_FENCE(); }
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs p) {
+  using C = Cfg<DH>;
+  static_assert(DH % 16 == 8 && C::DK - DH >= 3, "needs three spare contraction slots (folded L / Delta)");
+  constexpr int TILE = 64 * C::LDE;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE];       // [Q image 0][dO image 0][Q image 1][dO image 1]
+  const FragOff<DH> fo;
+  const Blk blk = xcd_block(p.xcd_raster);
+  const int b = blk.b, h = blk.h;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int key0 = blk.x * 256 + wave * 64 + li;                       // block 0: key0, block 1: key0 + 32
+  const bf16_t* Qb = p.Q + b * p.bq + h * DH;
+  const bf16_t* dOb = p.dO + b * p.bo + h * DH;
+  const float* Lb = p.L + ((long long)b * p.H + h) * p.T;
+  const float* Db = p.Delta + ((long long)b * p.H + h) * p.T;
+
+  bf16x8 kf[2][C::NKS], vf[2][C::NKS];
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    load_row_frags<DH>(p.K + b * p.bk + h * DH, p.ldk, key0 + 32 * x, p.S, hi, kf[x]);
+    load_row_frags<DH>(p.V + b * p.bv + h * DH, p.ldv, key0 + 32 * x, p.S, hi, vf[x]);
+    if (hi == 1) {                                 // ones against the three folded bf16 pieces of -L / scale2 (Q image) and -Delta (dO image)
+      Frag t;
+      t.q = make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u);
+      kf[x][DH / 16] = t.v; vf[x][DH / 16] = t.v;
+    }
+  }
+  const float inv_scale2 = 1.f / p.scale2;
+  TileRegsV<DH> qr, dor;
+  StatRegs st;
+  st.q = threadIdx.x & 63;
+  const __amdgpu_buffer_rsrc_t rsQ = make_rsrc(Qb, (unsigned)(((long long)(p.T - 1) * p.ldq + DH) * 2));
+  const __amdgpu_buffer_rsrc_t rsdO = make_rsrc(dOb, (unsigned)(((long long)(p.T - 1) * p.ldo + DH) * 2));
+  qr.init(p.ldq); dor.init(p.ldo);
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb) {                 // tiles 0 and 1 -> the two buffers
+    qr.load(rsQ); dor.load(rsdO); st.load(Lb, Db, p.T);
+    qr.store_rows(lds + tb * 2 * TILE); dor.store_rows(lds + tb * 2 * TILE + TILE);
+    *(uint4*)(lds + tb * 2 * TILE + img_off<C::LDE>(threadIdx.x & 63, C::NCH)) = split3_bf16(fmaxf(-st.l(p.T) * inv_scale2, -1e30f));
+    *(uint4*)(lds + tb * 2 * TILE + TILE + img_off<C::LDE>(threadIdx.x & 63, C::NCH)) = split3_bf16(-st.d(p.T));
+  }
+  qr.load(rsQ); dor.load(rsdO); st.load(Lb, Db, p.T);                   // tile 2 waits in registers for the first odd X phase
+
+  f32x16 dv0[C::NDT], dk0[C::NDT], dv1[C::NDT], dk1[C::NDT], s0, dp0, s1, dp1;
+  Frag pf0[2], sf0[2], pf1[2], sf1[2];
+  bf16x8 qT[C::NDT][2], doT[C::NDT][2], qrow[C::NKS], dorow[C::NKS];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dv0[dt][r] = 0.f; dk0[dt][r] = 0.f; dv1[dt][r] = 0.f; dk1[dt][r] = 0.f; }
+  {
+    Frag z;
+    z.q = make_uint4(0u, 0u, 0u, 0u);
+    pf0[0] = z; pf0[1] = z; sf0[0] = z; sf0[1] = z; pf1[0] = z; pf1[1] = z; sf1[0] = z; sf1[1] = z;
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) { qT[dt][0] = z.v; qT[dt][1] = z.v; doT[dt][0] = z.v; doT[dt][1] = z.v; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ks = 0; ks < C::NKS; ++ks) {
+    qrow[ks] = *(const bf16x8*)(lds + fo.row[ks]);
+    dorow[ks] = *(const bf16x8*)(lds + TILE + fo.row[ks]);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s0[r] = 0.f; dp0[r] = 0.f; }
+#pragma unroll
+  for (int ks = 0; ks < C::NKS; ++ks) {
+    mfma_vab(s0, qrow[ks], kf[0][ks]);
+    mfma_vab(dp0, dorow[ks], vf[0][ks]);
+  }
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");          // (these D registers are read a few instructions into the first phase)
+
+  const int ntiles = (p.T + 63) >> 6;
+  auto tile = [&](auto tb_) __attribute__((always_inline)) {
+    constexpr int TB = decltype(tb_)::value;
+    constexpr int QI = TB * 2 * TILE, QN = (1 - TB) * 2 * TILE;
+#define DKV64_ARGS_Y s0, dp0, pf0, sf0, s1, dp1, pf1, sf1, dv1, dk1, kf[1], vf[1]
+#define DKV64_ARGS_X s1, dp1, pf1, sf1, s0, dp0, pf0, sf0, dv0, dk0, kf[0], vf[0]
+#define DKV64_TAIL qT, doT, qrow, dorow, qr, dor, st, rsQ, rsdO, Lb, Db, p.T
+    dkv64_phase<DH, true, QI, QI + 32 * C::LDE, false, -1>(p.scale2, inv_scale2, fo, lds, DKV64_ARGS_Y, DKV64_TAIL);
+    dkv64_phase<DH, false, 0, 0, false, -1>(p.scale2, inv_scale2, fo, lds, DKV64_ARGS_X, DKV64_TAIL);
+    dkv64_phase<DH, true, QI + 32 * C::LDE, QN, true, -1>(p.scale2, inv_scale2, fo, lds, DKV64_ARGS_Y, DKV64_TAIL);
+    dkv64_phase<DH, false, 0, 0, false, QI>(p.scale2, inv_scale2, fo, lds, DKV64_ARGS_X, DKV64_TAIL);
+#undef DKV64_ARGS_Y
+#undef DKV64_ARGS_X
+#undef DKV64_TAIL
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(std::integral_constant<int, 0>{});
+    if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{});
+  }
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2)                   // the last sub-tile's gradient updates of block 1
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) {
+      dv1[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT[dt][k2], pf1[k2].v, dv1[dt], 0, 0, 0);
+      dk1[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT[dt][k2], sf1[k2].v, dk1[dt], 0, 0, 0);
+    }
+  int krow = key0;
+  asm volatile("" : "+v"(krow));
+  bf16_t* dVb = p.dV + b * p.bv + h * DH;
+  bf16_t* dKb = p.dK + b * p.bk + h * DH;
+  store_T_acc<DH>(dv0, 1.f, dVb, p.ldv, krow, p.S, hi);
+  store_T_acc<DH>(dk0, p.scale, dKb, p.ldk, krow, p.S, hi);
+  store_T_acc<DH>(dv1, 1.f, dVb, p.ldv, krow + 32, p.S, hi);
+  store_T_acc<DH>(dk1, p.scale, dKb, p.ldk, krow + 32, p.S, hi);
+}
+
 // dV / dK = sum over the query chunks' partials (fixed order: deterministic), dK scaled, one bf16 rounding
 template <int DH>
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs p, int Bn) {
@@ -1133,17 +1379,29 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
   // dh 64 (SD-2.x): three workgroups per CU cost the kernel a 16-byte spill and buy nothing (C5 B = 4: 85.3 vs 85.8 ms per step, B = 1 equal;
   // profiles/r04_ab/r04g_c5_occ*): it stays at two
   const int dkv_occ = DH > 64 ? 1 : ((p.S >= 2048 && DH < 64) ? 3 : DKV_WAVES);
+  const bool dkv64 = DH == 40 && ATTN_BWD64 && !p.causal && p.tsplit == 1 && p.T >= ATTN_FWD64_MIN_S && p.S >= 256;
   if (e4t_launch_log_enabled()) {
     const double el = (double)Bn * p.H * DH;      // elements per token row over all heads
     E4T_LOG_LAUNCH("attn_bwd_dq_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
                    2.0 * el * (4.0 * p.T + 2.0 * p.S) + 8.0 * Bn * p.H * p.T, 6.0 * Bn * p.H * (double)p.T * p.S * DH);
-    E4T_LOG_LAUNCH("attn_bwd_dkv_kernel<%d, %d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, dkv_occ, Bn, p.H, p.T, p.S, p.causal,
-                   2.0 * el * (2.0 * p.T + 4.0 * p.S) + 8.0 * Bn * p.H * p.T, 8.0 * Bn * p.H * (double)p.T * p.S * DH);
+    if (dkv64)
+      E4T_LOG_LAUNCH("attn_bwd_dkv64_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
+                     2.0 * el * (2.0 * p.T + 4.0 * p.S) + 8.0 * Bn * p.H * p.T, 8.0 * Bn * p.H * (double)p.T * p.S * DH);
+    else
+      E4T_LOG_LAUNCH("attn_bwd_dkv_kernel<%d, %d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, dkv_occ, Bn, p.H, p.T, p.S, p.causal,
+                     2.0 * el * (2.0 * p.T + 4.0 * p.S) + 8.0 * Bn * p.H * p.T, 8.0 * Bn * p.H * (double)p.T * p.S * DH);
   }
   // dQ first: its prologue also produces Delta (row_delta), which the dK/dV kernel behind it reads
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
   E4T_CHECK_LAUNCH("attn_bwd_dq_kernel");
   const dim3 gdkv(cdiv(p.S, 128) * p.tsplit, p.H, Bn);
+  if constexpr (DH == 40) {
+    if (dkv64) {
+      hipLaunchKernelGGL((attn_bwd_dkv64_kernel<DH>), dim3(cdiv(p.S, 256), p.H, Bn), dim3(256), 0, st, p);
+      E4T_CHECK_LAUNCH("attn_bwd_dkv64_kernel");
+      return 0;
+    }
+  }
   if constexpr (DH <= 64) {
     if (dkv_occ == 3) hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, 3>), gdkv, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<DH, DKV_WAVES>), gdkv, dim3(256), 0, st, p);

@@ -265,6 +265,9 @@ def check_attention(hip, emu, dev):
         # round 6: the 64-queries-per-wave forward (dh 40, S >= 512): last tile of 8 keys (its second sub-tile fully masked), of 33
         # keys, ragged T inside a 256-query block, exactly one tile pair
         (1, 2, 520, 520, 40), (2, 3, 700, 545, 40), (1, 1, 40, 512, 40), (2, 2, 256, 640, 40),
+        # ... and the 64-keys-per-wave dK/dV kernel + 64-queries-per-wave dQ kernel (dh 40, enough key blocks that the query range is
+        # not split): ragged T (last tile of 24 / 12 queries) and ragged S (last workgroup with 208 / 42 keys)
+        (4, 8, 600, 2000, 40), (2, 16, 1100, 2090, 40),
     ]
     for i, case in enumerate(cases):
         (B, H, T, S, DH), causal = case[:5], (len(case) > 5 and case[5])
