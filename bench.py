@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] block (tuning step, SD-2.x @768)")
+    ap.add_argument("--materialise-head-grad", action="store_true", help="A/B: write the E4T head's 845 MB stacked weight gradient (batched GEMM + plain AdamW) instead of the factored update")
     ap.add_argument("--head-allreduce", action="store_true", help="N > 1: all-reduce the E4T head's 845 MB stacked weight gradient instead of gathering its factors (A/B)")
     ap.add_argument("--step-graph", action="store_true", help="A/B: the whole step replayed from one HIP graph (no next-batch prefetch: the two exclude each other)")
     args = ap.parse_args()
@@ -199,6 +200,7 @@ def main():
     empty_ids = torch.tensor([[49406] + [49407] * 76], device=dev)
     tr = E4TTrainer(unet, enc, text, vae, lr=1e-6 * args.batch * world, class_token_id=1125, empty_prompt_ids=empty_ids, device=dev,
                     head_factor_exchange=not args.head_allreduce)
+    tr.factored_head_update = not args.materialise_head_grad
     if args.step_graph:
         tr.prefetch_mode = "0"
         assert tr.enable_step_graph(True)

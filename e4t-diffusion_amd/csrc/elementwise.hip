@@ -271,6 +271,79 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
   }
 }
 
+// ---- AdamW of the E4T head's stacked first_linears weights with the gradient formed IN REGISTERS (round 6) ----
+// The n = 129 weight gradients are rank-K products dW_i[r][c] = sum_k G[k][r] * Z[k][i*cols + c] (K = images of the step: the batch, or
+// under data parallelism every rank's rows gathered; encoder.py:159-162): 845 MB of fp32 that the step used to write (batched GEMM), read
+// back (AdamW) and clear (zero_grad).  Here a workgroup owns RB rows of one slot: a thread holds its 4 columns of the K x cols factor
+// slice (bf16 -> fp32 registers, re-read from L2 by the cols / RB workgroups of the slot), the RB x K factor block of G sits in LDS
+// and is read as broadcasts, and each element's gradient is a k-ordered fmaf chain in front of the same update arithmetic as
+// adamw_kernel: 24 B of HBM traffic per parameter instead of 36, ~2 K FMAs per element on a kernel that stays HBM-bound.
+template <int RB>
+__global__ __launch_bounds__(320) void adamw_rank_kernel(float* p, float* m, float* v, const bf16_t* G, const bf16_t* Z, int rows, int cols, int K,
+                                                         int ldg, long long ldz, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                         float bc2_sqrt, float gscale, const float* hyper) {
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; gscale = hyper[3]; }
+  __shared__ float gs[16 * RB];                      // G[k0 + k][r0 + rr] as fp32, [rr][k]
+  const int slot = blockIdx.y, r0 = blockIdx.x * RB;
+  const int Q = cols >> 2;
+  for (int q = threadIdx.x; q < (Q + (int)blockDim.x - 1) / (int)blockDim.x * (int)blockDim.x; q += blockDim.x) {      // (uniform trip count: barriers inside)
+    const bool on = q < Q;
+    float acc[RB][4];
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[rr][j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < 16 * RB; i += blockDim.x) {
+        const int rr = i >> 4, k = i & 15;
+        gs[i] = (k0 + k < K && r0 + rr < rows) ? bf2f(G[(long long)(k0 + k) * ldg + r0 + rr]) : 0.f;
+      }
+      float z[16][4];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        uint2 w = make_uint2(0u, 0u);
+        if (on && k0 + k < K) w = *(const uint2*)(Z + (long long)(k0 + k) * ldz + (long long)slot * cols + 4 * q);
+        unpack4(w, z[k]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const float4* g4 = (const float4*)(gs + rr * 16);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const float4 g = g4[kk];                   // broadcast read
+          const float gk[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[rr][j] = fmaf(gk[u], z[kk * 4 + u][j], acc[rr][j]);
+        }
+      }
+    }
+    if (!on) continue;
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) {
+      if (r0 + rr >= rows) continue;
+      const long long i = ((long long)slot * rows + r0 + rr) * cols + 4 * q;
+      float4 P = *(float4*)(p + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
+      float pp[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gg = acc[rr][j] * gscale;
+        pp[j] *= 1.f - lr * wd;
+        mm[j] = b1 * mm[j] + (1.f - b1) * gg;
+        vv[j] = b2 * vv[j] + (1.f - b2) * gg * gg;
+        const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+        pp[j] -= (lr / bc1) * mm[j] / denom;
+      }
+      *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+      *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+      *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+  }
+}
+
 // sum of squares of a flat fp32 buffer -> partial[blockIdx.x]
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long long n, float* partial) {
   __shared__ float red[16];
@@ -408,6 +481,23 @@ extern "C" int e4t_adamw_hyper(float* p, const float* g, float* m, float* v, lon
   E4T_LOG_LAUNCH("adamw_kernel|n%lld|%.0f|0", (long long)n, 28.0 * (double)n);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, 1.f, hyper_dev);
   E4T_CHECK_LAUNCH("adamw_kernel");
+  return 0;
+}
+extern "C" int e4t_adamw_rank(float* p, float* m, float* v, const void* G, const void* Z, int n, int rows, int cols, int K, int ldg, long long ldz,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, const float* hyper_dev,
+                              e4t_stream s) {
+  E4T_REQUIRE(p && m && v && G && Z && n > 0 && rows > 0 && cols > 0 && K > 0 && (hyper_dev || step >= 1), "adamw_rank: bad arguments");
+  E4T_REQUIRE(cols % 4 == 0 && ldz % 4 == 0 && ldg >= rows && ldz >= (long long)n * cols, "adamw_rank: cols and the Z row stride must be multiples of 4");
+  E4T_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)Z & 7) == 0 && ((uintptr_t)hyper_dev & 15) == 0,
+              "adamw_rank: buffers must be 16-B (factors 8-B) aligned");
+  const float bc1 = hyper_dev ? 1.f : 1.f - powf(beta1, (float)step), bc2 = hyper_dev ? 1.f : sqrtf(1.f - powf(beta2, (float)step));
+  constexpr int RB = 8;
+  const int threads = min(320, (cols / 4 + 63) / 64 * 64);
+  // algorithmic bytes: p, m, v read and written; the factors are L2 traffic
+  E4T_LOG_LAUNCH("adamw_rank_kernel<%d>|n%d rows%d cols%d K%d|%.0f|%.0f", RB, n, rows, cols, K, 24.0 * n * rows * cols, 2.0 * n * rows * (double)cols * K);
+  hipLaunchKernelGGL((adamw_rank_kernel<RB>), dim3(cdiv(rows, RB), n), dim3(threads), 0, (hipStream_t)s, p, m, v, (const bf16_t*)G, (const bf16_t*)Z, rows, cols, K,
+                     ldg, ldz, hyper_dev ? 0.f : lr, beta1, beta2, eps, weight_decay, bc1, bc2, hyper_dev ? 1.f : grad_scale, hyper_dev);
+  E4T_CHECK_LAUNCH("adamw_rank_kernel");
   return 0;
 }
 extern "C" int e4t_sumsq_partial(const float* g, long long n, float* partial, int nblocks, e4t_stream s) {

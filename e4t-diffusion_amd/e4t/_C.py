@@ -105,6 +105,7 @@ SIGNATURES = {
     "e4t_im2col": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "e4t_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "e4t_adamw_hyper": (i32, [vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, vp]),
+    "e4t_adamw_rank": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp]),
     "e4t_sumsq_partial": (i32, [vp, i64, vp, i32, vp]),
     "e4t_probe_mfma_layout": (i32, [vp, vp, vp]),
 }

@@ -197,7 +197,7 @@ class _HeadFn(torch.autograd.Function):
         gW, gB, gWf, gbf = enc._grad_storage()
         # (129 x [1280 x 1280] fp32 = 845 MB of gradient: the first write after the trainer zeroed it overwrites instead of accumulating —
         # half the traffic of this launch, 0.65 -> ~0.35 ms per step; a micro-batch accumulation step or plain autograd use accumulates)
-        fresh, enc._stack_grad_is_zero = getattr(enc, "_stack_grad_is_zero", False), False
+        fresh = getattr(enc, "_stack_grad_is_zero", False)
         # Data parallel: dW_i is a rank-B product of two SMALL factors (gb: B x w, z_i: B x w), so the sum over the ranks of the 845 MB
         # stack equals ONE product over all ranks' rows.  The trainer's exchange gathers the factors (5 MB per rank) instead of
         # all-reducing the stack; it answers None (local product, the stack goes through the all-reduce) outside a synchronising
@@ -208,10 +208,17 @@ class _HeadFn(torch.autograd.Function):
             got = ex(gbx, Zx)
             if got is not None:
                 gbx, Zx = got                                                                     # [world * B, w], [world * B, n * w]
-        bp = (gbx.shape[0] + 7) // 8 * 8
-        gbT = be.transpose(gbx, pad_to=bp)                                                        # [w, bp]
-        ZT = be.transpose(Zx, pad_to=bp)                                                          # [n*w, bp]
-        be.gemm(gbT.unsqueeze(0).expand(n, w, bp), ZT.view(n, w, bp), out=gW, accum=not fresh)
+        # Round 6: the stack's gradient need not exist at all.  A trainer that runs the optimiser right after this backward takes the two
+        # factors (take_head_factors) and its AdamW forms dW_i = gb^T z_i in registers (e4t_adamw_rank): no 845 MB write here, no read
+        # back, nothing to clear.  Declined (None hook / False) whenever the stack must exist: accumulated micro-batches, a gradient clip
+        # over the whole gradient, a stack that rides the all-reduce (local factors under data parallelism), plain autograd use.
+        take = enc.take_head_factors
+        if not (take is not None and fresh and (ex is None or gbx is not gb) and take(gbx, Zx)):
+            enc._stack_grad_is_zero = False
+            bp = (gbx.shape[0] + 7) // 8 * 8
+            gbT = be.transpose(gbx, pad_to=bp)                                                    # [w, bp]
+            ZT = be.transpose(Zx, pad_to=bp)                                                      # [n*w, bp]
+            be.gemm(gbT.unsqueeze(0).expand(n, w, bp), ZT.view(n, w, bp), out=gW, accum=not fresh)
         gB.add_(gs.sum(0)[None, :])
         # feature_linear: Z = hs W_fh^T + rowbias(c),  c = u W_fu^T + b_f
         dZ2 = dZ.view(B * n, w)
@@ -265,6 +272,7 @@ class E4TEncoder(nn.Module):
         self._gW = self._gB = None
         self.on_backward_done = None      # trainer hook: every encoder gradient is final (starts the head's all-reduce)
         self.exchange_head_factors = None     # trainer hook (data parallel): (gb, Z) -> every rank's rows of both, or None (_HeadFn.backward)
+        self.take_head_factors = None         # trainer hook: (gb, Z) -> True when its AdamW will form the stack's gradient from them (_HeadFn.backward)
 
     @property
     def dtype(self):

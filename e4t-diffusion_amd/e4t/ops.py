@@ -520,6 +520,17 @@ class HipBackend:
         self._timed("adamw", 0.0, lambda: _C.check(self.lib.e4t_adamw_hyper(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(hyper), beta1, beta2, eps, wd,
                                                                             _stream()), "e4t_adamw_hyper"), 28.0 * p.numel())
 
+    def adamw_rank(self, p, m, v, G, Z, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, hyper=None):
+        """AdamW of the stack p [n, rows, cols] (fp32, with its moments) under the never-materialised gradient
+        dW_i = grad_scale * G^T Z[:, i*cols:(i+1)*cols]   (G [K, rows], Z [K, n*cols], bf16).  hyper: device scalars as in adamw_hyper."""
+        n, rows, cols = p.shape
+        K = G.shape[0]
+        assert p.is_contiguous() and m.is_contiguous() and v.is_contiguous() and G.dtype == bf16 and Z.dtype == bf16
+        assert G.shape[1] == rows and Z.shape == (K, n * cols) and G.stride(1) == 1 and Z.stride(1) == 1
+        self._timed("adamw", 2.0 * p.numel() * K, lambda: _C.check(self.lib.e4t_adamw_rank(
+            _ptr(p), _ptr(m), _ptr(v), _ptr(G), _ptr(Z), n, rows, cols, K, G.stride(0), Z.stride(0), lr, beta1, beta2, eps, wd, int(step), grad_scale,
+            _ptr(hyper), _stream()), "e4t_adamw_rank"), 24.0 * p.numel())
+
     def im2col_T(self, x, B, Hin, Win, Hout, Wout, mode):
         """bf16 [B*Hin*Win, C] -> [9*C, ld] with ld = B*Hout*Wout rounded up to 8 (zero padded): B operand of the wgrad GEMM"""
         assert x.is_contiguous()

@@ -285,6 +285,15 @@ int e4t_adamw(float* p, const float* g, float* m, float* v, long long n, float l
  * refreshes the four floats before each replay; the arithmetic is that of e4t_adamw with the same values. */
 int e4t_adamw_hyper(float* p, const float* g, float* m, float* v, long long n, const float* hyper_dev, float beta1, float beta2, float eps,
                     float weight_decay, e4t_stream stream);
+/* AdamW (same arithmetic) of a stack of n [rows][cols] fp32 matrices whose gradient is the rank-K product
+ *   dW_i[r][c] = grad_scale * sum_k G[k][r] * Z[k][i*cols + c]        (bf16 factors, fp32 k-ordered fmaf chain)
+ * formed in registers and never written: the E4T head's 129 first_linears (encoder.py:108-123,159-162 — dW_i = g^T z_i over the step's
+ * images) under pretrain_e4t.py:387-392,652.  G: [K][ldg >= rows], Z: [K][ldz >= n*cols] (row-major bf16; under data parallelism every rank's
+ * gathered rows).  hyper_dev != NULL: {lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale} are read from device memory as in e4t_adamw_hyper
+ * (lr / step / grad_scale arguments ignored).  cols % 4 == 0; p, m, v 16-byte aligned. */
+int e4t_adamw_rank(float* p, float* m, float* v, const void* G, const void* Z, int n, int rows, int cols, int K, int ldg, long long ldz,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, const float* hyper_dev,
+                   e4t_stream stream);
 int e4t_sumsq_partial(const float* g, long long n, float* partial, int nblocks, e4t_stream stream);                      /* tuning_e4t.py:335 grad-norm */
 
 /* ---------------------------------------------------------------- probe (probe.hip) ---------- */

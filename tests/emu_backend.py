@@ -372,6 +372,18 @@ class EmuBackend:
         bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
         p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
 
+    def adamw_rank(self, p, m, v, G, Z, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, hyper=None):
+        n, rows, cols = p.shape
+        if hyper is not None:
+            lr, bc1, bc2s, grad_scale = (float(x) for x in hyper.tolist())
+        else:
+            bc1, bc2s = 1 - beta1 ** step, math.sqrt(1 - beta2 ** step)
+        g = torch.einsum("kr,knc->nrc", G.float(), Z.float().view(G.shape[0], n, cols)) * grad_scale
+        p.mul_(1 - lr * wd)
+        m.mul_(beta1).add_(g, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        p.addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr / bc1)
+
     def im2col_T(self, x, B, Hin, Win, Hout, Wout, mode):
         Cn = x.shape[1]
         xi = x.float().reshape(B, Hin, Win, Cn).permute(0, 3, 1, 2)

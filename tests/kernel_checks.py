@@ -448,6 +448,20 @@ def check_streaming(hip, emu, dev):
     emu.adamw(p2, gr, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3, 0.5)
     out += [("adamw p", rel(p, p2), TOLF), ("adamw m", rel(m, m2), TOLF), ("adamw v", rel(v, v2), TOLF)]
     out.append(("sumsq", rel(hip.sumsq(gr), emu.sumsq(gr)), 1e-4))
+    # AdamW of a weight stack under the never-materialised rank-K gradient G^T Z_i (round 6): K = 16 (one k chunk), 40 (three, ragged),
+    # rows not a multiple of the row block, columns that are / are not a multiple of the 64-lane quad count, device-resident scalars
+    for i, (n, rows, cols, K) in enumerate(((5, 64, 128, 16), (3, 100, 320, 40), (2, 1280, 1280, 16), (4, 24, 72, 3))):
+        gg = gen(470 + i, dev)
+        P = rnd(gg, n, rows, cols, dtype=f32, dev=dev)
+        M = rnd(gg, n, rows, cols, dtype=f32, dev=dev) * 0.1
+        Vv = rnd(gg, n, rows, cols, dtype=f32, dev=dev).abs() * 0.01
+        Gf, Zf = rnd(gg, K, rows, dev=dev), rnd(gg, K, n * cols, dev=dev)
+        P2, M2, V2 = P.clone(), M.clone(), Vv.clone()
+        hyper = torch.tensor([2e-3, 1 - 0.9 ** 4, (1 - 0.999 ** 4) ** 0.5, 0.25], dtype=f32, device=dev) if i == 1 else None
+        hip.adamw_rank(P, M, Vv, Gf, Zf, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3, 0.5, hyper=hyper)
+        emu.adamw_rank(P2, M2, V2, Gf, Zf, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3, 0.5, hyper=hyper)
+        tag = f"adamw_rank n{n} {rows}x{cols} K{K}" + (" hyper" if hyper is not None else "")
+        out += [(tag + " p", rel(P, P2), TOLF), (tag + " m", rel(M, M2), TOLF), (tag + " v", rel(Vv, V2), TOLF)]
     for mode, (Bn, Hin, Hout) in ((1, (2, 12, 12)), (2, (3, 9, 5)), (3, (2, 6, 12))):
         xi = rnd(g, Bn * Hin * Hin, 72, dev=dev)
         out.append((f"im2col_T mode{mode}", rel(hip.im2col_T(xi, Bn, Hin, Hin, Hout, Hout, mode), emu.im2col_T(xi, Bn, Hin, Hin, Hout, Hout, mode)), 0.0))

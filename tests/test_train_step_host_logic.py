@@ -221,6 +221,50 @@ def test_adamw_in_two_parts_around_a_deferred_region_changes_no_bit(emu_fp32):
     assert float((res[0][1] != 0).float().mean()) > 0.5         # (the gradients were there)
 
 
+def test_head_stack_update_from_factors_equals_the_materialised_gradient(emu_fp32):
+    """Round 6: a synchronising step hands the two factors of the head's stacked weight gradient (dW_i = gb^T z_i) to AdamW
+    (e4t_adamw_rank) and never writes the stack.  Same parameters / moments as the materialised path (a different summation order
+    only), the stack region of the flat gradient stays zero and is not cleared, and whatever needs the stack declines the factors:
+    accumulated micro-batches, a gradient clip."""
+    batches = [_data(2, 41), _data(2, 42)]
+    res, took = [], []
+    for factored in (True, False):
+        tr, _ = _trainer()
+        tr.factored_head_update = factored
+        n, rows, cols = tr._stack_shape
+        w_end = n * rows * cols
+        seen = []
+        orig = tr._take_head_factors
+        tr.encoder.take_head_factors = lambda gb, Z, orig=orig, seen=seen: (seen.append(orig(gb, Z)), seen[-1])[1]
+        for d in batches:
+            _step(tr, d)
+            assert float(tr.flat.grad.abs().sum()) == 0 and tr.encoder._stack_grad_is_zero and tr._head_factors is None
+        took.append(seen)
+        res.append((tr.flat.data.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), w_end))
+    assert took == [[True, True], [False, False]]
+    w_end = res[0][3]
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(a[w_end:], b[w_end:])                    # everything behind the stack: the same launches
+        torch.testing.assert_close(a[:w_end], b[:w_end], rtol=2e-4, atol=2e-6)
+    assert float((res[0][1][:w_end] != 0).float().mean()) > 0.5     # (the stack did get gradients)
+
+    # a micro-batch that only accumulates writes the stack; the synchronising step behind it must not take factors
+    tr, _ = _trainer()
+    ref, _ = _trainer()
+    ref.factored_head_update = False
+    for t in (tr, ref):
+        _step(t, batches[0], sync=False, loss_scale=0.5)
+        assert t._accum_pending and not t.encoder._stack_grad_is_zero
+        _step(t, batches[1], sync=True, loss_scale=0.5)
+        assert not t._accum_pending and t.encoder._stack_grad_is_zero and float(t.flat.grad.abs().sum()) == 0
+    assert torch.equal(tr.flat.data, ref.flat.data) and torch.equal(tr.exp_avg, ref.exp_avg)
+
+    # with a gradient clip the norm is taken over the materialised gradient
+    tr, _ = _trainer()
+    tr.max_grad_norm = 1.0
+    assert tr._take_head_factors(None, None) is False
+
+
 def test_training_state_round_trip_resumes_bitwise(emu_fp32, tmp_path):
     batches = [_data(2, 31 + i) for i in range(3)]
     tr, _ = _trainer()
