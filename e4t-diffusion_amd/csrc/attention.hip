@@ -555,6 +555,61 @@ __device__ __forceinline__ f32x2 pk_fms(f32x2 s, f32x2 sc, f32x2 mm) {
   return d;
 }
 
+// ---- compact LDS image for head dims <= 56 (round 6): [64 rows][8 slots of 16 B] = 128-byte rows, filled by LDS-DMA ----
+// slot L of row r lives at physical slot ((L>>2) ^ ((r>>1)&1)) << 2 | ((L&3) ^ ((r>>2)&3)) (an involution in L).  ds_read_b128 row
+// fragments (16 lanes of distinct r mod 16, one L): bank slot 8 (r&1) + 4 (q ^ (r>>1&1)) + (j ^ (r>>2&3)) takes 16 distinct values;
+// the transposing 4-row x 64-byte gathers (rows r0..r0+3, r0 % 4 == 0, one aligned block of 4 slots) hit the 4 bank quarters
+// 2 (r&1) + (q ^ (r>>1&1)) once each.  One buffer_load ... lds instruction writes 1 KB = 8 image rows linearly (lane l -> row l >> 3,
+// physical slot l & 7), so the swizzle is applied on the SOURCE side: each lane fetches the logical slot its physical slot holds;
+// lanes of the pad / unused slots (L >= DH / 8) fetch out of range = zeros.
+__device__ __forceinline__ int img64_slot(int r, int L) { return ((((L >> 2) ^ ((r >> 1) & 1)) << 2) | ((L & 3) ^ ((r >> 2) & 3))); }
+__device__ __forceinline__ int img64_off(int r, int L) { return r * 64 + img64_slot(r, L) * 8; }      // elements
+template <int DH>
+struct FragOff64 {
+  using C = Cfg<DH>;
+  static_assert(C::DV <= 64, "128-byte image rows hold 64 columns");
+  int row[C::NKS], tr_lo[C::NDT], tr_hi[C::NDT];
+  __device__ __forceinline__ FragOff64() {
+    const int lane = threadIdx.x & 63, li = lane & 31, hi = lane >> 5, il = lane & 15, d16 = (lane >> 4) & 1;
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) row[ks] = img64_off(li, ks * 2 + hi);
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) {
+      const int L = dt * 4 + 2 * d16 + ((il & 3) >> 1), r = 4 * hi + (il >> 2);
+      tr_lo[dt] = img64_off(r, L) + 4 * (il & 1);
+      tr_hi[dt] = img64_off(r + 8, L) + 4 * (il & 1);
+    }
+  }
+};
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, bf16_t* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// this wave's share (two of the eight 1-KB pieces) of a 64-row tile image; the row offset lives in the bounds-checked lane offset
+template <int DH>
+struct TileDma {
+  unsigned vo[2], step[2];
+  __device__ __forceinline__ void init(int ld) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 8 * (2 * wave + i) + (lane >> 3), L = img64_slot(r, lane & 7);
+      const bool on = L < Cfg<DH>::NCH;
+      vo[i] = on ? (unsigned)((r * ld + L * 8) * 2) : 0x80000000u;
+      step[i] = on ? (unsigned)(64 * ld * 2) : 0u;
+    }
+  }
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, bf16_t* img) {      // the next tile -> img
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      dma16(rs, vo[i], img + (2 * wave + i) * 512);
+      vo[i] += step[i];
+    }
+  }
+};
+
 // key-validity column of a K image: pad slot (d = DH .. DH + 7) of row r = {valid ? 0 : -29952, 0, ...}; four threads per row
 // write the same value (no divergent branch inside a phase)
 template <int DH>
@@ -565,18 +620,22 @@ __device__ __forceinline__ void write_key_mask(bf16_t* kimg, int row0, int S) {
 
 // One phase (see above).  x = the block whose scores sx become P (px); y = the other block: its pending P.V and its next scores.
 //   LOADS: Y phase — reload the V^T fragments from lds + VOFF after the P.V MFMAs and the K fragments from lds + KOFF after the
-//          score MFMAs (BAR: the tile barrier in front of the K reload);  STAGE >= 0: X phase that writes the staged registers
-//          into the images at lds + STAGE (K) / + STAGE + TILE (V) and issues the next tile's global loads.
-template <int DH, bool LOADS, int VOFF, int KOFF, bool BAR, int STAGE>
-__device__ __forceinline__ void fwd64_phase(const float scale2, const FragOff<DH>& fo, bf16_t* lds,
+//          score MFMAs.  PADS >= 0 (odd Y phase): in front of the K reload, the tile barrier — this wave's DMA pieces of the NEXT tile
+//          (issued THREE tiles earlier into the images at lds + PADS / + PADS + IMG) have landed (counted vmcnt: the 8 pieces of the two
+//          tiles behind it stay in flight), its pad slots are written (key validity column of K, ones column of V: the DMA zero-fills
+//          them), then s_barrier.
+//   STAGE >= 0: X phase that issues the DMA of the tile FOUR ahead into this tile's own images at lds + STAGE / + STAGE + IMG (nobody
+//          reads them any more: the barrier of the preceding Y phase).  Four tile buffers: a tile period is ~1 us, about the latency of
+//          an LDS-DMA piece under load — with two buffers (one tile of lead) the wait in front of the barrier cost ~90 us per launch.
+template <int DH, bool LOADS, int VOFF, int KOFF, int PADS, int STAGE>
+__device__ __forceinline__ void fwd64_phase(const f32x2 sc, const FragOff64<DH>& fo, bf16_t* lds,
                                             const f32x16& sx, f32x2& mm, Frag (&px)[2], f32x16 (&ox)[Cfg<DH>::NDT],
                                             f32x16& sy, const Frag (&py)[2], f32x16 (&oy)[Cfg<DH>::NDT], const bf16x8 (&qfy)[Cfg<DH>::NKS],
                                             bf16x8 (&vfr)[Cfg<DH>::NDT][2], bf16x8 (&kfr)[Cfg<DH>::NKS],
-                                            TileRegsV<DH>& kr, TileRegsV<DH>& vr, const __amdgpu_buffer_rsrc_t rsK,
-                                            const __amdgpu_buffer_rsrc_t rsV, const int stage_row0, const int S) {
+                                            TileDma<DH>& kd, TileDma<DH>& vd, const __amdgpu_buffer_rsrc_t rsK,
+                                            const __amdgpu_buffer_rsrc_t rsV, const int pad_row0, const int S) {
   using C = Cfg<DH>;
-  constexpr int NPV = 2 * C::NDT, NM = NPV + C::NKS, TILE = 64 * C::LDE;
-  const f32x2 sc = {scale2, scale2};
+  constexpr int NPV = 2 * C::NDT, NM = NPV + C::NKS, IMG = 64 * 64;
   f32x2 t = pk_fms(f32x2{sx[0], sx[1]}, sc, mm);   // the exp argument of chunk c is formed in chunk c - 1 (no dependent back-to-back VALU)
   float pe0 = 0.f, pe1 = 0.f;
 #pragma unroll
@@ -594,22 +653,28 @@ __device__ __forceinline__ void fwd64_phase(const float scale2, const FragOff<DH
         sy = a64_mfma(kfr[ks], qfy[ks], ks == 0 ? z : sy);
       }
       A64_FENCE();
-      if (LOADS && i == NPV - 1 && ATTN64_PROBE != 4 && ATTN64_PROBE != 7 && ATTN64_PROBE != 8) {                 // every V^T fragment has been consumed: fetch the next sub-tile's
+      if (LOADS && i == NPV - 1 && ATTN64_PROBE != 4 && ATTN64_PROBE != 7 && ATTN64_PROBE != 8) {      // every V^T fragment has been consumed: fetch the next sub-tile's
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
           for (int dt = 0; dt < C::NDT; ++dt) {
-            const bf16_t* vb = lds + VOFF + k2 * 16 * C::LDE;
+            const bf16_t* vb = lds + VOFF + k2 * 16 * 64;
             vfr[dt][k2] = tr_frag(vb + fo.tr_lo[dt], vb + fo.tr_hi[dt]);
           }
         A64_FENCE();
       }
-      if (LOADS && i == NM - 1 && BAR && ATTN64_PROBE != 6 && ATTN64_PROBE != 7) __syncthreads();
+      if (LOADS && i == NM - 1 && PADS >= 0 && ATTN64_PROBE != 6 && ATTN64_PROBE != 7) {
+        attn_wait_vmcnt<8>();                       // this wave's 4 pieces of the next tile have landed; the two tiles behind it stay in flight
+        const int r = threadIdx.x & 63;
+        *(uint4*)(lds + PADS + img64_off(r, C::NCH)) = make_uint4(pad_row0 + r < S ? 0u : 0xC6EAu, 0u, 0u, 0u);
+        *(uint4*)(lds + PADS + IMG + img64_off(r, C::NCH)) = make_uint4(0x3F80u, 0u, 0u, 0u);
+        __syncthreads();                           // the next tile's images are complete; nobody reads the old tile any more
+      }
       if (LOADS && i == NM - 1 && (ATTN64_PROBE == 4 || ATTN64_PROBE == 7 || ATTN64_PROBE == 9)) {      // (opaque: the score MFMAs must not become loop-invariant)
 #pragma unroll
         for (int ks = 0; ks < C::NKS; ++ks) asm volatile("" : "+v"(kfr[ks]));
       }
-      if (LOADS && i == NM - 1 && ATTN64_PROBE != 4 && ATTN64_PROBE != 7 && ATTN64_PROBE != 9) {                  // the next tile's image is complete; nobody reads the old tile any more
+      if (LOADS && i == NM - 1 && ATTN64_PROBE != 4 && ATTN64_PROBE != 7 && ATTN64_PROBE != 9) {
 #pragma unroll
         for (int ks = 0; ks < C::NKS; ++ks) kfr[ks] = *(const bf16x8*)(lds + KOFF + fo.row[ks]);
         A64_FENCE();
@@ -625,10 +690,8 @@ __device__ __forceinline__ void fwd64_phase(const float scale2, const FragOff<DH
     }
     A64_FENCE();
     if (STAGE >= 0 && ATTN64_PROBE != 5 && ATTN64_PROBE != 7) {
-      if (c == 0) { kr.store_rows(lds + STAGE); write_key_mask<DH>(lds + STAGE, stage_row0, S); A64_FENCE(); }
-      if (c == 1) { vr.store_rows(lds + STAGE + TILE); A64_FENCE(); }
-      if (c == 2) { kr.load(rsK); A64_FENCE(); }
-      if (c == 3) { vr.load(rsV); A64_FENCE(); }
+      if (c == 0) { kd.issue(rsK, lds + STAGE); A64_FENCE(); }
+      if (c == 1) { vd.issue(rsV, lds + STAGE + IMG); A64_FENCE(); }
     }
   }
   if (ATTN64_PROBE != 2 && ATTN64_PROBE != 7) px[1].w[3] = pack2bf(pe0, pe1);
@@ -637,7 +700,7 @@ __device__ __forceinline__ void fwd64_phase(const float scale2, const FragOff<DH
     float mv = sx[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mv = fmaxf(mv, sx[r]);
-    mv = xhalf_max(mv) * scale2;                   // scale2 > 0
+    mv = xhalf_max(mv) * sc.x;                     // scale2 > 0
     const float mn = fmaxf(mm.x, mv);
     const float alpha = fast_exp2(mm.x - mn);
     mm = f32x2{mn, mn};
@@ -656,10 +719,10 @@ __device__ __forceinline__ void fwd64_phase(const float scale2, const FragOff<DH
 template <int DH>
 __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArgs p) {
   using C = Cfg<DH>;
-  static_assert(DH % 16 == 8 && C::DV > DH, "needs a spare contraction slot (key mask) and a spare O^T row (row sum)");
-  constexpr int TILE = 64 * C::LDE;
-  __shared__ __attribute__((aligned(16))) bf16_t lds[4 * TILE];       // [K image 0][V image 0][K image 1][V image 1]
-  const FragOff<DH> fo;
+  static_assert(DH % 16 == 8 && C::DV > DH && C::DV <= 64, "needs a spare contraction slot (key mask), a spare O^T row (row sum), 128-byte image rows");
+  constexpr int IMG = 64 * 64, TILE = 2 * IMG;     // one image = 64 rows x 128 bytes; a tile = K image + V image
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[4 * TILE];      // four tile buffers of [K image][V image]: 64 KB
+  const FragOff64<DH> fo;
   const Blk blk = xcd_block(p.xcd_raster);
   const int b = blk.b, h = blk.h;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -668,6 +731,14 @@ __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArg
   const bf16_t* Qb = p.Q + b * p.bq + h * DH;
   const bf16_t* Kb = p.K + b * p.bk + h * DH;
   const bf16_t* Vb = p.V + b * p.bv + h * DH;
+  const f32x2 sc = {p.scale2, p.scale2};
+
+  TileDma<DH> kd, vd;
+  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(Kb, (unsigned)(((long long)(p.S - 1) * p.ldk + DH) * 2));
+  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(Vb, (unsigned)(((long long)(p.S - 1) * p.ldv + DH) * 2));
+  kd.init(p.ldk); vd.init(p.ldv);
+#pragma unroll
+  for (int tb = 0; tb < 4; ++tb) { kd.issue(rsK, lds + tb * TILE); vd.issue(rsV, lds + tb * TILE + IMG); }      // tiles 0..3
 
   bf16x8 qf[2][C::NKS];
   load_row_frags<DH>(Qb, p.ldq, q0, p.T, hi, qf[0]);
@@ -677,22 +748,6 @@ __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArg
     t.q = make_uint4(0x3F80u, 0u, 0u, 0u);
     qf[0][DH / 16] = t.v; qf[1][DH / 16] = t.v;
   }
-
-  TileRegsV<DH> kr, vr;
-  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(Kb, (unsigned)(((long long)(p.S - 1) * p.ldk + DH) * 2));
-  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(Vb, (unsigned)(((long long)(p.S - 1) * p.ldv + DH) * 2));
-  kr.init(p.ldk); vr.init(p.ldv);
-  kr.load(rsK); vr.load(rsV);                      // tile 0
-  if (threadIdx.x < 128) {                         // V images: element d = DH of every key row = 1.0, the rest of that slot 0; never overwritten
-    bf16_t* vimg = lds + ((threadIdx.x >> 6) * 2 + 1) * TILE;
-    *(uint4*)(vimg + img_off<C::LDE>(threadIdx.x & 63, C::NCH)) = make_uint4(0x3F80u, 0u, 0u, 0u);
-  }
-  write_key_mask<DH>(lds, 0, p.S);
-  write_key_mask<DH>(lds + 2 * TILE, 64, p.S);
-  kr.store_rows(lds); vr.store_rows(lds + TILE);
-  kr.load(rsK); vr.load(rsV);                      // tile 1
-  kr.store_rows(lds + 2 * TILE); vr.store_rows(lds + 3 * TILE);
-  kr.load(rsK); vr.load(rsV);                      // tile 2 waits in registers for the first odd X phase
 
   f32x16 oa[C::NDT], ob[C::NDT], sa, sb;
   Frag pa[2], pb[2];
@@ -709,6 +764,12 @@ __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArg
     for (int dt = 0; dt < C::NDT; ++dt) { vfr[dt][0] = z.v; vfr[dt][1] = z.v; }
   }
   f32x2 ma = {-1e30f, -1e30f}, mb = ma;      // running row max (log2 units), duplicated for the packed fma
+  attn_wait_vmcnt<0>();                           // (one-off; also covers the Q fragments)
+  {
+    const int r = threadIdx.x & 63;                // tile 0's pad slots (every later tile gets its own at its publishing barrier)
+    *(uint4*)(lds + img64_off(r, C::NCH)) = make_uint4(r < p.S ? 0u : 0xC6EAu, 0u, 0u, 0u);
+    *(uint4*)(lds + IMG + img64_off(r, C::NCH)) = make_uint4(0x3F80u, 0u, 0u, 0u);
+  }
   __syncthreads();
 #pragma unroll
   for (int ks = 0; ks < C::NKS; ++ks) kfr[ks] = *(const bf16x8*)(lds + fo.row[ks]);
@@ -721,16 +782,19 @@ __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArg
   // one 64-key tile in buffer TB: sub-tiles 2t, 2t + 1 (a ragged last tile is processed whole: its absent keys are masked)
   auto tile = [&](auto tb_, int t) __attribute__((always_inline)) {
     constexpr int TB = decltype(tb_)::value;
-    constexpr int KI = TB * 2 * TILE, VI = KI + TILE, KN = (1 - TB) * 2 * TILE;
-    fwd64_phase<DH, true, VI, KI + 32 * C::LDE, false, -1>(p.scale2, fo, lds, sa, ma, pa, oa, sb, pb, ob, qf[1], vfr, kfr, kr, vr, rsK, rsV, 0, p.S);
-    fwd64_phase<DH, false, 0, 0, false, -1>(p.scale2, fo, lds, sb, mb, pb, ob, sa, pa, oa, qf[0], vfr, kfr, kr, vr, rsK, rsV, 0, p.S);
-    fwd64_phase<DH, true, VI + 32 * C::LDE, KN, true, -1>(p.scale2, fo, lds, sa, ma, pa, oa, sb, pb, ob, qf[1], vfr, kfr, kr, vr, rsK, rsV, 0, p.S);
-    fwd64_phase<DH, false, 0, 0, false, KI>(p.scale2, fo, lds, sb, mb, pb, ob, sa, pa, oa, qf[0], vfr, kfr, kr, vr, rsK, rsV, (t + 2) * 64, p.S);
+    constexpr int KI = TB * TILE, VI = KI + IMG, KN = ((TB + 1) & 3) * TILE;
+    fwd64_phase<DH, true, VI, KI + 32 * 64, -1, -1>(sc, fo, lds, sa, ma, pa, oa, sb, pb, ob, qf[1], vfr, kfr, kd, vd, rsK, rsV, 0, p.S);
+    fwd64_phase<DH, false, 0, 0, -1, -1>(sc, fo, lds, sb, mb, pb, ob, sa, pa, oa, qf[0], vfr, kfr, kd, vd, rsK, rsV, 0, p.S);
+    fwd64_phase<DH, true, VI + 32 * 64, KN, KN, -1>(sc, fo, lds, sa, ma, pa, oa, sb, pb, ob, qf[1], vfr, kfr, kd, vd, rsK, rsV, (t + 1) * 64, p.S);
+    fwd64_phase<DH, false, 0, 0, -1, KI>(sc, fo, lds, sb, mb, pb, ob, sa, pa, oa, qf[0], vfr, kfr, kd, vd, rsK, rsV, 0, p.S);
   };
-  for (int t = 0; t < ntiles; t += 2) {
+  for (int t = 0; t < ntiles; t += 4) {
     tile(std::integral_constant<int, 0>{}, t);
     if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < ntiles) tile(std::integral_constant<int, 2>{}, t + 2);
+    if (t + 3 < ntiles) tile(std::integral_constant<int, 3>{}, t + 3);
   }
+  attn_wait_vmcnt<0>();                           // (DMA pieces of tiles beyond the end — zeros — must not outlive the workgroup's LDS)
 #pragma unroll
   for (int k2 = 0; k2 < 2; ++k2)                   // the last sub-tile's P.V of block b
 #pragma unroll
