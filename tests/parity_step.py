@@ -525,6 +525,11 @@ def run(case_name, dev, verbose=True):
     return rep
 
 
+# bounds of batch_consistency() on the E4T head's gradients (per tensor / pooled), with the LeakyReLU branches of the two native
+# realisations aligned (round 6; 0.5 / 0.25 before, when every kink flip was inside the bound)
+HEAD_GRAD_BOUND, HEAD_POOLED_BOUND = 2e-2, 1e-2          # measured on MI355X with aligned branches: 1.6e-3 / 3.2e-3 per tensor, 1.1e-3 / 2.5e-3 pooled (full_sd14 / tuning_full, B = 16)
+
+
 def batch_consistency(case_name, dev, B=16, verbose=True):
     """The native step at batch B against the SAME native step evaluated one sample at a time.
 
@@ -535,8 +540,9 @@ def batch_consistency(case_name, dev, B=16, verbose=True):
     loss_diff_i / B + loss_reg_i  (= the B-step's loss, pretrain_e4t.py:645-647).  Both sides are bf16 realisations of the same
     arithmetic, so the bounds are absolute: a mis-indexed tile or a wrong split-K reduction is an O(1) error.  (Forward bound 3e-2:
     the deepest encoder map is 1.4e-2 from the ORACLE in either realisation, measured 1.6e-2 between the two; UNet gradients pooled 1.2e-3.)
-    The E4T head's gradients see the LeakyReLU kink lottery between the two realisations (module docstring) and get a loose bound;
-    UNet-side gradients do not pass through the head's backward and get the tight one."""
+    The E4T head's two LeakyReLU kinks are ALIGNED between the two realisations (leg(follow=...)), so its gradients carry the same
+    bounds as the UNet-side ones (round 6; before, un-aligned, they were allowed 0.5 per tensor / 0.25 pooled — a wrong batched head
+    GEMM would have passed)."""
     import dataclasses
     from e4t import functional as Fn
     from e4t.trainer import E4TTrainer
@@ -549,9 +555,22 @@ def batch_consistency(case_name, dev, B=16, verbose=True):
     tr = E4TTrainer(n["unet"], n["enc"], n["text"], vae=n["vae"], lr=ADAM["lr"], reg_lambda=case.reg_lambda, prediction_type=case.prediction_type,
                     class_token_id=case.class_id, empty_prompt_ids=mv(d["empty_ids"]), device=dev, tuning=case.tuning)
 
-    def leg(sl, weight_diff):
-        """forward + backward of the samples `sl`; returns per-sample forward quantities; gradients ACCUMULATE in tr.flat.grad"""
+    real_lrelu = Fn.leaky_relu
+
+    def leg(sl, weight_diff, follow=None):
+        """forward + backward of the samples `sl`; returns per-sample forward quantities; gradients ACCUMULATE in tr.flat.grad.
+        follow = None: the head's two LeakyReLU inputs are recorded (out["_kinks"]); follow = recorded inputs of the SAME samples from
+        the other realisation: every element takes the branch the other realisation took (an input element near zero lands on either
+        side of the kink depending on the kernel instantiation — the module docstring's lottery; round 6: aligned here as compare()
+        aligns the oracle, which is what lets the head's gradients carry the same bound as everything else).  A branch that differs at
+        an input that is NOT tiny is a forward error and shows in e_hat."""
         out = {}
+        seen = []
+        if follow is None:
+            Fn.leaky_relu = lambda x: (seen.append(x.detach().clone()), real_lrelu(x))[1]
+        else:
+            it = iter(follow)
+            Fn.leaky_relu = lambda x: torch.where(next(it).to(x.device) > 0, x, 0.01 * x)
         nb = sl.stop - sl.start
         with torch.no_grad():
             if case.with_vae:
@@ -565,8 +584,12 @@ def batch_consistency(case_name, dev, B=16, verbose=True):
                 out[f"enc_map_{i:02d}"] = m.float().reshape(nb, -1).cpu()
         got = {}
         hook = n["enc"].register_forward_hook(lambda m, a, y: got.__setitem__("y", y.detach().float().cpu()))
-        loss, ld, lr_ = tr.losses(mv(d["pixels"][sl]), latents, mv(d["noise"][sl]), mv(d["t"][sl]), mv(d["ids"][sl]), mv(d["pidx"][sl]))
+        try:
+            loss, ld, lr_ = tr.losses(mv(d["pixels"][sl]), latents, mv(d["noise"][sl]), mv(d["t"][sl]), mv(d["ids"][sl]), mv(d["pidx"][sl]))
+        finally:
+            Fn.leaky_relu = real_lrelu
         hook.remove()
+        out["_kinks"] = seen
         out["e_hat"] = got["y"]
         out["loss_diff"], out["loss_reg"] = float(ld.detach()), float(lr_.detach())
         Fn.set_inplace_param_grads(True)
@@ -580,10 +603,13 @@ def batch_consistency(case_name, dev, B=16, verbose=True):
     full = leg(slice(0, B), 1.0)
     g_full = tr.flat.grad.clone()
     tr.zero_grad()
-    singles = [leg(slice(i, i + 1), 1.0 / B) for i in range(B)]
+    assert len(full["_kinks"]) == 2, len(full["_kinks"])
+    singles = [leg(slice(i, i + 1), 1.0 / B, follow=[k[i:i + 1] for k in full["_kinks"]]) for i in range(B)]
     g_sum = tr.flat.grad.clone()
     tr.zero_grad()
     rows = []
+    # how many kink inputs of the full-batch leg sit within 1e-2 of the median magnitude (the elements whose branch is a coin toss)
+    kink_near = [int((k.float().abs() < 1e-2 * k.float().abs().median()).sum()) for k in full["_kinks"]]
     for k in [k for k in full if k.startswith(("latents", "enc_map", "e_hat"))]:
         per = torch.cat([s_[k].reshape(1, -1) for s_ in singles], 0)
         rows.append((k, rel(full[k].reshape(B, -1), per)))
@@ -599,7 +625,7 @@ def batch_consistency(case_name, dev, B=16, verbose=True):
     pooled = {part: rel(torch.cat([tr.flat.view(i, g_full).reshape(-1) for i, p in enumerate(tr.flat.params) if names[id(p)].startswith(part)]),
                         torch.cat([tr.flat.view(i, g_sum).reshape(-1) for i, p in enumerate(tr.flat.params) if names[id(p)].startswith(part)]))
               for part in ("unet.", "e4t_encoder.")}
-    BOUND = dict(forward=3e-2, loss=2e-3, unet_grad=6e-2, unet_pooled=2e-2, head_grad=0.5, head_pooled=0.25)
+    BOUND = dict(forward=3e-2, loss=2e-3, unet_grad=6e-2, unet_pooled=2e-2, head_grad=HEAD_GRAD_BOUND, head_pooled=HEAD_POOLED_BOUND)
     bad = [(k, e) for k, e in rows if e > (BOUND["loss"] if k.startswith("loss") else BOUND["forward"])]
     bad += [(k, e) for k, e in grads if e > (BOUND["unet_grad"] if k.startswith("grad/unet.") else BOUND["head_grad"])]
     if pooled["unet."] > BOUND["unet_pooled"]:
@@ -609,7 +635,8 @@ def batch_consistency(case_name, dev, B=16, verbose=True):
     worst = lambda rs: dict(zip(("name", "rel_l2"), max(rs, key=lambda r: r[1])))
     rep = dict(case=case_name, B=B, bounds=BOUND, n_quantities=len(rows) + len(grads) + 2, n_bad=len(bad), bad=[dict(name=k, rel_l2=e) for k, e in bad[:16]],
                forward_worst=worst(rows), unet_grad_worst=worst([g for g in grads if g[0].startswith("grad/unet.")]),
-               head_grad_worst=worst([g for g in grads if g[0].startswith("grad/e4t_encoder.")]), pooled_grad_rel_l2=pooled)
+               head_grad_worst=worst([g for g in grads if g[0].startswith("grad/e4t_encoder.")]), pooled_grad_rel_l2=pooled,
+               kink_inputs_within_1pct_of_median=kink_near, kink_branches="single-sample legs follow the batch leg")
     if verbose:
         print(f"  batch-consistency[{case_name}, B={B}] forward worst {rep['forward_worst']}; unet grads worst {rep['unet_grad_worst']}, pooled {pooled['unet.']:.2e}; "
               f"head grads worst {rep['head_grad_worst']}, pooled {pooled['e4t_encoder.']:.2e}; bad {len(bad)}")

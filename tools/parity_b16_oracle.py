@@ -59,7 +59,8 @@ def main():
         ref_cal = ps.oracle_leg(case, o, d, follow_kinks=cal["_kinks"])
         sec["oracle_fp32_cpu_aligned_to_autocast"] = time.perf_counter() - t
     rep = ps.compare(case, nat, ref_nat, [(cal, ref_cal)], verbose=True, strict=False)
-    rep.update(batch=args.batch, seconds=sec, cpu_legs=1 if args.one_cpu_leg else 2, threads=torch.get_num_threads())
+    rep.update(batch=args.batch, seconds=sec, cpu_legs=1 if args.one_cpu_leg else 2, threads=torch.get_num_threads(),
+               commit=os.environ.get("E4T_COMMIT", "unknown (set E4T_COMMIT: the GPU box has no .git)"), kink_sigma=ps.KINK_SIGMA)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as fh:
         json.dump(rep, fh, indent=1)
