@@ -212,6 +212,8 @@ class _HeadFn(torch.autograd.Function):
         # factors (take_head_factors) and its AdamW forms dW_i = gb^T z_i in registers (e4t_adamw_rank): no 845 MB write here, no read
         # back, nothing to clear.  Declined (None hook / False) whenever the stack must exist: accumulated micro-batches, a gradient clip
         # over the whole gradient, a stack that rides the all-reduce (local factors under data parallelism), plain autograd use.
+        if fresh and getattr(enc, "debug_check_stack", False):      # the overwrite-on-first-write contract (trainer.zero_grad's invariant)
+            assert float(gW.abs().max()) == 0.0, "first_linears gradient stack was written behind zero_grad's back"
         take = enc.take_head_factors
         if not (take is not None and fresh and (ex is None or gbx is not gb) and take(gbx, Zx)):
             enc._stack_grad_is_zero = False

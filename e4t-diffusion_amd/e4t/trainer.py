@@ -73,6 +73,13 @@ class FlatParams:
         return buf[o:o + p.numel()].view(p.shape)
 
 
+class _AlwaysFalse(dict):
+    """_exchange_ok after a ragged batch was seen: every batch size answers False without another collective"""
+
+    def get(self, key, default=None):
+        return False
+
+
 def _runs_beside(main, side, device) -> bool:
     """does a kernel launched on `side` execute while `main` is busy?  (False: the two streams share a hardware queue)"""
     x = torch.zeros(64, device=device)
@@ -160,6 +167,7 @@ class E4TTrainer:
         # factors to AdamW (e4t_adamw_rank) instead of writing, reading and clearing the stack.  Off with a gradient clip (the norm is
         # taken over the materialised gradient) and while micro-batches accumulate.
         self.factored_head_update = True
+        self._exchange_ok = {}               # per-rank batch size -> every rank has it (checked with one collective at first use)
         self._head_factors = None
         self._accum_pending = False          # a non-synchronising step has left gradients behind (graph replay and the factored update assume none)
         self._setup_overlap(named, n)
@@ -472,6 +480,21 @@ class E4TTrainer:
         of the stack in a synchronising step; returns every rank's rows (rank order) and marks region W as already global, or None."""
         if not self._armed or self.regions is None or "W" in self._done:
             return None
+        # all_gather_into_tensor needs the same row count on every rank (advisor, round 5): checked once per batch size with a MIN / MAX
+        # all-reduce — a collective, so every rank must get here with the same first-write state, which a synchronising step of ranks
+        # that all accumulate alike guarantees (train_step's sync / loss_scale arguments are rank-uniform by contract).  A ragged
+        # batch switches the exchange off for good: the stack then rides the all-reduce, which tolerates any per-rank batch.
+        nb = int(gb.shape[0])
+        ok = self._exchange_ok.get(nb)
+        if ok is None:
+            lohi = torch.tensor([nb, -nb], dtype=torch.int64, device=gb.device)
+            torch.distributed.all_reduce(lohi, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+            ok = self._exchange_ok[nb] = bool(int(lohi[0]) == nb and int(lohi[1]) == -nb)
+            if not ok:
+                warnings.warn(f"E4TTrainer: per-rank batch sizes differ ({int(lohi[0])}..{-int(lohi[1])}): the head's factor exchange is off, its stacked gradient is all-reduced")
+                self._exchange_ok = _AlwaysFalse()
+        if not ok:
+            return None
         w = gb.shape[1]
         mine = torch.cat([gb, Z], dim=1)
         rows = torch.empty((self.world * mine.shape[0], mine.shape[1]), dtype=mine.dtype, device=mine.device)
@@ -671,6 +694,7 @@ class E4TTrainer:
             static = {k: v.clone() for k, v in ins.items() if v is not None}
             g = torch.cuda.CUDAGraph()
             self._capturing = True
+            captured = False
             try:
                 with ops.capture_guard():
                     torch.cuda.synchronize()
@@ -679,19 +703,34 @@ class E4TTrainer:
                         # under the default GLOBAL capture mode such a call from another thread invalidates the capture or kills the watchdog
                         # ("operation not permitted when stream is capturing", 4 of 12 runs of tests/rccl_one_rank.py).  Give it time to
                         # retire the finished work, and capture thread-locally so that its remaining calls are none of the capture's business.
+                        # (The device is already quiescent — synchronize() above; what the pause covers is the watchdog's own polling
+                        # loop, which ProcessGroupNCCL offers no call to drain.  thread_local mode is the guard, the pause only makes
+                        # its warning-free path the common one; a capture that still fails is handled collectively below.)
                         time.sleep(0.5)
                     with torch.cuda.graph(g, capture_error_mode="thread_local" if self._comm else "global"):
                         out = self._train_step(**{k: static.get(k) for k in ins})
+                captured = True
             except Exception as e:                    # e.g. a collective the RCCL build will not capture: eager from here on
                 if not self._comm:
                     raise
                 warnings.warn(f"E4TTrainer: capturing the step with its collectives failed ({type(e).__name__}: {e}); running eagerly")
-                self._capturing, self._step_graph_on, self._graph_failed = False, False, True
                 self._works, self._done = [], set()
                 torch.cuda.synchronize()
-                return self._train_step(**ins)
             finally:
                 self._capturing = False
+            if self._comm:
+                # the decision is COLLECTIVE (advisor, round 5): a rank that fell back alone would enqueue its step from Python while
+                # the others replay theirs in ~1 ms and then wait for it in every all-reduce.  One MIN all-reduce of "captured":
+                # either every rank replays or every rank drops its graph and runs eagerly from here on.
+                flag = torch.tensor([1 if captured else 0], dtype=torch.int32, device=self.device)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.pg)
+                if not bool(int(flag)):
+                    if captured:
+                        warnings.warn("E4TTrainer: another rank could not capture the step; running eagerly on every rank")
+                    del g
+                    self._step_graph_on, self._graph_failed = False, True
+                    self._works, self._done = [], set()
+                    return self._train_step(**ins)
             ent = self._step_graphs[sig] = (g, static, out)
         g, static, out = ent
         for k, v in static.items():

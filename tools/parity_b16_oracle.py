@@ -2,12 +2,11 @@
 B = 16) — TEST INFRASTRUCTURE, run offline once per round on the GPU box (the two CPU fp32 oracle steps at B = 16 take minutes, which is why
 this is not a `-m gpu` test; the suite's own B = 16 evidence is test_full_sd14_batch16_step_matches_sixteen_single_sample_steps).
 
-    python tools/parity_b16_oracle.py [--batch 16] [--one-cpu-leg] [--out profiles/r04_parity/parity_full_sd14_b16_oracle.json]
+    E4T_COMMIT=<sha> python tools/parity_b16_oracle.py [--batch 16] [--out profiles/r06_parity/parity_full_sd14_b16_oracle.json]
 
 Protocol = tests/parity_step.py: native B-step on the HIP kernels vs the CPU fp32 oracle B-step, every compared quantity
-bounded by 2 x (stock torch.autocast(bf16) of the oracle vs the oracle) + 3e-3, LeakyReLU kink elements inside the case's band aligned per
-leg.  --one-cpu-leg judges the autocast leg against the oracle run aligned to the NATIVE leg's branches (one CPU step instead of two): the
-calibration can then only come out larger, i.e. the bound looser, for the E4T-head gradients; everything upstream of the head is unaffected.
+bounded by 2 x (stock torch.autocast(bf16) of the oracle vs the oracle) + 3e-3, LeakyReLU kink elements inside the measured band aligned per
+leg (parity_step.evaluate, the function the -m gpu suite calls at B = 1).
 """
 import argparse
 import dataclasses
@@ -45,21 +44,11 @@ def main():
     del n
     torch.cuda.empty_cache()
     sec["native"] = time.perf_counter() - t
-    t = time.perf_counter()
-    cal = ps.oracle_leg(case, o, d, dev=dev, autocast=True)
-    torch.cuda.empty_cache()
-    sec["autocast_gpu"] = time.perf_counter() - t
-    t = time.perf_counter()
-    ref_nat = ps.oracle_leg(case, o, d, follow_kinks=nat["_kinks"])
-    sec["oracle_fp32_cpu_aligned_to_native"] = time.perf_counter() - t
-    if args.one_cpu_leg:
-        ref_cal = ref_nat
-    else:
-        t = time.perf_counter()
-        ref_cal = ps.oracle_leg(case, o, d, follow_kinks=cal["_kinks"])
-        sec["oracle_fp32_cpu_aligned_to_autocast"] = time.perf_counter() - t
-    rep = ps.compare(case, nat, ref_nat, [(cal, ref_cal)], verbose=True, strict=False)
-    rep.update(batch=args.batch, seconds=sec, cpu_legs=1 if args.one_cpu_leg else 2, threads=torch.get_num_threads(),
+    # exactly the suite's protocol (parity_step.evaluate: stock-autocast calibration leg on the GPU, one CPU fp32 oracle run aligned to
+    # its LeakyReLU branches, one aligned to the native leg's, kink band = KINK_SIGMA x the measured input error), at batch B
+    case = dataclasses.replace(case, cpu_calib=False)
+    rep, _ = ps.evaluate(case, o, d, nat, dev, verbose=True, strict=False, timings=sec, need_ref=False)
+    rep.update(batch=args.batch, seconds=sec, cpu_legs=2, threads=torch.get_num_threads(),
                commit=os.environ.get("E4T_COMMIT", "unknown (set E4T_COMMIT: the GPU box has no .git)"), kink_sigma=ps.KINK_SIGMA)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as fh:
