@@ -581,8 +581,26 @@ struct FragOff64 {
     }
   }
 };
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned voff, bf16_t* lds_wave_base) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+// The DMA is issued from inline asm, not through __builtin_amdgcn_raw_ptr_buffer_load_lds: hipcc (ROCm 7.2) puts its own
+// s_waitcnt vmcnt(0) in front of the first ds_read that follows a builtin LDS-DMA (it cannot prove that the read does not alias the
+// DMA's target), which turns a three-tile lead into none (measured: the 4-buffer ring was no faster than the 2-buffer one).  With
+// the asm form the compiler sees no LDS-DMA; the counted attn_wait_vmcnt<N>() in front of each tile barrier is the only wait.
+// Consequence: no compiler-counted VMEM load may live in a loop that uses these (its vmcnt would not include the asm pieces and
+// would over-wait).  M0 = LDS byte address of the wave's 1-KB destination, written in the same statement that uses it.
+typedef int i32x4_native __attribute__((ext_vector_type(4)));
+struct DmaRsrc { i32x4_native w; };
+__device__ __forceinline__ DmaRsrc make_dma_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  DmaRsrc r;
+  r.w = i32x4_native{__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)),
+                     __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000};
+  return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const bf16_t* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void dma16(const DmaRsrc& rs, unsigned voff, unsigned lds_wave_base_bytes) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave_base_bytes), "v"(voff), "s"(rs.w) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -600,11 +618,11 @@ struct TileDma {
       step[i] = on ? (unsigned)(64 * ld * 2) : 0u;
     }
   }
-  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, bf16_t* img) {      // the next tile -> img
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __device__ __forceinline__ void issue(const DmaRsrc& rs, bf16_t* img) {      // the next tile -> img
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(img) + (threadIdx.x >> 6) * 2048);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      dma16(rs, vo[i], img + (2 * wave + i) * 512);
+      dma16(rs, vo[i], base + i * 1024);
       vo[i] += step[i];
     }
   }
@@ -632,8 +650,8 @@ __device__ __forceinline__ void fwd64_phase(const f32x2 sc, const FragOff64<DH>&
                                             const f32x16& sx, f32x2& mm, Frag (&px)[2], f32x16 (&ox)[Cfg<DH>::NDT],
                                             f32x16& sy, const Frag (&py)[2], f32x16 (&oy)[Cfg<DH>::NDT], const bf16x8 (&qfy)[Cfg<DH>::NKS],
                                             bf16x8 (&vfr)[Cfg<DH>::NDT][2], bf16x8 (&kfr)[Cfg<DH>::NKS],
-                                            TileDma<DH>& kd, TileDma<DH>& vd, const __amdgpu_buffer_rsrc_t rsK,
-                                            const __amdgpu_buffer_rsrc_t rsV, const int pad_row0, const int S) {
+                                            TileDma<DH>& kd, TileDma<DH>& vd, const DmaRsrc& rsK, const DmaRsrc& rsV, const int pad_row0,
+                                            const int S) {
   using C = Cfg<DH>;
   constexpr int NPV = 2 * C::NDT, NM = NPV + C::NKS, IMG = 64 * 64;
   f32x2 t = pk_fms(f32x2{sx[0], sx[1]}, sc, mm);   // the exp argument of chunk c is formed in chunk c - 1 (no dependent back-to-back VALU)
@@ -734,8 +752,8 @@ __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArg
   const f32x2 sc = {p.scale2, p.scale2};
 
   TileDma<DH> kd, vd;
-  const __amdgpu_buffer_rsrc_t rsK = make_rsrc(Kb, (unsigned)(((long long)(p.S - 1) * p.ldk + DH) * 2));
-  const __amdgpu_buffer_rsrc_t rsV = make_rsrc(Vb, (unsigned)(((long long)(p.S - 1) * p.ldv + DH) * 2));
+  const DmaRsrc rsK = make_dma_rsrc(Kb, (unsigned)(((long long)(p.S - 1) * p.ldk + DH) * 2));
+  const DmaRsrc rsV = make_dma_rsrc(Vb, (unsigned)(((long long)(p.S - 1) * p.ldv + DH) * 2));
   kd.init(p.ldk); vd.init(p.ldv);
 #pragma unroll
   for (int tb = 0; tb < 4; ++tb) { kd.issue(rsK, lds + tb * TILE); vd.issue(rsV, lds + tb * TILE + IMG); }      // tiles 0..3
@@ -1364,6 +1382,122 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs p) {
   store_T_acc<DH>(dk1, p.scale, dKb, p.ldk, krow + 32, p.S, hi);
 }
 
+// ================================================================================================
+// backward dK, dV with LDS-DMA tile staging (round 6, dh = 40, un-split query range): attn_bwd_dkv_kernel's arithmetic and occupancy
+// (32 keys per wave, three workgroups per CU, FOLD), but the Q / dO tiles arrive by buffer_load ... lds into a ring of three
+// compact (128-byte-row) tile buffers, two tiles ahead of their use: no staging registers, no ds_write of the tiles, no global-load
+// latency in front of the stores, ONE barrier per 64-query tile instead of two.
+//   iteration t:  vmcnt(6) [tile t's pieces landed; tile t + 1's and its statistics stay in flight] -> pad columns of tile t
+//                 (folded -L / scale2, -Delta: from registers loaded two iterations ago) -> barrier -> statistics + DMA of tile t + 2
+//                 into the buffer of tile t - 1 -> the two 32-query sub-tiles of tile t.
+// Every wave issues the same VMEM sequence (2 statistics loads, 4 DMA pieces per tile), so the counted waits hold on every wave.
+// ================================================================================================
+#ifndef ATTN_DKV_DMA
+#define ATTN_DKV_DMA 1
+#endif
+template <int DH>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
+  using C = Cfg<DH>;
+  static_assert(DH % 16 == 8 && C::DK - DH >= 3 && C::DV <= 64, "folded statistics need three spare contraction slots; compact images 64 columns");
+  constexpr int IMG = 64 * 64, TILE = 2 * IMG, NB = 3;
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[NB * TILE];    // ring of [Q image][dO image]
+  const FragOff64<DH> fo;
+  const Blk blk = xcd_block(p.xcd_raster);
+  const int b = blk.b, h = blk.h;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int key = blk.x * 128 + wave * 32 + li;
+  const bf16_t* Qb = p.Q + b * p.bq + h * DH;
+  const bf16_t* dOb = p.dO + b * p.bo + h * DH;
+  const float* Lb = p.L + ((long long)b * p.H + h) * p.T;
+  const float* Db = p.Delta + ((long long)b * p.H + h) * p.T;
+
+  bf16x8 kf[C::NKS], vf[C::NKS];
+  load_row_frags<DH>(p.K + b * p.bk + h * DH, p.ldk, key, p.S, hi, kf);
+  load_row_frags<DH>(p.V + b * p.bv + h * DH, p.ldv, key, p.S, hi, vf);
+  if (hi == 1) {                                   // ones against the three folded bf16 pieces (see attn_bwd_dkv_kernel)
+    Frag t;
+    t.q = make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u);
+    kf[DH / 16] = t.v; vf[DH / 16] = t.v;
+  }
+  f32x16 dvt[C::NDT], dkt[C::NDT];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dvt[dt][r] = 0.f; dkt[dt][r] = 0.f; }
+
+  TileDma<DH> qd, dod;
+  const DmaRsrc rsQ = make_dma_rsrc(Qb, (unsigned)(((long long)(p.T - 1) * p.ldq + DH) * 2));
+  const DmaRsrc rsdO = make_dma_rsrc(dOb, (unsigned)(((long long)(p.T - 1) * p.ldo + DH) * 2));
+  qd.init(p.ldq); dod.init(p.ldo);
+  // statistics of the row (thread & 63) of tiles t, t + 1, t + 2: raw loads, the padded-row select is applied where they are used
+  const int srow = threadIdx.x & 63;
+  float l0, d0, l1, d1;
+  auto stat_load = [&](int q, float& l, float& d) { const int qc = min(q, p.T - 1); l = Lb[qc]; d = Db[qc]; };
+  stat_load(srow, l0, d0);
+  qd.issue(rsQ, lds); dod.issue(rsdO, lds + IMG);                      // tile 0
+  stat_load(64 + srow, l1, d1);
+  qd.issue(rsQ, lds + TILE); dod.issue(rsdO, lds + TILE + IMG);        // tile 1
+  const float inv_scale2 = 1.f / p.scale2;
+  const int ntiles = (p.T + 63) >> 6;
+
+  auto tile = [&](auto tb_, int t) __attribute__((always_inline)) {
+    constexpr int TB = decltype(tb_)::value;
+    constexpr int QI = TB * TILE, DI = QI + IMG, NXT = ((TB + 2) % NB) * TILE;      // tile t + 2 goes where tile t - 1 was
+    attn_wait_vmcnt<6>();
+    {
+      const int q = t * 64 + srow;
+      *(uint4*)(lds + QI + img64_off(srow, C::NCH)) = split3_bf16(fmaxf(-(q < p.T ? l0 : INFINITY) * inv_scale2, -1e30f));
+      *(uint4*)(lds + DI + img64_off(srow, C::NCH)) = split3_bf16(q < p.T ? -d0 : 0.f);
+    }
+    __syncthreads();
+    l0 = l1; d0 = d1;                              // tile t + 1's (loaded one iteration ago); tile t + 2's land in l1 / d1 during this tile
+    stat_load((t + 2) * 64 + srow, l1, d1);
+    qd.issue(rsQ, lds + NXT); dod.issue(rsdO, lds + NXT + IMG);
+    auto sub_tile = [&](auto sub_) __attribute__((always_inline)) {
+      constexpr int SO = decltype(sub_)::value * 32 * 64;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < C::NKS; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lds + QI + SO + fo.row[ks]), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lds + DI + SO + fo.row[ks]), vf[ks], dp, 0, 0, 0);
+      }
+      float pr[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 t2 = f32x2{s[r], s[r + 1]} * f32x2{p.scale2, p.scale2};
+        const f32x2 e2 = f32x2{fast_exp2(t2.x), fast_exp2(t2.y)};
+        const f32x2 o2 = e2 * f32x2{dp[r], dp[r + 1]};
+        pr[r] = e2.x; pr[r + 1] = e2.y; ds[r] = o2.x; ds[r + 1] = o2.y;
+      }
+      const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);
+      const bf16x8 sf0 = pack_acc(ds, 0), sf1 = pack_acc(ds, 1);
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) {
+        const bf16_t* q0 = lds + QI + SO, *q1 = q0 + 16 * 64, *o0 = lds + DI + SO, *o1 = o0 + 16 * 64;
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(o0 + fo.tr_lo[dt], o0 + fo.tr_hi[dt]), pf0, dvt[dt], 0, 0, 0);
+        dvt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(o1 + fo.tr_lo[dt], o1 + fo.tr_hi[dt]), pf1, dvt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(q0 + fo.tr_lo[dt], q0 + fo.tr_hi[dt]), sf0, dkt[dt], 0, 0, 0);
+        dkt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(q1 + fo.tr_lo[dt], q1 + fo.tr_hi[dt]), sf1, dkt[dt], 0, 0, 0);
+      }
+    };
+    sub_tile(std::integral_constant<int, 0>{});
+    if (p.T - t * 64 > 32) sub_tile(std::integral_constant<int, 1>{});
+  };
+  for (int t = 0; t < ntiles; t += 3) {
+    tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < ntiles) tile(std::integral_constant<int, 2>{}, t + 2);
+  }
+  attn_wait_vmcnt<0>();                           // (DMA pieces of tiles beyond the end must not outlive the workgroup's LDS)
+  int krow = key;
+  asm volatile("" : "+v"(krow));
+  store_T_acc<DH>(dvt, 1.f, p.dV + b * p.bv + h * DH, p.ldv, krow, p.S, hi);
+  store_T_acc<DH>(dkt, p.scale, p.dK + b * p.bk + h * DH, p.ldk, krow, p.S, hi);
+}
+
 // dV / dK = sum over the query chunks' partials (fixed order: deterministic), dK scaled, one bf16 rounding
 template <int DH>
 __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(AttnArgs p, int Bn) {
@@ -1444,11 +1578,15 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
   // profiles/r04_ab/r04g_c5_occ*): it stays at two
   const int dkv_occ = DH > 64 ? 1 : ((p.S >= 2048 && DH < 64) ? 3 : DKV_WAVES);
   const bool dkv64 = DH == 40 && ATTN_BWD64 && !p.causal && p.tsplit == 1 && p.T >= ATTN_FWD64_MIN_S && p.S >= 256;
+  const bool dkv_dma = DH == 40 && ATTN_DKV_DMA && !dkv64 && !p.causal && p.tsplit == 1 && p.T >= 192;
   if (e4t_launch_log_enabled()) {
     const double el = (double)Bn * p.H * DH;      // elements per token row over all heads
     E4T_LOG_LAUNCH("attn_bwd_dq_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
                    2.0 * el * (4.0 * p.T + 2.0 * p.S) + 8.0 * Bn * p.H * p.T, 6.0 * Bn * p.H * (double)p.T * p.S * DH);
-    if (dkv64)
+    if (dkv_dma)
+      E4T_LOG_LAUNCH("attn_bwd_dkv_dma_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
+                     2.0 * el * (2.0 * p.T + 4.0 * p.S) + 8.0 * Bn * p.H * p.T, 8.0 * Bn * p.H * (double)p.T * p.S * DH);
+    else if (dkv64)
       E4T_LOG_LAUNCH("attn_bwd_dkv64_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
                      2.0 * el * (2.0 * p.T + 4.0 * p.S) + 8.0 * Bn * p.H * p.T, 8.0 * Bn * p.H * (double)p.T * p.S * DH);
     else
@@ -1460,6 +1598,11 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
   E4T_CHECK_LAUNCH("attn_bwd_dq_kernel");
   const dim3 gdkv(cdiv(p.S, 128) * p.tsplit, p.H, Bn);
   if constexpr (DH == 40) {
+    if (dkv_dma) {
+      hipLaunchKernelGGL((attn_bwd_dkv_dma_kernel<DH>), gdkv, dim3(256), 0, st, p);
+      E4T_CHECK_LAUNCH("attn_bwd_dkv_dma_kernel");
+      return 0;
+    }
     if (dkv64) {
       hipLaunchKernelGGL((attn_bwd_dkv64_kernel<DH>), dim3(cdiv(p.S, 256), p.H, Bn), dim3(256), 0, st, p);
       E4T_CHECK_LAUNCH("attn_bwd_dkv64_kernel");
