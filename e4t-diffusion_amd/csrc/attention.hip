@@ -39,6 +39,7 @@ struct AttnArgs {
   bf16_t *Out, *dQ, *dK, *dV;
   float* L;      // [B][H][T] log2-domain logsumexp
   float* Delta;  // [B][H][T] rowsum(dO * O)
+  float* LD;     // [B][H][T][2] {L, Delta} pairs (written by the dQ kernel next to Delta for the DMA-staged dK/dV kernel) or null
   int T, S, H;
   int ldq, ldk, ldv, ldo;      // row strides (elements)
   long long bq, bk, bv, bo;    // batch strides (elements)
@@ -491,6 +492,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
 #ifndef ATTN_FWD64_FENCE
 #define ATTN_FWD64_FENCE 1
 #endif
+#ifndef ATTN_FWD64_ROWS
+#define ATTN_FWD64_ROWS 128
+#endif
 #ifndef ATTN_FWD64_MIN_S
 #define ATTN_FWD64_MIN_S 512
 #endif
@@ -605,23 +609,24 @@ __device__ __forceinline__ void dma16(const DmaRsrc& rs, unsigned voff, unsigned
 template <int N>
 __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // this wave's share (two of the eight 1-KB pieces) of a 64-row tile image; the row offset lives in the bounds-checked lane offset
-template <int DH>
+template <int DH, int ROWS = 64>
 struct TileDma {
-  unsigned vo[2], step[2];
+  static constexpr int NP = ROWS / 32;             // 1-KB pieces (8 image rows each) per wave of a 4-wave workgroup
+  unsigned vo[NP], step[NP];
   __device__ __forceinline__ void init(int ld) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = 8 * (2 * wave + i) + (lane >> 3), L = img64_slot(r, lane & 7);
+    for (int i = 0; i < NP; ++i) {
+      const int r = 8 * (NP * wave + i) + (lane >> 3), L = img64_slot(r, lane & 7);
       const bool on = L < Cfg<DH>::NCH;
       vo[i] = on ? (unsigned)((r * ld + L * 8) * 2) : 0x80000000u;
-      step[i] = on ? (unsigned)(64 * ld * 2) : 0u;
+      step[i] = on ? (unsigned)(ROWS * ld * 2) : 0u;
     }
   }
   __device__ __forceinline__ void issue(const DmaRsrc& rs, bf16_t* img) {      // the next tile -> img
-    const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(img) + (threadIdx.x >> 6) * 2048);
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds_addr(img) + (threadIdx.x >> 6) * (NP * 1024));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NP; ++i) {
       dma16(rs, vo[i], base + i * 1024);
       vo[i] += step[i];
     }
@@ -645,15 +650,15 @@ __device__ __forceinline__ void write_key_mask(bf16_t* kimg, int row0, int S) {
 //   STAGE >= 0: X phase that issues the DMA of the tile FOUR ahead into this tile's own images at lds + STAGE / + STAGE + IMG (nobody
 //          reads them any more: the barrier of the preceding Y phase).  Four tile buffers: a tile period is ~1 us, about the latency of
 //          an LDS-DMA piece under load — with two buffers (one tile of lead) the wait in front of the barrier cost ~90 us per launch.
-template <int DH, bool LOADS, int VOFF, int KOFF, int PADS, int STAGE>
+template <int DH, int ROWS, bool LOADS, int VOFF, int KOFF, int PADS, int STAGE>
 __device__ __forceinline__ void fwd64_phase(const f32x2 sc, const FragOff64<DH>& fo, bf16_t* lds,
                                             const f32x16& sx, f32x2& mm, Frag (&px)[2], f32x16 (&ox)[Cfg<DH>::NDT],
                                             f32x16& sy, const Frag (&py)[2], f32x16 (&oy)[Cfg<DH>::NDT], const bf16x8 (&qfy)[Cfg<DH>::NKS],
                                             bf16x8 (&vfr)[Cfg<DH>::NDT][2], bf16x8 (&kfr)[Cfg<DH>::NKS],
-                                            TileDma<DH>& kd, TileDma<DH>& vd, const DmaRsrc& rsK, const DmaRsrc& rsV, const int pad_row0,
+                                            TileDma<DH, ROWS>& kd, TileDma<DH, ROWS>& vd, const DmaRsrc& rsK, const DmaRsrc& rsV, const int pad_row0,
                                             const int S) {
   using C = Cfg<DH>;
-  constexpr int NPV = 2 * C::NDT, NM = NPV + C::NKS, IMG = 64 * 64;
+  constexpr int NPV = 2 * C::NDT, NM = NPV + C::NKS, IMG = ROWS * 64;
   f32x2 t = pk_fms(f32x2{sx[0], sx[1]}, sc, mm);   // the exp argument of chunk c is formed in chunk c - 1 (no dependent back-to-back VALU)
   float pe0 = 0.f, pe1 = 0.f;
 #pragma unroll
@@ -682,10 +687,17 @@ __device__ __forceinline__ void fwd64_phase(const f32x2 sc, const FragOff64<DH>&
         A64_FENCE();
       }
       if (LOADS && i == NM - 1 && PADS >= 0 && ATTN64_PROBE != 6 && ATTN64_PROBE != 7) {
-        attn_wait_vmcnt<8>();                       // this wave's 4 pieces of the next tile have landed; the two tiles behind it stay in flight
-        const int r = threadIdx.x & 63;
-        *(uint4*)(lds + PADS + img64_off(r, C::NCH)) = make_uint4(pad_row0 + r < S ? 0u : 0xC6EAu, 0u, 0u, 0u);
-        *(uint4*)(lds + PADS + IMG + img64_off(r, C::NCH)) = make_uint4(0x3F80u, 0u, 0u, 0u);
+        if (ROWS == 64) {
+          attn_wait_vmcnt<8>();                     // this wave's 4 pieces of the next tile have landed; the two tiles behind it stay in flight
+          const int r = threadIdx.x & 63;
+          *(uint4*)(lds + PADS + img64_off(r, C::NCH)) = make_uint4(pad_row0 + r < S ? 0u : 0xC6EAu, 0u, 0u, 0u);
+          *(uint4*)(lds + PADS + IMG + img64_off(r, C::NCH)) = make_uint4(0x3F80u, 0u, 0u, 0u);
+        } else {                                    // 128-row tiles, two buffers: the next tile (issued one tile ago) is the only one in flight
+          attn_wait_vmcnt<0>();
+          const int r = threadIdx.x & 127;
+          const unsigned w0 = threadIdx.x >= 128 ? 0x3F80u : (pad_row0 + r < S ? 0u : 0xC6EAu);      // K image: validity; V image: 1.0
+          *(uint4*)(lds + PADS + (threadIdx.x >> 7) * IMG + img64_off(r, C::NCH)) = make_uint4(w0, 0u, 0u, 0u);
+        }
         __syncthreads();                           // the next tile's images are complete; nobody reads the old tile any more
       }
       if (LOADS && i == NM - 1 && (ATTN64_PROBE == 4 || ATTN64_PROBE == 7 || ATTN64_PROBE == 9)) {      // (opaque: the score MFMAs must not become loop-invariant)
@@ -734,12 +746,13 @@ __device__ __forceinline__ void fwd64_phase(const f32x2 sc, const FragOff64<DH>&
   }
 }
 
-template <int DH>
+template <int DH, int ROWS>
 __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   static_assert(DH % 16 == 8 && C::DV > DH && C::DV <= 64, "needs a spare contraction slot (key mask), a spare O^T row (row sum), 128-byte image rows");
-  constexpr int IMG = 64 * 64, TILE = 2 * IMG;     // one image = 64 rows x 128 bytes; a tile = K image + V image
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[4 * TILE];      // four tile buffers of [K image][V image]: 64 KB
+  static_assert(ROWS == 64 || ROWS == 128, "64-key tiles in a ring of four, or 128-key tiles in two buffers");
+  constexpr int IMG = ROWS * 64, TILE = 2 * IMG, NBUF = 256 / ROWS;    // one image = ROWS rows x 128 bytes; a tile = K image + V image
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[NBUF * TILE];   // 64 KB either way
   const FragOff64<DH> fo;
   const Blk blk = xcd_block(p.xcd_raster);
   const int b = blk.b, h = blk.h;
@@ -751,12 +764,12 @@ __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArg
   const bf16_t* Vb = p.V + b * p.bv + h * DH;
   const f32x2 sc = {p.scale2, p.scale2};
 
-  TileDma<DH> kd, vd;
+  TileDma<DH, ROWS> kd, vd;
   const DmaRsrc rsK = make_dma_rsrc(Kb, (unsigned)(((long long)(p.S - 1) * p.ldk + DH) * 2));
   const DmaRsrc rsV = make_dma_rsrc(Vb, (unsigned)(((long long)(p.S - 1) * p.ldv + DH) * 2));
   kd.init(p.ldk); vd.init(p.ldv);
 #pragma unroll
-  for (int tb = 0; tb < 4; ++tb) { kd.issue(rsK, lds + tb * TILE); vd.issue(rsV, lds + tb * TILE + IMG); }      // tiles 0..3
+  for (int tb = 0; tb < NBUF; ++tb) { kd.issue(rsK, lds + tb * TILE); vd.issue(rsV, lds + tb * TILE + IMG); }      // the first NBUF tiles
 
   bf16x8 qf[2][C::NKS];
   load_row_frags<DH>(Qb, p.ldq, q0, p.T, hi, qf[0]);
@@ -783,8 +796,7 @@ __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArg
   }
   f32x2 ma = {-1e30f, -1e30f}, mb = ma;      // running row max (log2 units), duplicated for the packed fma
   attn_wait_vmcnt<0>();                           // (one-off; also covers the Q fragments)
-  {
-    const int r = threadIdx.x & 63;                // tile 0's pad slots (every later tile gets its own at its publishing barrier)
+  for (int r = threadIdx.x; r < ROWS; r += 256) {  // tile 0's pad slots (every later tile gets its own at its publishing barrier)
     *(uint4*)(lds + img64_off(r, C::NCH)) = make_uint4(r < p.S ? 0u : 0xC6EAu, 0u, 0u, 0u);
     *(uint4*)(lds + IMG + img64_off(r, C::NCH)) = make_uint4(0x3F80u, 0u, 0u, 0u);
   }
@@ -796,21 +808,35 @@ __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArg
 #pragma unroll
   for (int ks = 0; ks < C::NKS; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[ks], qf[0][ks], sa, 0, 0, 0);
 
-  const int ntiles = (p.S + 63) >> 6;
-  // one 64-key tile in buffer TB: sub-tiles 2t, 2t + 1 (a ragged last tile is processed whole: its absent keys are masked)
+  constexpr int NSUB = ROWS / 32;
+  const int ntiles = (p.S + ROWS - 1) / ROWS;
+  // one ROWS-key tile in buffer TB: sub-tiles NSUB t .. NSUB t + NSUB - 1 (a ragged last tile is processed whole: its absent keys are
+  // masked).  The last sub-tile's Y phase carries the tile barrier, its X phase the DMA of the tile NBUF ahead into this tile's images.
   auto tile = [&](auto tb_, int t) __attribute__((always_inline)) {
     constexpr int TB = decltype(tb_)::value;
-    constexpr int KI = TB * TILE, VI = KI + IMG, KN = ((TB + 1) & 3) * TILE;
-    fwd64_phase<DH, true, VI, KI + 32 * 64, -1, -1>(sc, fo, lds, sa, ma, pa, oa, sb, pb, ob, qf[1], vfr, kfr, kd, vd, rsK, rsV, 0, p.S);
-    fwd64_phase<DH, false, 0, 0, -1, -1>(sc, fo, lds, sb, mb, pb, ob, sa, pa, oa, qf[0], vfr, kfr, kd, vd, rsK, rsV, 0, p.S);
-    fwd64_phase<DH, true, VI + 32 * 64, KN, KN, -1>(sc, fo, lds, sa, ma, pa, oa, sb, pb, ob, qf[1], vfr, kfr, kd, vd, rsK, rsV, (t + 1) * 64, p.S);
-    fwd64_phase<DH, false, 0, 0, -1, KI>(sc, fo, lds, sb, mb, pb, ob, sa, pa, oa, qf[0], vfr, kfr, kd, vd, rsK, rsV, 0, p.S);
+    constexpr int KI = TB * TILE, VI = KI + IMG, KN = ((TB + 1) % NBUF) * TILE;
+#define F64_Y sa, ma, pa, oa, sb, pb, ob, qf[1], vfr, kfr, kd, vd, rsK, rsV
+#define F64_X sb, mb, pb, ob, sa, pa, oa, qf[0], vfr, kfr, kd, vd, rsK, rsV
+    fwd64_phase<DH, ROWS, true, VI, KI + 32 * 64, -1, -1>(sc, fo, lds, F64_Y, 0, p.S);
+    fwd64_phase<DH, ROWS, false, 0, 0, -1, -1>(sc, fo, lds, F64_X, 0, p.S);
+    if constexpr (NSUB == 4) {
+      fwd64_phase<DH, ROWS, true, VI + 32 * 64, KI + 64 * 64, -1, -1>(sc, fo, lds, F64_Y, 0, p.S);
+      fwd64_phase<DH, ROWS, false, 0, 0, -1, -1>(sc, fo, lds, F64_X, 0, p.S);
+      fwd64_phase<DH, ROWS, true, VI + 64 * 64, KI + 96 * 64, -1, -1>(sc, fo, lds, F64_Y, 0, p.S);
+      fwd64_phase<DH, ROWS, false, 0, 0, -1, -1>(sc, fo, lds, F64_X, 0, p.S);
+    }
+    fwd64_phase<DH, ROWS, true, VI + (ROWS - 32) * 64, KN, KN, -1>(sc, fo, lds, F64_Y, (t + 1) * ROWS, p.S);
+    fwd64_phase<DH, ROWS, false, 0, 0, -1, KI>(sc, fo, lds, F64_X, 0, p.S);
+#undef F64_Y
+#undef F64_X
   };
-  for (int t = 0; t < ntiles; t += 4) {
+  for (int t = 0; t < ntiles; t += NBUF) {
     tile(std::integral_constant<int, 0>{}, t);
     if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
-    if (t + 2 < ntiles) tile(std::integral_constant<int, 2>{}, t + 2);
-    if (t + 3 < ntiles) tile(std::integral_constant<int, 3>{}, t + 3);
+    if constexpr (NBUF == 4) {
+      if (t + 2 < ntiles) tile(std::integral_constant<int, 2>{}, t + 2);
+      if (t + 3 < ntiles) tile(std::integral_constant<int, 3>{}, t + 3);
+    }
   }
   attn_wait_vmcnt<0>();                           // (DMA pieces of tiles beyond the end — zeros — must not outlive the workgroup's LDS)
 #pragma unroll
@@ -880,7 +906,10 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
   const float Dq = row_delta<DH>(p.O + b * p.bo + h * DH, p.ldo, q, p.T, hi, dof);      // (0 for q >= T: both fragments are zero there)
   if (q < p.T) {
     Lq = p.L[((long long)b * p.H + h) * p.T + q];
-    if (hi == 0) p.Delta[((long long)b * p.H + h) * p.T + q] = Dq;      // for the dK/dV kernel, launched behind this one
+    if (hi == 0) {                                  // for the dK/dV kernel, launched behind this one
+      p.Delta[((long long)b * p.H + h) * p.T + q] = Dq;
+      if (p.LD) *(float2*)(p.LD + 2 * (((long long)b * p.H + h) * p.T + q)) = make_float2(Lq, Dq);
+    }
   }
 
   f32x16 acc[C::NDT];
@@ -1399,18 +1428,17 @@ template <int DH>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
   using C = Cfg<DH>;
   static_assert(DH % 16 == 8 && C::DK - DH >= 3 && C::DV <= 64, "folded statistics need three spare contraction slots; compact images 64 columns");
-  constexpr int IMG = 64 * 64, TILE = 2 * IMG, NB = 3;
-  __shared__ __attribute__((aligned(1024))) bf16_t lds[NB * TILE];    // ring of [Q image][dO image]
+  constexpr int IMG = 64 * 64, STAT = 512, TILE = 2 * IMG + STAT, NB = 3;           // slot = [Q image 8 KB][dO image 8 KB][{L, Delta} x 64 + slack: 1 KB]
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[NB * TILE];                  // 51 KB: three workgroups per CU
   const FragOff64<DH> fo;
   const Blk blk = xcd_block(p.xcd_raster);
   const int b = blk.b, h = blk.h;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 31, hi = lane >> 5;
   const int key = blk.x * 128 + wave * 32 + li;
   const bf16_t* Qb = p.Q + b * p.bq + h * DH;
   const bf16_t* dOb = p.dO + b * p.bo + h * DH;
-  const float* Lb = p.L + ((long long)b * p.H + h) * p.T;
-  const float* Db = p.Delta + ((long long)b * p.H + h) * p.T;
+  const float* LDb = p.LD + 2 * ((long long)b * p.H + h) * p.T;
 
   bf16x8 kf[C::NKS], vf[C::NKS];
   load_row_frags<DH>(p.K + b * p.bk + h * DH, p.ldk, key, p.S, hi, kf);
@@ -1429,31 +1457,36 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
   TileDma<DH> qd, dod;
   const DmaRsrc rsQ = make_dma_rsrc(Qb, (unsigned)(((long long)(p.T - 1) * p.ldq + DH) * 2));
   const DmaRsrc rsdO = make_dma_rsrc(dOb, (unsigned)(((long long)(p.T - 1) * p.ldo + DH) * 2));
+  const DmaRsrc rsLD = make_dma_rsrc(LDb, (unsigned)(p.T * 8));
   qd.init(p.ldq); dod.init(p.ldo);
-  // statistics of the row (thread & 63) of tiles t, t + 1, t + 2: raw loads, the padded-row select is applied where they are used
-  const int srow = threadIdx.x & 63;
-  float l0, d0, l1, d1;
-  auto stat_load = [&](int q, float& l, float& d) { const int qc = min(q, p.T - 1); l = Lb[qc]; d = Db[qc]; };
-  stat_load(srow, l0, d0);
-  qd.issue(rsQ, lds); dod.issue(rsdO, lds + IMG);                      // tile 0
-  stat_load(64 + srow, l1, d1);
-  qd.issue(rsQ, lds + TILE); dod.issue(rsdO, lds + TILE + IMG);        // tile 1
+  // wave 0 also fetches the tile's 64 {L, Delta} pairs (512 B: lanes 0..31, 16 B each; the other lanes out of range) and turns them
+  // into the folded pad columns; NOTHING in the loop is a compiler-counted VMEM load (see dma16), so the counted waits below are exact:
+  // wave 0 has 5 pieces per tile in flight, the others 4.
+  unsigned svo = lane < 32 ? (unsigned)(lane * 16) : 0x80000000u;
+  const unsigned sstep = lane < 32 ? 512u : 0u;
+  auto issue_tile = [&](bf16_t* slot) {
+    qd.issue(rsQ, slot); dod.issue(rsdO, slot + IMG);
+    if (wave == 0) { dma16(rsLD, svo, __builtin_amdgcn_readfirstlane(lds_addr(slot + 2 * IMG))); svo += sstep; }
+  };
+  issue_tile(lds);                                 // tile 0
+  issue_tile(lds + TILE);                          // tile 1
   const float inv_scale2 = 1.f / p.scale2;
   const int ntiles = (p.T + 63) >> 6;
 
   auto tile = [&](auto tb_, int t) __attribute__((always_inline)) {
     constexpr int TB = decltype(tb_)::value;
-    constexpr int QI = TB * TILE, DI = QI + IMG, NXT = ((TB + 2) % NB) * TILE;      // tile t + 2 goes where tile t - 1 was
-    attn_wait_vmcnt<6>();
-    {
-      const int q = t * 64 + srow;
-      *(uint4*)(lds + QI + img64_off(srow, C::NCH)) = split3_bf16(fmaxf(-(q < p.T ? l0 : INFINITY) * inv_scale2, -1e30f));
-      *(uint4*)(lds + DI + img64_off(srow, C::NCH)) = split3_bf16(q < p.T ? -d0 : 0.f);
+    constexpr int QI = TB * TILE, DI = QI + IMG, SI = QI + 2 * IMG, NXT = ((TB + 2) % NB) * TILE;      // tile t + 2 goes where tile t - 1 was
+    if (wave == 0) {
+      attn_wait_vmcnt<5>();                        // tile t's pieces (and its statistics) have landed; tile t + 1's stay in flight
+      const float2 ld = *(const float2*)((const float*)(lds + SI) + 2 * lane);
+      const int q = t * 64 + lane;
+      *(uint4*)(lds + QI + img64_off(lane, C::NCH)) = split3_bf16(fmaxf(-(q < p.T ? ld.x : INFINITY) * inv_scale2, -1e30f));
+      *(uint4*)(lds + DI + img64_off(lane, C::NCH)) = split3_bf16(q < p.T ? -ld.y : 0.f);
+    } else {
+      attn_wait_vmcnt<4>();
     }
     __syncthreads();
-    l0 = l1; d0 = d1;                              // tile t + 1's (loaded one iteration ago); tile t + 2's land in l1 / d1 during this tile
-    stat_load((t + 2) * 64 + srow, l1, d1);
-    qd.issue(rsQ, lds + NXT); dod.issue(rsdO, lds + NXT + IMG);
+    issue_tile(lds + NXT);
     auto sub_tile = [&](auto sub_) __attribute__((always_inline)) {
       constexpr int SO = decltype(sub_)::value * 32 * 64;
       f32x16 s, dp;
@@ -1553,7 +1586,7 @@ int launch_fwd(const AttnArgs& p, int Bn, hipStream_t st) {
                  2.0 * Bn * p.H * DH * (2.0 * p.T + 2.0 * p.S) + 4.0 * Bn * p.H * p.T, 4.0 * Bn * p.H * (double)p.T * p.S * DH);
   if constexpr (DH == 40) {
     if (fwd64) {
-      hipLaunchKernelGGL((attn_fwd64_kernel<DH>), dim3(cdiv(p.T, 256), p.H, Bn), dim3(256), 0, st, p);
+      hipLaunchKernelGGL((attn_fwd64_kernel<DH, ATTN_FWD64_ROWS>), dim3(cdiv(p.T, 256), p.H, Bn), dim3(256), 0, st, p);
       E4T_CHECK_LAUNCH("attn_fwd64_kernel");
       return 0;
     }
@@ -1571,6 +1604,8 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
     const size_t need = (size_t)total + (size_t)p.tsplit * Bn * p.H * 2 * p.S * DH;
     if (ws_floats >= need) p.part = p.Delta + (((size_t)total + 3) & ~(size_t)3);     // 16-byte aligned behind Delta
     if (ws_floats < need + 3) { p.tsplit = 1; p.part = nullptr; }                     // caller sized the workspace for Delta only
+  } else if (ws_floats >= 3 * (size_t)total + 4) {
+    p.LD = p.Delta + (((size_t)total + 3) & ~(size_t)3);                              // {L, Delta} pairs for the DMA-staged dK/dV kernel
   }
   // measured (tools/ab_dkv.py, dh 40, B16 H8 T4096): S = 4096 1.790 vs 1.835 ms per backward with 3 workgroups per CU, S = 77
   // 0.194 vs 0.167 ms (one workgroup per (batch, head): nothing to cover the un-prefetched tile loads) -> long key ranges only
@@ -1578,7 +1613,7 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
   // profiles/r04_ab/r04g_c5_occ*): it stays at two
   const int dkv_occ = DH > 64 ? 1 : ((p.S >= 2048 && DH < 64) ? 3 : DKV_WAVES);
   const bool dkv64 = DH == 40 && ATTN_BWD64 && !p.causal && p.tsplit == 1 && p.T >= ATTN_FWD64_MIN_S && p.S >= 256;
-  const bool dkv_dma = DH == 40 && ATTN_DKV_DMA && !dkv64 && !p.causal && p.tsplit == 1 && p.T >= 192;
+  const bool dkv_dma = DH == 40 && ATTN_DKV_DMA && !dkv64 && !p.causal && p.tsplit == 1 && p.T >= 192 && p.LD != nullptr && (long long)p.T * 8 < 0x7fffffffLL;
   if (e4t_launch_log_enabled()) {
     const double el = (double)Bn * p.H * DH;      // elements per token row over all heads
     E4T_LOG_LAUNCH("attn_bwd_dq_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
@@ -1660,7 +1695,7 @@ extern "C" size_t e4t_attention_bwd_workspace_floats(int Bn, int H, int T, int S
   int tsplit, tchunk;
   dkv_tsplit(Bn, H, T, S, &tsplit, &tchunk);
   const size_t delta = (size_t)Bn * H * T;
-  return tsplit > 1 ? delta + 4 + (size_t)tsplit * Bn * H * 2 * S * DH : delta;
+  return tsplit > 1 ? delta + 4 + (size_t)tsplit * Bn * H * 2 * S * DH : 3 * delta + 4;      // un-split: Delta + the {L, Delta} pairs
 }
 
 extern "C" int e4t_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,

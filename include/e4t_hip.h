@@ -156,7 +156,8 @@ int e4t_attention_bwd(const void* Q, const void* K, const void* V, const void* O
 /* The same with a workspace of ws_floats >= e4t_attention_bwd_workspace_floats(B, H, T, S, DH) fp32 (16-byte aligned): with few
  * keys (cross-attention over the 77 text tokens, cross_attention.py:516-531) the dK/dV kernel then cuts the query range into chunks
  * that run as separate workgroups and a second kernel sums their fp32 partials in a fixed order (deterministic).  A workspace of
- * only B*H*T floats gives the un-split kernel of e4t_attention_bwd. */
+ * only B*H*T floats gives the un-split kernel of e4t_attention_bwd.  For an un-split query range the stated size is 3*B*H*T + 4: Delta plus
+ * the {L, Delta} pairs the dQ kernel leaves for the dK/dV kernel's LDS-DMA staging (dh 40; round 6). */
 size_t e4t_attention_bwd_workspace_floats(int B, int H, int T, int S, int DH);
 int e4t_attention_bwd_ws(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                          float* ws, size_t ws_floats, void* dQ, void* dK, void* dV, int B, int H, int T, int S, int DH, int ldq,
