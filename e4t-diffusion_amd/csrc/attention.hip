@@ -991,6 +991,114 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
 }
 
 // ================================================================================================
+// backward dQ with LDS-DMA tile staging (round 6, dh = 40, non-causal): attn_bwd_dq_kernel's arithmetic and occupancy, the K / V
+// tiles arriving by buffer_load ... lds into a ring of three compact tile buffers two tiles ahead (see attn_bwd_dkv_dma_kernel).
+// The DMA zero-fills the pad columns and the rows beyond S; nothing but the DMA pieces is a VMEM operation inside the loop.
+// (Needs the TileDma / FragOff64 helpers defined with the forward kernel above.)
+// ================================================================================================
+#ifndef ATTN_DQ_DMA
+#define ATTN_DQ_DMA 1
+#endif
+template <int DH>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_dma_kernel(AttnArgs p) {
+  using C = Cfg<DH>;
+  static_assert(C::DV <= 64, "compact images hold 64 columns");
+  constexpr int IMG = 64 * 64, TILE = 2 * IMG, NB = 3;
+  __shared__ __attribute__((aligned(1024))) bf16_t lds[NB * TILE];    // ring of [K image][V image]: 48 KB
+  const FragOff64<DH> fo;
+  const Blk blk = xcd_block(p.xcd_raster);
+  const int b = blk.b, h = blk.h;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int q = blk.x * 128 + wave * 32 + li;
+  const bf16_t* Kb = p.K + b * p.bk + h * DH;
+  const bf16_t* Vb = p.V + b * p.bv + h * DH;
+
+  TileDma<DH> kd, vd;
+  const DmaRsrc rsK = make_dma_rsrc(Kb, (unsigned)(((long long)(p.S - 1) * p.ldk + DH) * 2));
+  const DmaRsrc rsV = make_dma_rsrc(Vb, (unsigned)(((long long)(p.S - 1) * p.ldv + DH) * 2));
+  kd.init(p.ldk); vd.init(p.ldv);
+  kd.issue(rsK, lds); vd.issue(rsV, lds + IMG);                        // tile 0
+  kd.issue(rsK, lds + TILE); vd.issue(rsV, lds + TILE + IMG);          // tile 1
+
+  bf16x8 qf[C::NKS], dof[C::NKS];
+  load_row_frags<DH>(p.Q + b * p.bq + h * DH, p.ldq, q, p.T, hi, qf);
+  load_row_frags<DH>(p.dO + b * p.bo + h * DH, p.ldo, q, p.T, hi, dof);
+  float Lq = 0.f;
+  const float Dq = row_delta<DH>(p.O + b * p.bo + h * DH, p.ldo, q, p.T, hi, dof);
+  if (q < p.T) {
+    Lq = p.L[((long long)b * p.H + h) * p.T + q];
+    if (hi == 0) {
+      p.Delta[((long long)b * p.H + h) * p.T + q] = Dq;
+      if (p.LD) *(float2*)(p.LD + 2 * (((long long)b * p.H + h) * p.T + q)) = make_float2(Lq, Dq);
+    }
+  }
+  f32x16 acc[C::NDT];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+  // (the prologue's compiler-counted loads / stores above were issued BEHIND the pieces of tiles 0 and 1 and share the in-order
+  // counter with them: the first counted wait below is merely stricter than needed)
+  const int ntiles = (p.S + 63) >> 6;
+
+  auto tile = [&](auto tb_, int t) __attribute__((always_inline)) {
+    constexpr int TB = decltype(tb_)::value;
+    constexpr int KI = TB * TILE, VI = KI + IMG, NXT = ((TB + 2) % NB) * TILE;      // tile t + 2 goes where tile t - 1 was
+    attn_wait_vmcnt<4>();                          // tile t landed; tile t + 1's 4 pieces stay in flight
+    __syncthreads();
+    kd.issue(rsK, lds + NXT); vd.issue(rsV, lds + NXT + IMG);
+    const int kv0 = t * 64;
+    auto sub_tile = [&](auto sub_) __attribute__((always_inline)) {
+      constexpr int sub = decltype(sub_)::value, SO = sub * 32 * 64;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < C::NKS; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lds + KI + SO + fo.row[ks]), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)(lds + VI + SO + fo.row[ks]), dof[ks], dp, 0, 0, 0);
+      }
+      float ds[16];
+      if (kv0 + 64 > p.S) {                // ragged last tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + sub * 32 + acc_row(r, hi);
+          const float pv = key < p.S ? fast_exp2(s[r] * p.scale2 - Lq) : 0.f;
+          ds[r] = pv * (dp[r] - Dq);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 t2 = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-Lq, -Lq});
+          const f32x2 d = pk_fma(f32x2{Dq, Dq}, f32x2{-1.f, -1.f}, f32x2{dp[r], dp[r + 1]});      // dp - Dq, kept packed
+          const f32x2 o2 = f32x2{fast_exp2(t2.x), fast_exp2(t2.y)} * d;
+          ds[r] = o2.x; ds[r + 1] = o2.y;
+        }
+      }
+      const bf16x8 f0 = pack_acc(ds, 0), f1 = pack_acc(ds, 1);
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt) {
+        const bf16_t* k0 = lds + KI + SO, *k1 = k0 + 16 * 64;
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(k0 + fo.tr_lo[dt], k0 + fo.tr_hi[dt]), f0, acc[dt], 0, 0, 0);
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(k1 + fo.tr_lo[dt], k1 + fo.tr_hi[dt]), f1, acc[dt], 0, 0, 0);
+      }
+    };
+    sub_tile(std::integral_constant<int, 0>{});
+    if (p.S - kv0 > 32) sub_tile(std::integral_constant<int, 1>{});
+  };
+  for (int t = 0; t < ntiles; t += 3) {
+    tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < ntiles) tile(std::integral_constant<int, 2>{}, t + 2);
+  }
+  attn_wait_vmcnt<0>();                           // (DMA pieces of tiles beyond the end must not outlive the workgroup's LDS)
+  int qrow = q;
+  asm volatile("" : "+v"(qrow));
+  store_T_acc<DH>(acc, p.scale, p.dQ + b * p.bq + h * DH, p.ldq, qrow, p.T, hi);
+}
+
+// ================================================================================================
 // backward dK, dV: one wave = 32 keys, loop over query tiles
 // ================================================================================================
 // OCC = workgroups per CU the register allocation is bounded for.  OCC = 3 (dh <= 64 only) gives up the register prefetch of the
@@ -1613,10 +1721,11 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
   // profiles/r04_ab/r04g_c5_occ*): it stays at two
   const int dkv_occ = DH > 64 ? 1 : ((p.S >= 2048 && DH < 64) ? 3 : DKV_WAVES);
   const bool dkv64 = DH == 40 && ATTN_BWD64 && !p.causal && p.tsplit == 1 && p.T >= ATTN_FWD64_MIN_S && p.S >= 256;
+  const bool dq_dma = DH <= 64 && ATTN_DQ_DMA && !p.causal && p.S >= 192;      // (dh 32 / 40 / 64: rows of at most 128 bytes)
   const bool dkv_dma = DH == 40 && ATTN_DKV_DMA && !dkv64 && !p.causal && p.tsplit == 1 && p.T >= 192 && p.LD != nullptr && (long long)p.T * 8 < 0x7fffffffLL;
   if (e4t_launch_log_enabled()) {
     const double el = (double)Bn * p.H * DH;      // elements per token row over all heads
-    E4T_LOG_LAUNCH("attn_bwd_dq_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
+    E4T_LOG_LAUNCH("%s<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", dq_dma ? "attn_bwd_dq_dma_kernel" : "attn_bwd_dq_kernel", DH, Bn, p.H, p.T, p.S, p.causal,
                    2.0 * el * (4.0 * p.T + 2.0 * p.S) + 8.0 * Bn * p.H * p.T, 6.0 * Bn * p.H * (double)p.T * p.S * DH);
     if (dkv_dma)
       E4T_LOG_LAUNCH("attn_bwd_dkv_dma_kernel<%d>|B%d H%d T%d S%d causal%d|%.0f|%.0f", DH, Bn, p.H, p.T, p.S, p.causal,
@@ -1629,8 +1738,18 @@ int launch_bwd(AttnArgs p, int Bn, size_t ws_floats, hipStream_t st) {
                      2.0 * el * (2.0 * p.T + 4.0 * p.S) + 8.0 * Bn * p.H * p.T, 8.0 * Bn * p.H * (double)p.T * p.S * DH);
   }
   // dQ first: its prologue also produces Delta (row_delta), which the dK/dV kernel behind it reads
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
-  E4T_CHECK_LAUNCH("attn_bwd_dq_kernel");
+  bool dq_done = false;
+  if constexpr (DH <= 64) {
+    if (dq_dma) {
+      hipLaunchKernelGGL((attn_bwd_dq_dma_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
+      E4T_CHECK_LAUNCH("attn_bwd_dq_dma_kernel");
+      dq_done = true;
+    }
+  }
+  if (!dq_done) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<DH>), dim3(cdiv(p.T, 128), p.H, Bn), dim3(256), 0, st, p);
+    E4T_CHECK_LAUNCH("attn_bwd_dq_kernel");
+  }
   const dim3 gdkv(cdiv(p.S, 128) * p.tsplit, p.H, Bn);
   if constexpr (DH == 40) {
     if (dkv_dma) {
