@@ -551,8 +551,13 @@ class VisionTransformer(nn.Module):
     def forward(self, x):
         x = self.conv1(x)
         x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
-        cls = self.class_embedding[None, None, :].expand(x.shape[0], 1, -1)
-        x = torch.cat([cls, x], dim=1) + self.positional_embedding
+        # open_clip casts both embeddings to the activations' dtype (`self.class_embedding.to(x.dtype) + zeros(..., dtype=x.dtype)`,
+        # `x + self.positional_embedding.to(x.dtype)`): no-ops in fp32 — this oracle — but under torch.autocast(bf16), the calibration leg
+        # of tests/parity_step.py, they are what keeps the residual stream in bf16.  Without them torch.cat([fp32 cls, bf16 x]) promotes
+        # the stream to fp32 for all 32 blocks and the calibration understates the reference's own bf16 error (round 6: the README
+        # recipe's trainable tower, which computes on open_clip's bf16 stream, sat at 0.92 of a bound calibrated on an fp32 stream).
+        cls = self.class_embedding.to(x.dtype)[None, None, :].expand(x.shape[0], 1, -1)
+        x = torch.cat([cls, x], dim=1) + self.positional_embedding.to(x.dtype)
         x = self.transformer(self.ln_pre(x))
         if self.tokens_after_ln_post:
             x = self.ln_post(x)
