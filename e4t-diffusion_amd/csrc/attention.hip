@@ -606,6 +606,9 @@ __device__ __forceinline__ unsigned lds_addr(const bf16_t* p) {
 __device__ __forceinline__ void dma16(const DmaRsrc& rs, unsigned voff, unsigned lds_wave_base_bytes) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave_base_bytes), "v"(voff), "s"(rs.w) : "memory");
 }
+__device__ __forceinline__ void dma4(const DmaRsrc& rs, unsigned voff, unsigned lds_wave_base_bytes) {      // 4 bytes per lane: 256 B per piece
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_wave_base_bytes), "v"(voff), "s"(rs.w) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // this wave's share (two of the eight 1-KB pieces) of a 64-row tile image; the row offset lives in the bounds-checked lane offset
@@ -639,6 +642,22 @@ template <int DH>
 __device__ __forceinline__ void write_key_mask(bf16_t* kimg, int row0, int S) {
   const int r = threadIdx.x & 63;
   *(uint4*)(kimg + img_off<Cfg<DH>::LDE>(r, Cfg<DH>::NCH)) = make_uint4(row0 + r < S ? 0u : 0xC6EAu, 0u, 0u, 0u);
+}
+
+// Pad slots of a freshly landed tile: key-validity column of the K image, ones column of the V image (the DMA zero-fills them).
+// EVERY WAVE WRITES ONLY THE ROWS ITS OWN DMA PIECES COVER (rows [ROWS / 4 * wave, + ROWS / 4) of both images), behind its own vmcnt
+// wait: a pad written into a row whose piece is still in flight from ANOTHER wave is overwritten with zeros when that piece lands
+// (round 6: found as a one-in-hundreds-of-workgroups wrong dK / dV at three workgroups per CU; the same write pattern had been
+// latent here, hidden by the long DMA lead).
+template <int DH, int ROWS>
+__device__ __forceinline__ void fwd64_write_pads(bf16_t* tile, int row0, int S) {
+  constexpr int IMG = ROWS * 64, PER = ROWS / 4;               // rows per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int img = lane / PER, r = PER * wave + lane % PER;      // lanes [0, PER): K image, [PER, 2 PER): V image
+  if (img < 2) {
+    const unsigned w0 = img ? 0x3F80u : (row0 + r < S ? 0u : 0xC6EAu);
+    *(uint4*)(tile + img * IMG + img64_off(r, Cfg<DH>::NCH)) = make_uint4(w0, 0u, 0u, 0u);
+  }
 }
 
 // One phase (see above).  x = the block whose scores sx become P (px); y = the other block: its pending P.V and its next scores.
@@ -687,17 +706,9 @@ __device__ __forceinline__ void fwd64_phase(const f32x2 sc, const FragOff64<DH>&
         A64_FENCE();
       }
       if (LOADS && i == NM - 1 && PADS >= 0 && ATTN64_PROBE != 6 && ATTN64_PROBE != 7) {
-        if (ROWS == 64) {
-          attn_wait_vmcnt<8>();                     // this wave's 4 pieces of the next tile have landed; the two tiles behind it stay in flight
-          const int r = threadIdx.x & 63;
-          *(uint4*)(lds + PADS + img64_off(r, C::NCH)) = make_uint4(pad_row0 + r < S ? 0u : 0xC6EAu, 0u, 0u, 0u);
-          *(uint4*)(lds + PADS + IMG + img64_off(r, C::NCH)) = make_uint4(0x3F80u, 0u, 0u, 0u);
-        } else {                                    // 128-row tiles, two buffers: the next tile (issued one tile ago) is the only one in flight
-          attn_wait_vmcnt<0>();
-          const int r = threadIdx.x & 127;
-          const unsigned w0 = threadIdx.x >= 128 ? 0x3F80u : (pad_row0 + r < S ? 0u : 0xC6EAu);      // K image: validity; V image: 1.0
-          *(uint4*)(lds + PADS + (threadIdx.x >> 7) * IMG + img64_off(r, C::NCH)) = make_uint4(w0, 0u, 0u, 0u);
-        }
+        if (ROWS == 64) attn_wait_vmcnt<8>();      // this wave's 4 pieces of the next tile have landed; the two tiles behind it stay in flight
+        else attn_wait_vmcnt<0>();                  // 128-row tiles, two buffers: the next tile (issued one tile ago) is the only one in flight
+        fwd64_write_pads<DH, ROWS>(lds + PADS, pad_row0, S);
         __syncthreads();                           // the next tile's images are complete; nobody reads the old tile any more
       }
       if (LOADS && i == NM - 1 && (ATTN64_PROBE == 4 || ATTN64_PROBE == 7 || ATTN64_PROBE == 9)) {      // (opaque: the score MFMAs must not become loop-invariant)
@@ -796,10 +807,7 @@ __global__ __launch_bounds__(256, ATTN_FWD64_OCC) void attn_fwd64_kernel(AttnArg
   }
   f32x2 ma = {-1e30f, -1e30f}, mb = ma;      // running row max (log2 units), duplicated for the packed fma
   attn_wait_vmcnt<0>();                           // (one-off; also covers the Q fragments)
-  for (int r = threadIdx.x; r < ROWS; r += 256) {  // tile 0's pad slots (every later tile gets its own at its publishing barrier)
-    *(uint4*)(lds + img64_off(r, C::NCH)) = make_uint4(r < p.S ? 0u : 0xC6EAu, 0u, 0u, 0u);
-    *(uint4*)(lds + IMG + img64_off(r, C::NCH)) = make_uint4(0x3F80u, 0u, 0u, 0u);
-  }
+  fwd64_write_pads<DH, ROWS>(lds, 0, p.S);        // tile 0's pad slots (every later tile gets its own at its publishing barrier)
   __syncthreads();
 #pragma unroll
   for (int ks = 0; ks < C::NKS; ++ks) kfr[ks] = *(const bf16x8*)(lds + fo.row[ks]);
@@ -999,6 +1007,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
 #ifndef ATTN_DQ_DMA
 #define ATTN_DQ_DMA 1
 #endif
+
 template <int DH>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_dma_kernel(AttnArgs p) {
   using C = Cfg<DH>;
@@ -1532,6 +1541,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv64_kernel(AttnArgs p) {
 #ifndef ATTN_DKV_DMA
 #define ATTN_DKV_DMA 1
 #endif
+
 template <int DH>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
   using C = Cfg<DH>;
@@ -1567,14 +1577,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
   const DmaRsrc rsdO = make_dma_rsrc(dOb, (unsigned)(((long long)(p.T - 1) * p.ldo + DH) * 2));
   const DmaRsrc rsLD = make_dma_rsrc(LDb, (unsigned)(p.T * 8));
   qd.init(p.ldq); dod.init(p.ldo);
-  // wave 0 also fetches the tile's 64 {L, Delta} pairs (512 B: lanes 0..31, 16 B each; the other lanes out of range) and turns them
-  // into the folded pad columns; NOTHING in the loop is a compiler-counted VMEM load (see dma16), so the counted waits below are exact:
-  // wave 0 has 5 pieces per tile in flight, the others 4.
-  unsigned svo = lane < 32 ? (unsigned)(lane * 16) : 0x80000000u;
+  // Every wave also fetches the {L, Delta} pairs of ITS 16 query rows of the tile (rows [16 wave, +16): the rows its own tile pieces
+  // cover) as one 4-bytes-per-lane piece — 32 floats = lanes 0..31, the other lanes out of range — into its own 256 bytes of the
+  // slot's statistics area, and turns them into the folded pad columns of exactly those rows behind its own vmcnt wait (a pad written
+  // into a row whose piece another wave still has in flight would be zero-filled again when that piece lands).  NOTHING in the loop is
+  // a compiler-counted VMEM load (see dma16), so the counted waits are exact: 5 pieces per tile and wave.
+  unsigned svo = lane < 32 ? (unsigned)((32 * wave + lane) * 4) : 0x80000000u;
   const unsigned sstep = lane < 32 ? 512u : 0u;
   auto issue_tile = [&](bf16_t* slot) {
     qd.issue(rsQ, slot); dod.issue(rsdO, slot + IMG);
-    if (wave == 0) { dma16(rsLD, svo, __builtin_amdgcn_readfirstlane(lds_addr(slot + 2 * IMG))); svo += sstep; }
+    dma4(rsLD, svo, __builtin_amdgcn_readfirstlane(lds_addr(slot + 2 * IMG) + wave * 256));
+    svo += sstep;
   };
   issue_tile(lds);                                 // tile 0
   issue_tile(lds + TILE);                          // tile 1
@@ -1584,14 +1597,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
   auto tile = [&](auto tb_, int t) __attribute__((always_inline)) {
     constexpr int TB = decltype(tb_)::value;
     constexpr int QI = TB * TILE, DI = QI + IMG, SI = QI + 2 * IMG, NXT = ((TB + 2) % NB) * TILE;      // tile t + 2 goes where tile t - 1 was
-    if (wave == 0) {
-      attn_wait_vmcnt<5>();                        // tile t's pieces (and its statistics) have landed; tile t + 1's stay in flight
-      const float2 ld = *(const float2*)((const float*)(lds + SI) + 2 * lane);
-      const int q = t * 64 + lane;
-      *(uint4*)(lds + QI + img64_off(lane, C::NCH)) = split3_bf16(fmaxf(-(q < p.T ? ld.x : INFINITY) * inv_scale2, -1e30f));
-      *(uint4*)(lds + DI + img64_off(lane, C::NCH)) = split3_bf16(q < p.T ? -ld.y : 0.f);
-    } else {
-      attn_wait_vmcnt<4>();
+    attn_wait_vmcnt<5>();                          // tile t's pieces (and this wave's statistics) have landed; tile t + 1's stay in flight
+    if (lane < 32) {                               // lanes 0..15: Q image pad of row 16 wave + lane; 16..31: dO image pad of the same rows
+      const int r = 16 * wave + (lane & 15);
+      const float2 ld = *(const float2*)((const float*)(lds + SI) + 64 * wave + 2 * (lane & 15));
+      const int q = t * 64 + r;
+      const float x = lane < 16 ? fmaxf(-(q < p.T ? ld.x : INFINITY) * inv_scale2, -1e30f) : (q < p.T ? -ld.y : 0.f);
+      *(uint4*)(lds + (lane < 16 ? QI : DI) + img64_off(r, C::NCH)) = split3_bf16(x);
     }
     __syncthreads();
     issue_tile(lds + NXT);
