@@ -29,7 +29,7 @@ HOT_FLOP_PER_IMAGE = {"sd14": 2.72e12, "sd21": 7.13e12}
 STEP_FLOP_PER_IMAGE = {"sd14": 3.86e12, "sd21": 9.83e12}   # incl. frozen VAE encode + text encoder
 MFMA_PEAK = 2.5e15                                         # bf16 dense, /opt/skills/guides/MI355X_MICROARCH.md
 # the newest round whose counter pass (tools/profile_round.sh) is committed under profiles/
-PROFILE_ROUND = next((r for r in ("r05", "r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_pmc_traffic.csv"))), "r03")
+PROFILE_ROUND = next((r for r in ("r06", "r05", "r04", "r03", "r02") if os.path.exists(os.path.join(ROOT, "profiles", r + "_pmc_traffic.csv"))), "r03")
 HBM_PEAK = 8.0e12                                          # HBM3E spec (6.3e12 achievable), same guide
 
 
