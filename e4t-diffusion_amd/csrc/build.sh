@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../e4t/libe4t_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
-SRCS="core gemm attention norm wo elementwise image"
+SRCS="core gemm attention norm wo elementwise image comm"
 STAMP=obj/.experimental
 mkdir -p obj
 if [ -n "$E4T_EXPERIMENTAL" ]; then
@@ -26,5 +26,5 @@ for f in $SRCS; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC obj/*.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC obj/*.o -ldl -o $OUT
 echo "built $OUT"

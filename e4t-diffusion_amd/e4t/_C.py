@@ -108,12 +108,21 @@ SIGNATURES = {
     "e4t_adamw_rank": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, f32, f32, f32, f32, f32, i32, f32, vp, vp]),
     "e4t_sumsq_partial": (i32, [vp, i64, vp, i32, vp]),
     "e4t_probe_mfma_layout": (i32, [vp, vp, vp]),
+    "e4t_comm_unique_id": (i32, [vp]),
+    "e4t_comm_init": (i32, [C.POINTER(vp), vp, i32, i32]),
+    "e4t_comm_allreduce": (i32, [vp, vp, i64, i32, i32, vp]),
+    "e4t_comm_allgather": (i32, [vp, vp, vp, i64, i32, vp]),
+    "e4t_comm_wait": (i32, [vp, vp]),
+    "e4t_comm_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)]),
+    "e4t_comm_destroy": (i32, [vp]),
 }
 
 # flag / enum mirrors of the header
 OUT_F32, RES_F32, ACT_GELU, ACCUM, REDUCE_BATCH = 1, 2, 4, 8, 16
 CONV_S1, CONV_S2, CONV_UP2, CONV_S2T, CONV_S2A = 1, 2, 3, 4, 5
 WO_STORE_F32, WO_OFFSETS_ONLY = 1, 2
+COMM_F32, COMM_BF16 = 0, 1
+COMM_SUM, COMM_AVG, COMM_MIN, COMM_MAX = 0, 1, 2, 3
 OP_SILU, OP_SILU_BWD, OP_GELU, OP_GELU_BWD, OP_LRELU, OP_LRELU_BWD, OP_QGELU, OP_QGELU_BWD = range(8)
 
 _lib = None

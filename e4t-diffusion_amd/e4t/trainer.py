@@ -104,7 +104,7 @@ class E4TTrainer:
     def __init__(self, unet, e4t_encoder, text_encoder, vae, *, lr=1e-6, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
                  domain_embed_scale=0.1, reg_lambda=0.01, prediction_type="epsilon", class_token_id=0,
                  empty_prompt_ids: Optional[torch.Tensor] = None, process_group=None, device=None, tuning=False,
-                 max_grad_norm: Optional[float] = None, head_factor_exchange=True):
+                 max_grad_norm: Optional[float] = None, head_factor_exchange=True, collectives="torch"):
         self.unet, self.encoder, self.text_encoder, self.vae = unet, e4t_encoder, text_encoder, vae
         # data parallel: all-gather the two small factors of the 129-slot head's weight gradient instead of all-reducing the 845 MB
         # stack (_exchange_head_factors); needs the same per-rank batch size on every rank.  False = the stack rides the all-reduce.
@@ -136,6 +136,15 @@ class E4TTrainer:
         self.world = torch.distributed.get_world_size(process_group) if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         # E4T_FORCE_COMM=1: run the collective path even in a 1-rank group (exercises the RCCL calls / stream ordering on one GPU)
         self._comm = self.world > 1 or (os.environ.get("E4T_FORCE_COMM") == "1" and torch.distributed.is_available() and torch.distributed.is_initialized())
+        # "torch": the gradient collectives are torch.distributed's on `process_group` (the launcher's communicator).  "library": they go
+        # through the C ABI's own RCCL communicator (e4t/comm.py, include/e4t_hip.h e4t_comm_*) on the library's stream — what a host
+        # without torch.distributed calls; the handful of control-plane collectives (batch-size / finiteness flags) stay on the group.
+        if collectives not in ("torch", "library"):
+            raise ValueError(f"collectives={collectives!r}: 'torch' or 'library'")
+        self._lib_comm = None
+        if collectives == "library" and self._comm:
+            from .comm import LibraryComm
+            self._lib_comm = LibraryComm.from_process_group(process_group)
         self.step_count = 0
         self.acp = ddpm_alphas_cumprod(device=self.device)
         self.max_grad_norm = max_grad_norm
@@ -502,7 +511,10 @@ class E4TTrainer:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.comm_timing.setdefault("enqueue", {})["W(factors)"] = ev
-        torch.distributed.all_gather_into_tensor(rows, mine, group=self.pg)
+        if self._lib_comm is not None:
+            self._lib_comm.all_gather_into_tensor(rows, mine).wait()      # the stream is ordered after it before `mine` can be recycled
+        else:
+            torch.distributed.all_gather_into_tensor(rows, mine, group=self.pg)
         self._done.add("W")
         self._factor_bytes = mine.numel() * mine.element_size()
         return rows[:, :w], rows[:, w:]
@@ -534,7 +546,18 @@ class E4TTrainer:
         g = self.flat.grad
         bucket = 64 << 20          # 256 MB fp32: xGMI rings are per-link bound, large buckets run them at rate
         for o in range(a, b, bucket):
-            self._works.append((key, torch.distributed.all_reduce(g[o:min(o + bucket, b)], group=self.pg, async_op=True)))
+            self._works.append((key, self._all_reduce(g[o:min(o + bucket, b)], async_op=True)))
+
+    def _all_reduce(self, t, async_op=False):
+        """SUM all-reduce of a slice of the flat gradient on the configured back end; async_op: a handle whose wait() orders the current
+        stream after it"""
+        if self._lib_comm is None:
+            return torch.distributed.all_reduce(t, group=self.pg, async_op=async_op)
+        h = self._lib_comm.all_reduce(t)
+        if async_op:
+            return h
+        h.wait()
+        return None
 
     def all_reduce_grads(self, defer=None):
         """Wait for the regions' all-reduces (enqueueing whatever no hook announced).  `defer` names ONE region whose handles are not
@@ -546,7 +569,7 @@ class E4TTrainer:
             g = self.flat.grad
             bucket = 64 << 20
             for o in range(0, g.numel(), bucket):
-                torch.distributed.all_reduce(g[o:o + bucket], group=self.pg)
+                self._all_reduce(g[o:o + bucket])
             return None
         for key in ("U", "W", "H", "D", "T"):      # whatever was not triggered during the backward
             if self.regions[key][1] > self.regions[key][0]:
@@ -642,6 +665,8 @@ class E4TTrainer:
     def enable_step_graph(self, on=True):
         if on and (not self.flat.data.is_cuda or self.text_trainable or self._graph_failed):
             return False
+        if on and self._lib_comm is not None:
+            return False          # the library's collective stream is not a torch stream: its work is not captured with the step
         self._step_graph_on = bool(on)
         if on and self._hyper is None:
             # allocated once and kept for the trainer's lifetime: captured graphs hold its raw pointer
@@ -813,6 +838,13 @@ class E4TTrainer:
         dev = self.device
         cur = torch.cuda.current_stream(dev)
         cands = [cur] + [torch.cuda.Stream(device=dev) for _ in range(5)]
+        if self._lib_comm is not None:
+            # the library's collective stream is known: ask the hardware-queue question directly, no collective involved
+            ext = torch.cuda.ExternalStream(self._lib_comm.stream_handle(), device=dev)
+            found = [_runs_beside(c, ext, dev) for c in cands]
+            self.stream_probe = found
+            self._train_stream = None if (found[0] or not any(found)) else cands[found.index(True)]
+            return self._train_stream
         src = torch.ones(1024, device=dev)
         dst = torch.empty(self.world * 1024, device=dev)
         torch.distributed.all_gather_into_tensor(dst, src, group=self.pg)          # the communicator's lazy set-up is not part of the probe

@@ -297,6 +297,30 @@ int e4t_adamw_rank(float* p, float* m, float* v, const void* G, const void* Z, i
                    e4t_stream stream);
 int e4t_sumsq_partial(const float* g, long long n, float* partial, int nblocks, e4t_stream stream);                      /* tuning_e4t.py:335 grad-norm */
 
+/* ---------------------------------------------------------------- data-parallel collectives (comm.hip) ---------- */
+/* An RCCL communicator owned by the library, for a host that does not bring torch.distributed: replaces the DDP reducer accelerate wraps
+ * the reference's models with (pretrain_e4t.py:410-412 `accelerator.prepare`, :648 `accelerator.backward`; tuning_e4t.py:197-200, :328).
+ * Collectives run IN PLACE on a library-owned high-priority stream: each call first orders that stream after everything queued so far on
+ * the caller's `stream` (the kernels that produced the buffer), and returns without waiting; e4t_comm_wait(comm, stream) makes `stream`
+ * wait — on the device, no host sync — for every collective issued so far.  One communicator per process (= per GPU); calls on one
+ * communicator come from one host thread.  librccl.so is resolved at first use from the copy already mapped into the process (torch's),
+ * else loaded by name (E4T_RCCL_LIB overrides); without one every e4t_comm_* call returns -38.  The Python host in this repository
+ * uses torch.distributed by default and this path with E4TTrainer(collectives="library"). */
+typedef struct e4t_comm* e4t_comm_t;
+#define E4T_COMM_F32 0
+#define E4T_COMM_BF16 1
+#define E4T_COMM_SUM 0
+#define E4T_COMM_AVG 1
+#define E4T_COMM_MIN 2
+#define E4T_COMM_MAX 3
+int e4t_comm_unique_id(void* id128);                 /* rank 0: 128 bytes the launcher hands to every rank (ncclGetUniqueId) */
+int e4t_comm_init(e4t_comm_t* comm, const void* id128, int rank, int world);   /* collective over all ranks; current HIP device */
+int e4t_comm_allreduce(e4t_comm_t comm, void* buf, long long count, int dtype, int op, e4t_stream stream);
+int e4t_comm_allgather(e4t_comm_t comm, const void* send, void* recv /* world * count */, long long count, int dtype, e4t_stream stream);
+int e4t_comm_wait(e4t_comm_t comm, e4t_stream stream);
+int e4t_comm_info(e4t_comm_t comm, int* rank, int* world, e4t_stream* comm_stream);
+int e4t_comm_destroy(e4t_comm_t comm);
+
 /* ---------------------------------------------------------------- probe (probe.hip) ---------- */
 /* writes, for lane l and register r of v_mfma_f32_32x32x16_bf16 with A[i][k] = i*16+k... see probe.hip */
 int e4t_probe_mfma_layout(float* out_rows /* [64][16] */, float* out_cols /* [64][16] */, e4t_stream stream);

@@ -16,7 +16,7 @@ for p in (os.path.join(ROOT, "e4t-diffusion_amd"), ROOT, HERE, os.path.join(ROOT
         sys.path.insert(0, p)
 
 
-def run(dev, comm, tuning, steps=3):
+def run(dev, comm, tuning, steps=3, collectives="torch"):
     from test_train_step_host_logic import TEXT_CFG, build
     from e4t.text import CLIPTextModel
     from e4t.trainer import E4TTrainer
@@ -26,8 +26,8 @@ def run(dev, comm, tuning, steps=3):
     text.load_state_dict(text_t.state_dict())
     n_unet.to(dev), n_enc.to(dev), text.to(dev)
     tr = E4TTrainer(n_unet, n_enc, text, vae=None, lr=1e-3, class_token_id=11, empty_prompt_ids=torch.zeros(1, 9, dtype=torch.long, device=dev),
-                    device=dev, tuning=tuning, max_grad_norm=1.0 if tuning else None)
-    assert tr._comm == comm and (tr.regions is not None) == comm
+                    device=dev, tuning=tuning, max_grad_norm=1.0 if tuning else None, collectives=collectives)
+    assert tr._comm == comm and (tr.regions is not None) == comm and (tr._lib_comm is not None) == (comm and collectives == "library")
     log = []
     if comm:
         orig = tr._reduce_region
@@ -88,6 +88,53 @@ def run_graph(dev, comm, graph, steps=4, hop=False):
     return torch.stack(losses), tr.flat.data.detach().cpu().clone(), (len(tr._step_graphs), tr._graph_failed)
 
 
+def library_comm(dev):
+    """the C ABI's own communicator (include/e4t_hip.h e4t_comm_*): the collectives themselves, their ordering against the compute
+    stream, and the trainer with collectives="library" against the no-communication run"""
+    from e4t.comm import LibraryComm
+    from e4t import _C
+    c = LibraryComm.from_process_group(None)
+    assert (c.rank, c.world) == (0, 1) and c.stream_handle() != 0
+    # ordering: the buffer's producer is still running on the compute stream when the all-reduce is issued; the consumer is queued after wait()
+    x = torch.zeros(1 << 24, device=dev)
+    torch.cuda._sleep(20_000_000)
+    x.add_(3.0)
+    h = c.all_reduce(x)                                    # 1 rank: sum = identity
+    h.wait()
+    y = x * 2
+    assert float(y.min()) == 6.0 and float(y.max()) == 6.0
+    for op in ("avg", "min", "max"):
+        c.all_reduce(x, op).wait()
+    assert float(x.min()) == 3.0 and float(x.max()) == 3.0
+    b = torch.randn(5, 1280, device=dev).bfloat16()
+    out = torch.empty(5, 1280, device=dev, dtype=torch.bfloat16)
+    c.all_gather_into_tensor(out, b).wait()
+    assert torch.equal(out, b)
+    for bad, kw in ((torch.zeros(4, device=dev, dtype=torch.int32), {}), (torch.zeros(4), {}), (x[::2], {})):
+        try:
+            c.all_reduce(bad, **kw)
+            raise AssertionError("accepted")
+        except ValueError:
+            pass
+    lib = _C.load()
+    assert lib.e4t_comm_allreduce(c._h, x.data_ptr(), 4, 7, 0, None) == -22 and b"dtype" in lib.e4t_last_error()
+    assert lib.e4t_comm_allreduce(None, x.data_ptr(), 4, 0, 0, None) == -22
+    c.close()
+    try:
+        c.all_reduce(x)
+        raise AssertionError("closed communicator accepted a collective")
+    except _C.E4TError:
+        pass
+    print("rccl one-rank, library communicator: all-reduce / all-gather ordered against the compute stream, argument errors refused")
+    for tuning in (False, True):
+        l0, p0, _ = run(dev, comm=False, tuning=tuning)
+        l1, p1, log = run(dev, comm=True, tuning=tuning, collectives="library")
+        assert torch.equal(l0, l1), (tuning, l0, l1)
+        assert torch.equal(p0, p1), (tuning, float((p0 - p1).abs().max()))
+        assert log == [("U", False), ("H", False), ("D", False), ("U", False), ("W", False), ("H", False), ("D", False)], log
+        print(f"rccl one-rank {'tuning' if tuning else 'pretrain'}, collectives='library': {p0.numel()} parameters bit-identical with / without the collective path")
+
+
 def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -115,6 +162,7 @@ def main():
     assert torch.equal(l0, l1), (l0, l1)
     assert torch.equal(p0, p1), float((p0 - p1).abs().max())
     print("rccl one-rank, the step on a stream of the trainer's: bit-identical to the eager no-comm run")
+    library_comm(dev)
     dist.barrier()
     dist.destroy_process_group()
     print("RCCL_ONE_RANK_OK")

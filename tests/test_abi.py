@@ -115,3 +115,27 @@ def test_integration_md_gemm_desc_example_has_the_c_layout(tmp_path):
     assert int(got["sizeof"]) == C.sizeof(doc), (got["sizeof"], C.sizeof(doc))
     for f, _ in doc._fields_:
         assert int(got[f]) == getattr(doc, f).offset, f
+
+
+def test_comm_entry_points_fail_cleanly_without_a_gpu():
+    """e4t_comm_* (csrc/comm.hip): RCCL is resolved at first use, not linked; with no device the calls return an error code and a message"""
+    import ctypes as C
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    lib = _C.load()
+    buf = C.create_string_buffer(128)
+    rc = lib.e4t_comm_unique_id(buf)          # torch's RCCL answers without a device, ROCm's own does not: either is fine
+    assert rc == 0 or lib.e4t_last_error()
+    if rc == 0:
+        h0 = _C.vp()
+        assert lib.e4t_comm_init(C.byref(h0), buf, 0, 1) < 0 and lib.e4t_last_error() and not h0.value
+    assert lib.e4t_comm_unique_id(None) == -22
+    h = _C.vp()
+    assert lib.e4t_comm_init(C.byref(h), buf, 2, 2) == -22 and b"rank 2 of world 2" in lib.e4t_last_error()
+    assert lib.e4t_comm_allreduce(None, None, 0, 0, 0, None) == -22
+    assert lib.e4t_comm_wait(None, None) == -22
+    assert lib.e4t_comm_destroy(None) == 0
+    import subprocess, sys
+    out = subprocess.run(["ldd", _C.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in out, out          # not a link dependency

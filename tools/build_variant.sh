@@ -9,8 +9,8 @@ mkdir -p ../e4t/variants obj
 [ -f obj/core.o ] || bash build.sh
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result $EXTRA -c $UNIT.hip -o /tmp/variant_${NAME}_$UNIT.o
 OBJS=""
-for f in core gemm attention norm wo elementwise image; do
+for f in core gemm attention norm wo elementwise image comm; do
   if [ $f = $UNIT ]; then OBJS="$OBJS /tmp/variant_${NAME}_$UNIT.o"; else OBJS="$OBJS obj/$f.o"; fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o ../e4t/variants/libe4t_hip_$NAME.so
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -ldl -o ../e4t/variants/libe4t_hip_$NAME.so
 echo "built e4t/variants/libe4t_hip_$NAME.so"
