@@ -145,7 +145,28 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 #define ATTN_PACKED 1
 #endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// Packed fp32 VALU (v_pk_fma_f32 / v_pk_mul_f32) beside MFMAs: measured per kernel (round 6, tools/ab_attn_all.py, one box).  In the
+// DMA-staged dh-40 kernels it costs MORE than the two scalar ops it replaces (forward 471 -> 445 us, backward 1564 -> 1533 us); the
+// register-staged kernels (3 waves per SIMD at dh <= 64, the dh-80 / 160 ones) run 2-3 % faster WITH it.  So the pair helpers take the
+// choice as a template argument (ATTN_PK_OLD / ATTN_PK_DMA, 0 / 1, for the A/B), and the file is compiled with
+// -fno-slp-vectorize so that the compiler packs nothing on its own.
+#ifndef ATTN_PK_OLD
+#define ATTN_PK_OLD 1
+#endif
+#ifndef ATTN_PK_DMA
+#define ATTN_PK_DMA 0
+#endif
+template <bool PK>
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  if constexpr (PK) return __builtin_elementwise_fma(a, b, c);
+  else return f32x2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
+}
+template <bool PK>
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+  if constexpr (PK) return a * b;
+  else return f32x2{a.x * b.x, a.y * b.y};
+}
+
 
 // element offset of the logical 16-byte slot L of tile row r in a swizzled LDS image (see Cfg)
 template <int LDE>
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 4 : DH <= 80 ? 2 : 1)) void attn_f
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         if (ATTN_PACKED && ATTN_PROBE == 0) {
-          const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-m, -m});
+          const f32x2 t = pk_fma<ATTN_PK_OLD>(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-m, -m});
           pr[r] = fast_exp2(t.x); pr[r + 1] = fast_exp2(t.y);
         } else {
 #pragma unroll
@@ -553,9 +574,17 @@ struct TileRegsV {
 
 // s * sc - mm on two adjacent score elements as ONE packed VALU instruction (the compiler scalarises the builtin form in most
 // chunks of the phase below: +1 VALU and a hazard nop each)
+#ifndef ATTN64_SCALAR_FMA
+#define ATTN64_SCALAR_FMA (!ATTN_PK_DMA)
+#endif
 __device__ __forceinline__ f32x2 pk_fms(f32x2 s, f32x2 sc, f32x2 mm) {
   f32x2 d;
+#if ATTN64_SCALAR_FMA
+  asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(d.x) : "v"(s.x), "s"(sc.x), "v"(mm.x));
+  asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(d.y) : "v"(s.y), "s"(sc.x), "v"(mm.x));
+#else
   asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(s), "s"(sc), "v"(mm));
+#endif
   return d;
 }
 
@@ -751,7 +780,7 @@ __device__ __forceinline__ void fwd64_phase(const f32x2 sc, const FragOff64<DH>&
       for (int r = 0; r < 16; ++r) ox[dt][r] *= alpha;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const f32x2 u = pk_fma(f32x2{sx[2 * c], sx[2 * c + 1]}, sc, -mm);
+      const f32x2 u = pk_fma<ATTN_PK_DMA>(f32x2{sx[2 * c], sx[2 * c + 1]}, sc, -mm);
       px[c >> 2].w[c & 3] = pack2bf(fast_exp2(u.x), fast_exp2(u.y));
     }
   }
@@ -968,9 +997,9 @@ __global__ __launch_bounds__(256, (DH <= 64 ? 3 : DH <= 80 ? 2 : 1)) void attn_b
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           if (ATTN_PACKED && DH <= 48) {      // (dh 64 would spill)
-            const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-Lq, -Lq});
-            const f32x2 d = pk_fma(f32x2{Dq, Dq}, f32x2{-1.f, -1.f}, f32x2{dp[r], dp[r + 1]});      // dp - Dq, kept packed
-            const f32x2 o2 = f32x2{fast_exp2(t.x), fast_exp2(t.y)} * d;
+            const f32x2 t = pk_fma<ATTN_PK_OLD>(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-Lq, -Lq});
+            const f32x2 d = pk_fma<ATTN_PK_OLD>(f32x2{Dq, Dq}, f32x2{-1.f, -1.f}, f32x2{dp[r], dp[r + 1]});      // dp - Dq, kept packed
+            const f32x2 o2 = pk_mul<ATTN_PK_OLD>(f32x2{fast_exp2(t.x), fast_exp2(t.y)}, d);
             ds[r] = o2.x; ds[r + 1] = o2.y;
           } else {
             ds[r] = fast_exp2(s[r] * p.scale2 - Lq) * (dp[r] - Dq);
@@ -1079,9 +1108,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_dma_kernel(AttnArgs p) {
       } else {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2 t2 = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-Lq, -Lq});
-          const f32x2 d = pk_fma(f32x2{Dq, Dq}, f32x2{-1.f, -1.f}, f32x2{dp[r], dp[r + 1]});      // dp - Dq, kept packed
-          const f32x2 o2 = f32x2{fast_exp2(t2.x), fast_exp2(t2.y)} * d;
+          const f32x2 t2 = pk_fma<ATTN_PK_DMA>(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-Lq, -Lq});
+          const f32x2 d = pk_fma<ATTN_PK_DMA>(f32x2{Dq, Dq}, f32x2{-1.f, -1.f}, f32x2{dp[r], dp[r + 1]});      // dp - Dq, kept packed
+          const f32x2 o2 = pk_mul<ATTN_PK_DMA>(f32x2{fast_exp2(t2.x), fast_exp2(t2.y)}, d);
           ds[r] = o2.x; ds[r + 1] = o2.y;
         }
       }
@@ -1225,9 +1254,9 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
       if (FOLD && ATTN_PROBE == 0) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-          const f32x2 t = f32x2{s[r], s[r + 1]} * f32x2{p.scale2, p.scale2};
+          const f32x2 t = pk_mul<ATTN_PK_OLD>(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2});
           const f32x2 e2 = f32x2{fast_exp2(t.x), fast_exp2(t.y)};
-          const f32x2 o2 = e2 * f32x2{dp[r], dp[r + 1]};
+          const f32x2 o2 = pk_mul<ATTN_PK_OLD>(e2, f32x2{dp[r], dp[r + 1]});
           pr[r] = e2.x; pr[r + 1] = e2.y; ds[r] = o2.x; ds[r + 1] = o2.y;
         }
       } else
@@ -1240,10 +1269,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_dkv_kernel(AttnArgs p) {
         for (int j = 0; j < 4; j += 2) {
           const int r = 4 * g + j;
           if (ATTN_PACKED && ATTN_PROBE == 0) {
-            const f32x2 t = pk_fma(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-lq[j], -lq[j + 1]});
-            const f32x2 d = pk_fma(f32x2{dq[j], dq[j + 1]}, f32x2{-1.f, -1.f}, f32x2{dp[r], dp[r + 1]});      // dp - dq, kept packed
+            const f32x2 t = pk_fma<ATTN_PK_OLD>(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2}, f32x2{-lq[j], -lq[j + 1]});
+            const f32x2 d = pk_fma<ATTN_PK_OLD>(f32x2{dq[j], dq[j + 1]}, f32x2{-1.f, -1.f}, f32x2{dp[r], dp[r + 1]});      // dp - dq, kept packed
             const f32x2 e2 = f32x2{fast_exp2(t.x), fast_exp2(t.y)};
-            const f32x2 o2 = e2 * d;
+            const f32x2 o2 = pk_mul<ATTN_PK_OLD>(e2, d);
             pr[r] = e2.x; pr[r + 1] = e2.y; ds[r] = o2.x; ds[r + 1] = o2.y;
           } else {
 #pragma unroll
@@ -1397,7 +1426,7 @@ __device__ __forceinline__ void dkv64_phase(const float scale2, const float inv_
       const f32x2 t = pk_mul_s(f32x2{sx[2 * c], sx[2 * c + 1]}, sc);
       e0 = fast_exp2(t.x); e1 = fast_exp2(t.y);
     } else {
-      const f32x2 d2 = f32x2{e0, e1} * f32x2{dpx[2 * c], dpx[2 * c + 1]};
+      const f32x2 d2 = pk_mul<ATTN_PK_DMA>(f32x2{e0, e1}, f32x2{dpx[2 * c], dpx[2 * c + 1]});
       pfx[c >> 2].w[c & 3] = pack2bf(e0, e1);
       sfx[c >> 2].w[c & 3] = pack2bf(d2.x, d2.y);
     }
@@ -1620,9 +1649,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
       float pr[16], ds[16];
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const f32x2 t2 = f32x2{s[r], s[r + 1]} * f32x2{p.scale2, p.scale2};
+        const f32x2 t2 = pk_mul<ATTN_PK_DMA>(f32x2{s[r], s[r + 1]}, f32x2{p.scale2, p.scale2});
         const f32x2 e2 = f32x2{fast_exp2(t2.x), fast_exp2(t2.y)};
-        const f32x2 o2 = e2 * f32x2{dp[r], dp[r + 1]};
+        const f32x2 o2 = pk_mul<ATTN_PK_DMA>(e2, f32x2{dp[r], dp[r + 1]});
         pr[r] = e2.x; pr[r + 1] = e2.y; ds[r] = o2.x; ds[r + 1] = o2.y;
       }
       const bf16x8 pf0 = pack_acc(pr, 0), pf1 = pack_acc(pr, 1);

@@ -21,6 +21,7 @@ for f in $SRCS; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || { [[ $f == gemm* ]] && [ gemm_common.h -nt obj/$f.o ]; } || [ ../../include/e4t_hip.h -nt obj/$f.o ]; then
     EXTRA=""
     [ $f = image ] && EXTRA="-ffp-contract=off"      # byte-exact INTER_AREA: float ops must not be fused (see image.hip)
+    [ $f = attention ] && EXTRA="-fno-slp-vectorize" # packed fp32 VALU beside MFMAs is slower than the scalar pair (attention.hip: ATTN_PK)
     hipcc $FLAGS $EXTRA -c $f.hip -o obj/$f.o &
     pids+=($!)
   fi
