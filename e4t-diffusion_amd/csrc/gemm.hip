@@ -240,10 +240,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : 1) vo
   __shared__ __attribute__((aligned(16))) bf16_t smem[NSTAGE * TILE];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (an SGPR: the DMA destinations are wave-uniform)
   const int wm = wave / WGN, wn = wave % WGN;
   // B pieces this wave issues per K-tile (wave-uniform): NB, or fewer in the last wave(s) of a ragged split
-  const int nbw = RAGGED_B ? min(NB, max(0, BN / RPP - __builtin_amdgcn_readfirstlane(wave) * NB)) : NB;
+  const int nbw = RAGGED_B ? min(NB, max(0, BN / RPP - wave * NB)) : NB;
   int tile_x, tile_y;
   xcd_tile(tile_x, tile_y, p.group_m);
   const int m0 = tile_y * BM, n0 = tile_x * BN;
