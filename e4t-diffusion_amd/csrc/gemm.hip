@@ -217,7 +217,9 @@ __device__ unsigned long long g_dma_trace[128 * 16];
 // (48 KiB) instead of 1 (32 KiB) in flight per workgroup.  The cycle-stamp trace (tools/dma_trace.sh) shows the K loop of every
 // shape waiting ~1700-2500 cycles per 64-wide tile for a DMA issued one iteration earlier against ~500 cycles of MFMA work.
 template <int BM, int BN, int WGM, int WGN, int MODE, int NSTAGE, bool GENERAL = false, int KT = 64>
-__global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : 1) void gemm_dma_kernel(GemmArgs p) {
+// (second argument = waves per SIMD the register allocation must leave room for: the 2-stage 128 x 160 tile runs TWO 4-wave workgroups per CU — at 260
+// registers instead of 256 it ran one, 40 % slower: M16384 N640 K640 22.8 -> 31.9 us, round 6)
+__global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : (BN == 160 ? 2 : 1)) void gemm_dma_kernel(GemmArgs p) {
 #ifdef DMA_TRACE
   const int dt_lin = blockIdx.y * gridDim.x + blockIdx.x;
   const int dt_wg = dt_lin >> 3;
