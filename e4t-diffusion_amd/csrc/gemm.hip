@@ -516,6 +516,149 @@ __global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : (BN =
 #endif
   DT(12);
 }
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution on 256-pixel ROW SEGMENTS, the A operand staged as STRIPS (round 6; the VAE's 128-channel level).
+//
+// gemm_dma_kernel<256, 128, ..., 32> fetches a 256-pixel x 32-channel A tile per (tap, channel chunk): the three taps of one kernel
+// row read the SAME pixels shifted by one, three times through the CU's fill path (a timing probe that let two of three taps fetch
+// nothing ran the 128 -> 128 conv at 512 x 512 in 1223 instead of 1430 us).  When a tile is 256 consecutive pixels of ONE image row
+// (W % 256 == 0), the pixels x0 - 1 .. x0 + 256 of input row y + ky - 1 are staged ONCE per (ky, chunk) — a strip of 258 rows x 64
+// bytes — and the taps kx = 0, 1, 2 read it at row offsets 0, 1, 2: the fragment read of output pixel r for tap kx is strip row
+// r + kx (any 16 consecutive rows of the (r >> 2) & 3 slot swizzle are conflict-free, so the shift costs nothing in LDS).  A-side fill
+// bytes and DMA instructions per MFMA drop 3 x / 2 x; the B side (weights, one 128 x 32 tile per tap and chunk) is unchanged.
+//   LDS: two strip buffers of 24 pieces (384 rows; rows beyond 257 and pixels outside the image carry the out-of-range offset and
+//   fetch nothing) + three B buffers = 72 KB, two workgroups per CU, the epilogue staging of gemm_dma_kernel on top of it.
+//   Order of the K walk: ky, channel chunk, kx (B follows: column (3 ky + kx) Cin + 32 chunk): only the fp32 summation order differs.
+//   Pipeline: sub-step j = (strip s, kx) issues B(j + 2) and, at kx = 0, strip s + 1; per wave 3 strip pieces + 1 B piece, so the
+//   counted waits are vmcnt(1) / (4) / (1) for kx = 0 / 1 / 2 (what may still be in flight behind the B tile — and strip — the sub-step
+//   needs), one barrier per sub-step as in the tile kernel.
+// ------------------------------------------------------------------------------------------------
+#ifndef CONV_STRIP
+#define CONV_STRIP 1
+#endif
+__global__ __launch_bounds__(512, 4) void conv_strip_kernel(GemmArgs p) {
+  constexpr int BN = 128, KT = 32, WGN = 2, WM = 64, WN = 64, FM = 2, FN = 2;
+  constexpr int ASZ = 384 * KT, BSZ = BN * KT;                       // elements per strip / B buffer
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * ASZ + 3 * BSZ];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  int tile_x, tile_y;
+  xcd_tile(tile_x, tile_y, p.group_m);
+  const int m0 = tile_y * 256, n0 = tile_x * BN;
+  const int hw = p.Hin * p.Win;
+  const int b = m0 / hw, rem = m0 - b * hw, y = rem / p.Win, x0 = rem - y * p.Win;
+  const int ncc = p.Cin / KT, nstrip = 3 * ncc, nsub = 3 * nstrip;
+  constexpr unsigned OOB = 0xFFFF0000u;
+  auto swz = [](int r) { return (r >> 2) & 3; };
+
+  const __amdgpu_buffer_rsrc_t rs_a = cm_rsrc(p);                   // base lowered by one image row + one pixel (never touched: masked lanes)
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+  // strip pieces of this wave: piece q = wave + 8 i covers strip rows 16 q .. 16 q + 15; strip row j = input pixel x0 - 1 + j
+  unsigned a_vo[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = 16 * (wave + 8 * i) + (lane >> 2), ix = x0 - 1 + j;
+    const bool ok = j < 258 && ix >= 0 && ix < p.Win;
+    a_vo[i] = ok ? (unsigned)((j * p.Cin + ((lane & 3) ^ swz(j)) * 8) * 2) : OOB;
+  }
+  unsigned b_vo;
+  {
+    const int r = 16 * wave + (lane >> 2);
+    b_vo = n0 + r < p.N ? (unsigned)((((size_t)(n0 + r)) * p.ldb + ((lane & 3) ^ swz(r)) * 8) * 2) : OOB;
+  }
+  // walkers (incremental: no division per issue)
+  int a_ky = 0, a_cc = 0;                        // next strip to issue
+  int b_ky = 0, b_cc = 0, b_kx = 0;              // next B tile to issue
+  auto issue_a = [&](bf16_t* buf) __attribute__((always_inline)) {
+    const int iy = y + a_ky - 1;
+    const bool vy = iy >= 0 && iy < p.Hin;
+    // ((b H + iy) W + x0 - 1) Cin + 32 cc, against the lowered base: + (W + 1) Cin  ->  ((b H + iy + 1) W + x0) Cin + 32 cc  >= 0
+    const int so = __builtin_amdgcn_readfirstlane((int)(((((long long)b * p.Hin + iy + 1) * p.Win + x0) * p.Cin + a_cc * KT) * 2));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) buf_dma16(rs_a, vy ? a_vo[i] : OOB, so, buf + (wave + 8 * i) * 512);
+    if (++a_cc == ncc) { a_cc = 0; ++a_ky; }
+  };
+  auto issue_b = [&](bf16_t* buf) __attribute__((always_inline)) {
+    const int so = __builtin_amdgcn_readfirstlane((((b_ky * 3 + b_kx) * p.Cin) + b_cc * KT) * 2);
+    buf_dma16(rs_b, b_vo, so, buf + wave * 512);
+    if (++b_kx == 3) { b_kx = 0; if (++b_cc == ncc) { b_cc = 0; ++b_ky; } }
+  };
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int frow = lane & 31, fhi = lane >> 5;
+  int a_off[3][FM][2], b_off[FN][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int r = wm * WM + i * 32 + frow + kx;
+        a_off[kx][i][ks] = r * KT + (((ks * 2 + fhi) ^ swz(r)) * 8);
+      }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int r = wn * WN + j * 32 + frow;
+      b_off[j][ks] = r * KT + (((ks * 2 + fhi) ^ swz(r)) * 8);
+    }
+  }
+  bf16_t* const Bs = smem + 2 * ASZ;
+  issue_a(smem);                                 // strip 0
+  issue_b(Bs);                                   // B(0), B(1)
+  issue_b(Bs + BSZ);
+
+  auto sub = [&](auto par_, auto kx_, int s) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_)::value, KX = decltype(kx_)::value;
+    const int j = 3 * s + KX;
+    if (s + 1 == nstrip && KX > 0) wait_vmcnt<0>();          // the last strip: nothing (or one B tile) behind the one needed
+    else if (KX == 1) wait_vmcnt<4>();                        // strip s + 1 (3 pieces) and B(j + 1) may still fly
+    else wait_vmcnt<1>();                                     // B(j + 1) may
+    loop_barrier();
+    if (KX == 0 && s + 1 < nstrip) issue_a(smem + (PAR ^ 1) * ASZ);
+    if (j + 2 < nsub) issue_b(Bs + ((KX + 2) % 3) * BSZ);
+    const bf16_t* sa = smem + PAR * ASZ;
+    const bf16_t* sb = Bs + KX * BSZ;
+    bf16x8 af[2][FM], bfr[2][FN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[ks][i] = *(const bf16x8*)(sa + a_off[KX][i][ks]);
+#pragma unroll
+      for (int jj = 0; jj < FN; ++jj) bfr[ks][jj] = *(const bf16x8*)(sb + b_off[jj][ks]);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < FN; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][jj], acc[i][jj], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  for (int s = 0; s < nstrip; s += 2) {
+    sub(I0{}, I0{}, s); sub(I0{}, I1{}, s); sub(I0{}, I2{}, s);
+    if (s + 1 < nstrip) { sub(I1{}, I0{}, s + 1); sub(I1{}, I1{}, s + 1); sub(I1{}, I2{}, s + 1); }
+  }
+  __syncthreads();   // all fragment reads done before the epilogue reuses the LDS
+  write_tile<WM, WN, FM, FN, false>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
+}
+// may a 256 x 128 x 32 conv launch go to conv_strip_kernel?
+static bool conv_strip_ok(const GemmArgs& p, int splitk, int batch) {
+  static const bool on = CONV_STRIP && getenv("E4T_CONV_NOSTRIP") == nullptr;          // A/B switch
+  return on && p.mode == E4T_CONV_S1 && p.chan_major && splitk == 1 && batch == 1 && p.Win % 256 == 0 && p.Wout == p.Win && p.Hout == p.Hin &&
+         p.Cin % 32 == 0 && p.K == 9 * p.Cin;
+}
+
 #ifdef DMA_TRACE
 }  // namespace
 extern "C" int e4t_debug_dma_trace(unsigned long long* out) {
@@ -1950,7 +2093,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                                                    : (conv ? (p.chan_major ? "gemm_pp_kernel<1, false, true>" : "gemm_pp_kernel<1, false, false>") : "gemm_pp_kernel<0, false, false>"))
                       : tile == 640 ? (conv ? "gemm_pt_kernel<1>" : "gemm_pt_kernel<0>")
                       : tile == 256 && !kt32 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 64>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 64>")
-                      : tile == 256 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>")
+                      : tile == 256 ? (conv ? (conv_strip_ok(p, splitk, batch) ? "conv_strip_kernel" : "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>")
+                                            : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>")
                       : nullptr;
     char symbuf[64];
     if (!sym && tile >= 2000) {
@@ -2007,7 +2151,8 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
 #endif
     } else if (tile == 256 && kt32) {
       block = dim3(512);       // experimental (5256): 256 x 128 with 32-wide K-tiles, 3 x 24 KiB stages = two workgroups per CU
-      if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>), grid, block, 0, st, p);
+      if (conv && conv_strip_ok(p, splitk, batch)) hipLaunchKernelGGL(conv_strip_kernel, grid, block, 0, st, p);
+      else if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>), grid, block, 0, st, p);
 #ifdef E4T_EXPERIMENTAL
     } else if (tile == 256) {

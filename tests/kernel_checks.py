@@ -227,6 +227,10 @@ def check_conv(hip, emu, dev):
         (4, 32, 32, 320, 320, CONV_S1, 32, 32, 2320, 1), (2, 16, 16, 256, 640, CONV_S1, 16, 16, 2320, 2), (2, 8, 8, 128, 320, CONV_S2T, 16, 16, 2320, 1),
         (3, 16, 16, 64, 320, CONV_S2, 8, 8, 2320, 1), (2, 8, 8, 64, 320, CONV_UP2, 16, 16, 2320, 1),
         (16, 64, 64, 64, 320, CONV_S1, 64, 64, 2320, 1),
+        # round 6: conv_strip_kernel (stride 1, W % 256 == 0, the 256 x 128 x 32 tile): image borders in both directions, several 256-pixel
+        # segments per row, one-row images, Cout beyond one column tile, batch crossing
+        (2, 6, 256, 64, 128, CONV_S1, 6, 256, 5256, 1), (1, 3, 768, 192, 256, CONV_S1, 3, 768, 5256, 1), (3, 1, 256, 64, 128, CONV_S1, 1, 256, 5256, 1),
+        (2, 5, 512, 128, 128, CONV_S1, 5, 512, 0, 0),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
         if not _product_tile(hip, tile):
