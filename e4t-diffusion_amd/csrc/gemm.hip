@@ -537,8 +537,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, (BM == 256 && KT == 32) ? 4 : (BN =
 #ifndef CONV_STRIP
 #define CONV_STRIP 1
 #endif
-__global__ __launch_bounds__(512, 4) void conv_strip_kernel(GemmArgs p) {
-  constexpr int BN = 128, KT = 32, WGN = 2, WM = 64, WN = 64, FM = 2, FN = 2;
+// WGN = 2: 256 x 128 tile, 8 waves, two workgroups per CU.  WGN = 4: 256 x 256 tile, 16 waves in ONE workgroup per CU — the same four waves
+// per SIMD, a strip now feeds 256 output channels (half the A-side fill per flop again), and the waves split the issue work: waves 0-7
+// stage the strips (3 pieces each per strip), waves 8-15 the 256 x 32 B tiles (2 pieces each per sub-step), each group with its own
+// counted wait (vmcnt(0) once per strip / vmcnt(2) per sub-step).
+template <int WGN>
+__global__ __launch_bounds__(256 * WGN, 4) void conv_strip_kernel(GemmArgs p) {
+  constexpr int BN = 64 * WGN, KT = 32, WM = 64, WN = 64, FM = 2, FN = 2;
+  constexpr bool SPLIT = WGN == 4;                                   // issue roles split between wave groups
+  constexpr int NBP = SPLIT ? 2 : 1;                                 // B pieces per issuing wave and sub-step
   constexpr int ASZ = 384 * KT, BSZ = BN * KT;                       // elements per strip / B buffer
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * ASZ + 3 * BSZ];
   const int tid = threadIdx.x;
@@ -549,6 +556,9 @@ __global__ __launch_bounds__(512, 4) void conv_strip_kernel(GemmArgs p) {
   const int m0 = tile_y * 256, n0 = tile_x * BN;
   const int hw = p.Hin * p.Win;
   const int b = m0 / hw, rem = m0 - b * hw, y = rem / p.Win, x0 = rem - y * p.Win;
+  // the tile's 256 output pixels: one 256-pixel segment of an image row (W % 256 == 0), or 256 / W whole rows (W = 16 .. 128: x0 = 0).
+  // A strip = those rows of input row y + ky - 1 (+ ry), each widened by one pixel on both sides: SW = min(W, 256) + 2 strip rows per image row
+  const int segw = p.Win < 256 ? p.Win : 256, SW = segw + 2, nrows = 256 / segw;
   const int ncc = p.Cin / KT, nstrip = 3 * ncc, nsub = 3 * nstrip;
   constexpr unsigned OOB = 0xFFFF0000u;
   auto swz = [](int r) { return (r >> 2) & 3; };
@@ -557,32 +567,45 @@ __global__ __launch_bounds__(512, 4) void conv_strip_kernel(GemmArgs p) {
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
   // strip pieces of this wave: piece q = wave + 8 i covers strip rows 16 q .. 16 q + 15; strip row j = input pixel x0 - 1 + j
   unsigned a_vo[3];
+  int a_inv[3];                                  // bit ky set = this strip row reads padding (or nothing) for kernel row ky
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int j = 16 * (wave + 8 * i) + (lane >> 2), ix = x0 - 1 + j;
-    const bool ok = j < 258 && ix >= 0 && ix < p.Win;
-    a_vo[i] = ok ? (unsigned)((j * p.Cin + ((lane & 3) ^ swz(j)) * 8) * 2) : OOB;
+    const int j = 16 * (wave + 8 * i) + (lane >> 2);
+    const int ry = j / SW, xs = j - ry * SW, ix = x0 - 1 + xs;
+    const bool ok = ry < nrows && ix >= 0 && ix < p.Win;
+    a_vo[i] = (unsigned)(((ry * p.Win + xs) * p.Cin + ((lane & 3) ^ swz(j)) * 8) * 2);
+    int m = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ry + ky - 1;
+      if (!(ok && iy >= 0 && iy < p.Hin)) m |= 1 << ky;
+    }
+    a_inv[i] = m;
   }
-  unsigned b_vo;
-  {
-    const int r = 16 * wave + (lane >> 2);
-    b_vo = n0 + r < p.N ? (unsigned)((((size_t)(n0 + r)) * p.ldb + ((lane & 3) ^ swz(r)) * 8) * 2) : OOB;
+  const bool a_wave = !SPLIT || wave < 8, b_wave = !SPLIT || wave >= 8;      // (wave-uniform)
+  const int bw = SPLIT ? wave - 8 : wave;                                     // B pieces of this wave: NBP bw .. NBP bw + NBP - 1
+  unsigned b_vo[NBP];
+#pragma unroll
+  for (int i = 0; i < NBP; ++i) {
+    const int r = 16 * (NBP * bw + i) + (lane >> 2);
+    b_vo[i] = (b_wave && n0 + r < p.N) ? (unsigned)((((size_t)(n0 + r)) * p.ldb + ((lane & 3) ^ swz(r)) * 8) * 2) : OOB;
   }
   // walkers (incremental: no division per issue)
   int a_ky = 0, a_cc = 0;                        // next strip to issue
   int b_ky = 0, b_cc = 0, b_kx = 0;              // next B tile to issue
   auto issue_a = [&](bf16_t* buf) __attribute__((always_inline)) {
     const int iy = y + a_ky - 1;
-    const bool vy = iy >= 0 && iy < p.Hin;
     // ((b H + iy) W + x0 - 1) Cin + 32 cc, against the lowered base: + (W + 1) Cin  ->  ((b H + iy + 1) W + x0) Cin + 32 cc  >= 0
     const int so = __builtin_amdgcn_readfirstlane((int)(((((long long)b * p.Hin + iy + 1) * p.Win + x0) * p.Cin + a_cc * KT) * 2));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) buf_dma16(rs_a, vy ? a_vo[i] : OOB, so, buf + (wave + 8 * i) * 512);
+    for (int i = 0; i < 3; ++i)      // the lane's offset, or all-ones (out of range) where the strip row is padding for this kernel row
+      buf_dma16(rs_a, a_vo[i] | (unsigned)__builtin_amdgcn_sbfe(a_inv[i], (unsigned)a_ky, 1u), so, buf + (wave + 8 * i) * 512);
     if (++a_cc == ncc) { a_cc = 0; ++a_ky; }
   };
   auto issue_b = [&](bf16_t* buf) __attribute__((always_inline)) {
     const int so = __builtin_amdgcn_readfirstlane((((b_ky * 3 + b_kx) * p.Cin) + b_cc * KT) * 2);
-    buf_dma16(rs_b, b_vo, so, buf + wave * 512);
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) buf_dma16(rs_b, b_vo[i], so, buf + (NBP * bw + i) * 512);
     if (++b_kx == 3) { b_kx = 0; if (++b_cc == ncc) { b_cc = 0; ++b_ky; } }
   };
 
@@ -601,7 +624,8 @@ __global__ __launch_bounds__(512, 4) void conv_strip_kernel(GemmArgs p) {
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int r = wm * WM + i * 32 + frow + kx;
+        const int o = wm * WM + i * 32 + frow;                 // output pixel of the tile
+        const int r = (o / segw) * SW + o % segw + kx;         // its strip row for tap kx
         a_off[kx][i][ks] = r * KT + (((ks * 2 + fhi) ^ swz(r)) * 8);
       }
 #pragma unroll
@@ -611,19 +635,24 @@ __global__ __launch_bounds__(512, 4) void conv_strip_kernel(GemmArgs p) {
     }
   }
   bf16_t* const Bs = smem + 2 * ASZ;
-  issue_a(smem);                                 // strip 0
-  issue_b(Bs);                                   // B(0), B(1)
-  issue_b(Bs + BSZ);
+  if (a_wave) issue_a(smem);                     // strip 0
+  if (b_wave) { issue_b(Bs); issue_b(Bs + BSZ); }      // B(0), B(1)
 
   auto sub = [&](auto par_, auto kx_, int s) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_)::value, KX = decltype(kx_)::value;
     const int j = 3 * s + KX;
-    if (s + 1 == nstrip && KX > 0) wait_vmcnt<0>();          // the last strip: nothing (or one B tile) behind the one needed
-    else if (KX == 1) wait_vmcnt<4>();                        // strip s + 1 (3 pieces) and B(j + 1) may still fly
-    else wait_vmcnt<1>();                                     // B(j + 1) may
+    if (SPLIT) {
+      if (a_wave) { if (KX == 0) wait_vmcnt<0>(); }             // strip s (issued three sub-steps ago) is this wave's only traffic
+      else if (j + 1 == nsub) wait_vmcnt<0>();                  // the last B tile
+      else wait_vmcnt<2>();                                     // B(j + 1) may still fly
+    } else {
+      if (s + 1 == nstrip && KX > 0) wait_vmcnt<0>();          // the last strip: nothing (or one B tile) behind the one needed
+      else if (KX == 1) wait_vmcnt<4>();                        // strip s + 1 (3 pieces) and B(j + 1) may still fly
+      else wait_vmcnt<1>();                                     // B(j + 1) may
+    }
     loop_barrier();
-    if (KX == 0 && s + 1 < nstrip) issue_a(smem + (PAR ^ 1) * ASZ);
-    if (j + 2 < nsub) issue_b(Bs + ((KX + 2) % 3) * BSZ);
+    if (a_wave && KX == 0 && s + 1 < nstrip) issue_a(smem + (PAR ^ 1) * ASZ);
+    if (b_wave && j + 2 < nsub) issue_b(Bs + ((KX + 2) % 3) * BSZ);
     const bf16_t* sa = smem + PAR * ASZ;
     const bf16_t* sb = Bs + KX * BSZ;
     bf16x8 af[2][FM], bfr[2][FN];
@@ -650,12 +679,20 @@ __global__ __launch_bounds__(512, 4) void conv_strip_kernel(GemmArgs p) {
     if (s + 1 < nstrip) { sub(I1{}, I0{}, s + 1); sub(I1{}, I1{}, s + 1); sub(I1{}, I2{}, s + 1); }
   }
   __syncthreads();   // all fragment reads done before the epilogue reuses the LDS
-  write_tile<WM, WN, FM, FN, false>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
+  if constexpr (SPLIT) {     // 16 staging areas of a whole wave tile would not fit the operand buffers: two row halves (as the tall gemm_dma tiles do)
+    static_assert(4 * WGN * (WM / 2) * (WN + 8) <= 2 * ASZ + 3 * BSZ, "epilogue staging must fit");
+    write_tile<WM / 2, WN, FM / 2, FN, false>(p, *(f32x16(*)[FM / 2][FN])(acc + 0), wave_stage<WM / 2, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
+    __syncthreads();
+    write_tile<WM / 2, WN, FM / 2, FN, false>(p, *(f32x16(*)[FM / 2][FN])(acc + FM / 2), wave_stage<WM / 2, WN>(smem, wave), lane, m0 + wm * WM + WM / 2, n0 + wn * WN);
+  } else {
+    write_tile<WM, WN, FM, FN, false>(p, acc, wave_stage<WM, WN>(smem, wave), lane, m0 + wm * WM, n0 + wn * WN);
+  }
 }
-// may a 256 x 128 x 32 conv launch go to conv_strip_kernel?
+// may a 256 x 128 x 32 (WGN = 2) / 256 x 256 (WGN = 4, in place of the ping-pong kernel) conv launch go to conv_strip_kernel?
 static bool conv_strip_ok(const GemmArgs& p, int splitk, int batch) {
   static const bool on = CONV_STRIP && getenv("E4T_CONV_NOSTRIP") == nullptr;          // A/B switch
-  return on && p.mode == E4T_CONV_S1 && p.chan_major && splitk == 1 && batch == 1 && p.Win % 256 == 0 && p.Wout == p.Win && p.Hout == p.Hin &&
+  const bool rows = p.Win % 256 == 0 || (p.Win >= 16 && 256 % p.Win == 0 && p.Hin % (256 / p.Win) == 0);      // row segments, or whole rows per tile
+  return on && p.mode == E4T_CONV_S1 && p.chan_major && splitk == 1 && batch == 1 && rows && p.Wout == p.Win && p.Hout == p.Hin &&
          p.Cin % 32 == 0 && p.K == 9 * p.Cin;
 }
 
@@ -2139,6 +2176,14 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
         else if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_pp_kernel<0, true>), grid, block, 0, st, p);
       } else {
+#ifdef E4T_EXPERIMENTAL
+        // measured and rejected (round 6): the 16-wave 256 x 256 strip kernel EQUALS the ping-pong kernel on every conv shape of the step (1072 / 1007 /
+        // 526 / 254 / 126 us against 1046-1082 / 995-1011 / 515-531 / 253 / 125-128) although it fills a third of the A bytes — with 64 x 64 wave tiles
+        // it needs one fragment ds_read per MFMA, 125 B/clk/CU of LDS reads at the MFMA peak against the LDS's 128
+        static const bool strip256 = getenv("E4T_CONV_STRIP256") != nullptr && atoi(getenv("E4T_CONV_STRIP256")) != 0;
+        if (conv && strip256 && conv_strip_ok(p, splitk, batch)) hipLaunchKernelGGL(conv_strip_kernel<4>, grid, dim3(1024), 0, st, p);
+        else
+#endif
         if (conv && p.chan_major) hipLaunchKernelGGL((gemm_pp_kernel<1, false, true>), grid, block, 0, st, p);
         else if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_pp_kernel<0>), grid, block, 0, st, p);
@@ -2151,7 +2196,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
 #endif
     } else if (tile == 256 && kt32) {
       block = dim3(512);       // experimental (5256): 256 x 128 with 32-wide K-tiles, 3 x 24 KiB stages = two workgroups per CU
-      if (conv && conv_strip_ok(p, splitk, batch)) hipLaunchKernelGGL(conv_strip_kernel, grid, block, 0, st, p);
+      if (conv && conv_strip_ok(p, splitk, batch)) hipLaunchKernelGGL(conv_strip_kernel<2>, grid, block, 0, st, p);
       else if (conv) hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>), grid, block, 0, st, p);
 #ifdef E4T_EXPERIMENTAL

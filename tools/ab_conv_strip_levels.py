@@ -17,8 +17,8 @@ def graph_time(fns, iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / iters * 1e3)
     return min(ts)
-for B, H, Cin, Cout in [(16, 256, 128, 256), (16, 256, 256, 256), (16, 512, 128, 128)]:
-  for tile in (0, 5256):
+for B, H, Cin, Cout in [(16, 256, 128, 256), (16, 256, 256, 256), (16, 512, 128, 128), (16, 128, 512, 512), (16, 128, 256, 512), (16, 64, 512, 512), (16, 64, 320, 320), (16, 64, 640, 640), (16, 32, 640, 640), (16, 32, 1280, 1280), (16, 16, 1280, 1280)]:
+  for tile in ((0, 512) if os.environ.get('E4T_CONV_STRIP256') else (0, 5256)):
     xs = [r(B * H * H, Cin) for _ in range(2)]
     w = r(Cout, 9 * Cin) * (9 * Cin) ** -0.5
     outs = [torch.empty((B * H * H, Cout), dtype=bf16, device=dev) for _ in range(2)]
