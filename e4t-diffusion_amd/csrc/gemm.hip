@@ -1025,6 +1025,215 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_pp_kernel for stride-1 3x3 convs with the A operand staged as STRIPS (round 6; see conv_strip_kernel for the idea and the probe
+// behind it: a third of the A-side fill is worth 12-16 % to the ping-pong kernel on every conv shape of the step).
+//
+// Same machine — two groups of four waves alternating an LDS/DMA segment with an 8-MFMA segment, B quarters of 256 x 32 by LDS-DMA, the
+// channel-chunk-major K order (K-tile kt = chunk kt / 9, tap kt % 9) — but the three K-tiles kx = 0, 1, 2 of one kernel row read ONE strip:
+// the tile's 256 output pixels (a 256-pixel row segment, or 256 / W whole rows) of input row y + ky - 1, each image row widened by a pixel
+// on both sides, as two HALF-STRIPS (k 0-31 | 32-63 of the 64-channel chunk; <= 288 rows x 64 B, staged as 24 pieces = 3 per wave, rows
+// beyond the strip / outside the image fetch nothing).  The fragment of output pixel o for tap kx is strip row (o / w)(w + 2) + o % w + kx.
+//   * LDS: [strip parity][k half] 4 x 24 KB + [B buffer][k half] 4 x 16 KB = 160 KB — all of it;
+//   * issue stream per K-tile: ph0 B-hi(t + 1), ph2 B-lo(t + 2) as before; the A stream shrinks to the kx = 0 tile's ph1 (lo half of strip
+//     s + 1) and ph3 (hi half): 18 instead of 24 DMA instructions per wave and three K-tiles; a half-strip slot is re-staged >= 4 phases
+//     after its last read and first read >= 8 phases after its issue;
+//   * the counted wait keeps the ping-pong kernel's rule — after a phase's issue, at most the pieces of the LAST FOUR issue events may be
+//     outstanding — with the events' sizes now 2, 3 or 0 pieces: vmcnt(4, 7, 7, 10 | 10, 7, 7, 4 | 4, 4, 4, 4) over the 12 phases of a strip;
+//   * 6 K-tiles per loop body (tap shift, strip parity and B buffer are compile-time in every phase); the last tiles run the same phases
+//     with the "is there anything left to stage" decisions, draining the counter where an issue is skipped.
+// Requires: E4T_CONV_S1, chan_major, Cin % 64 == 0, W % 256 == 0 or (256 % W == 0, W >= 16, H % (256 / W) == 0), a K range per split that
+// starts and ends on a kernel row (ktiles_per_split % 3 == 0).  Results differ from gemm_pp_kernel's in nothing (same K order, same MFMAs).
+// ------------------------------------------------------------------------------------------------
+template <bool GENERAL>
+__global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, HK = 32;
+  constexpr int QUART = 256 * HK;                        // elements per B quarter
+  constexpr int HSTRIP = 384 * HK;                       // elements per half-strip (24 pieces)
+  constexpr int A_EL = 4 * HSTRIP;
+  constexpr int SMEM = A_EL + 4 * QUART;                 // 160 KB
+  static_assert(8 * 64 * (64 + 8) <= SMEM, "write_tile staging must fit");
+  __shared__ __attribute__((aligned(16))) bf16_t smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  int tile_x, tile_y;
+  xcd_tile(tile_x, tile_y, p.group_m);
+  const int m0 = tile_y * BM, n0 = tile_x * BN;
+
+  const int nkt = p.K / BK;
+  const int bz = blockIdx.z / p.splitk, sz = blockIdx.z - bz * p.splitk;
+  if (p.bias) p.bias += bz * p.strideBias;
+  if (!p.reduce_batch) {
+    if (p.flags & E4T_OUT_F32) p.C = (float*)p.C + bz * p.strideC;
+    else p.C = (bf16_t*)p.C + bz * p.strideC;
+  }
+  const int kt_begin = sz * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nkt) kt_end = nkt;
+
+  const int hw = p.Hin * p.Win;
+  const int ib = m0 / hw, rem = m0 - ib * hw, y = rem / p.Win, x0 = rem - y * p.Win;
+  const int segw = p.Win < 256 ? p.Win : 256, SW = segw + 2, nrows = 256 / segw;
+  const __amdgpu_buffer_rsrc_t rs_a = cm_rsrc(p);
+  const __amdgpu_buffer_rsrc_t rs_b = uniform_rsrc(p.B, p.b_bytes);
+  constexpr unsigned OOB = 0xFFFF0000u;
+  const int drow = lane >> 2, dslot = lane & 3;
+  // half-strip pieces of this wave: piece q = wave + 8 i = strip rows 16 q .. 16 q + 15
+  unsigned a_vo[3];
+  int a_inv[3];                                  // bit ky set = this strip row is padding (or no row at all) for kernel row ky
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = 16 * (wave + 8 * i) + drow;
+    const int ry = j / SW, xs = j - ry * SW, ix = x0 - 1 + xs;
+    const bool ok = ry < nrows && ix >= 0 && ix < p.Win && m0 < p.M;
+    a_vo[i] = (unsigned)(((ry * p.Win + xs) * p.Cin + (dslot ^ ((j >> 2) & 3)) * 8) * 2);
+    int m = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = y + ry + ky - 1;
+      if (!(ok && iy >= 0 && iy < p.Hin)) m |= 1 << ky;
+    }
+    a_inv[i] = m;
+  }
+  unsigned b_vo[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = wave * 32 + j * 16 + drow;
+    const int gn = n0 + r;
+    b_vo[j] = gn < p.N ? (unsigned)(((size_t)gn * p.ldb + (dslot ^ ((r >> 2) & 3)) * 8) * 2) : OOB;
+  }
+  CmWalk wb;                       // B stream: (tap, chunk) of the next K-tile to issue
+  wb.init(kt_begin, BK);
+  int b_so = 0;
+  int a_ky = (kt_begin % 9) / 3, a_chb = (kt_begin / 9) * BK * 2;       // A stream: kernel row and chunk byte offset of the next strip to issue
+  auto issue_b = [&](bool hi, bf16_t* dst) __attribute__((always_inline)) {
+    if (!hi) b_so = cm_b_so(p, wb);
+    else b_so = __builtin_amdgcn_readfirstlane(b_so + HK * 2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) buf_dma16(rs_b, b_vo[j], b_so, dst + (wave * 32 + j * 16) * HK);
+    if (hi) wb.next(BK);
+  };
+  auto issue_strip = [&](bool hi, bf16_t* dst) __attribute__((always_inline)) {
+    const int iy = y + a_ky - 1;
+    // pixel (iy, x0 - 1) of image ib against the lowered base (+ (W + 1) Cin elements): ((ib H + iy + 1) W + x0) Cin  >= 0
+    const int so = __builtin_amdgcn_readfirstlane((int)((((long long)ib * p.Hin + iy + 1) * p.Win + x0) * p.Cin * 2) + a_chb + (hi ? HK * 2 : 0));
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      buf_dma16(rs_a, a_vo[i] | (unsigned)__builtin_amdgcn_sbfe(a_inv[i], (unsigned)a_ky, 1u), so, dst + (wave + 8 * i) * 512);
+    if (hi && ++a_ky == 3) { a_ky = 0; a_chb += BK * 2; }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frow = lane & 31, fhi = lane >> 5;
+  int a_off[3][4][2], b_off[2][2];     // fragment offsets inside a half-strip (per tap shift) / a quarter (elements)
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = wr * 128 + i * 32 + frow;
+        const int r = (o / segw) * SW + o % segw + kx;
+        a_off[kx][i][ks] = r * HK + (((ks * 2 + fhi) ^ ((r >> 2) & 3)) * 8);
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = wc * 64 + j * 32 + frow;
+      b_off[j][ks] = r * HK + (((ks * 2 + fhi) ^ ((r >> 2) & 3)) * 8);
+    }
+  }
+  bf16_t* const Bq = smem + A_EL;      // B quarter (buffer bb, half kh) at Bq + (2 bb + kh) QUART; half-strip (parity sp, half kh) at smem + (2 sp + kh) HSTRIP
+  issue_strip(false, smem);
+  issue_strip(true, smem + HSTRIP);
+  issue_b(false, Bq);
+  issue_b(true, Bq + QUART);
+  if (kt_begin + 1 < kt_end) issue_b(false, Bq + 2 * QUART);
+  wait_vmcnt<0>();                 // (once per workgroup: the counted waits of the loop start from an empty queue)
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[2][2], bfr[2][2];
+  auto phase = [&](auto Bc, auto Pc, auto ALLc, auto KXc, auto SPc, int kt) {
+    constexpr int bb = decltype(Bc)::value, ph = decltype(Pc)::value, KX = decltype(KXc)::value, SP = decltype(SPc)::value;
+    constexpr bool ALL = decltype(ALLc)::value;      // steady state: everything this phase stages exists
+    constexpr int kh = ph >> 1, mh = ph & 1;
+    const bf16_t* const qa = smem + (2 * SP + kh) * HSTRIP;
+    const bf16_t* const qb = Bq + (2 * bb + kh) * QUART;
+    // ---- L segment ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *(const bf16x8*)(qa + a_off[KX][mh * 2 + i][ks]);
+    if (mh == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bfr[j][ks] = *(const bf16x8*)(qb + b_off[j][ks]);
+    }
+    bool staged = true;              // phases that issue nothing by design keep the pattern's count
+    if (ph == 0)      { staged = ALL || kt + 1 < kt_end; if (staged) issue_b(true, Bq + (2 * (bb ^ 1) + 1) * QUART); }
+    else if (ph == 2) { staged = ALL || kt + 2 < kt_end; if (staged) issue_b(false, Bq + (2 * bb + 0) * QUART); }
+    else if (KX == 0) { staged = ALL || kt + 3 < kt_end; if (staged) issue_strip(ph == 3, smem + (2 * (SP ^ 1) + kh) * HSTRIP); }
+    // at most the pieces of the last four issue events outstanding (2 per B quarter, 3 per half-strip, 0 where nothing is issued)
+    constexpr int NW_ = KX == 0 ? (ph == 0 ? 4 : ph == 3 ? 10 : 7) : KX == 1 ? (ph == 0 ? 10 : ph == 3 ? 4 : 7) : 4;
+    if (ALL || staged) wait_vmcnt<NW_>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M segment ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[mh * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ks], bfr[j][ks], acc[mh * 2 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+  // K-tile i of a 6-tile body: B buffer i & 1, tap shift i % 3, strip parity (i / 3) & 1
+  auto ktile = [&](auto Bc, auto KXc, auto SPc, auto ALLc, int kt) __attribute__((always_inline)) {
+    phase(Bc, I0{}, ALLc, KXc, SPc, kt); phase(Bc, I1{}, ALLc, KXc, SPc, kt); phase(Bc, I2{}, ALLc, KXc, SPc, kt); phase(Bc, I3{}, ALLc, KXc, SPc, kt);
+  };
+
+  if (wr == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one barrier interval behind group 0
+  {
+    using YES = std::true_type; using NO = std::false_type;
+    int kt = kt_begin;
+    for (; kt + 8 <= kt_end; kt += 6) {       // steady state: everything the six tiles stage (up to B-lo of tile kt + 7, the strip of kt + 6) exists
+      ktile(I0{}, I0{}, I0{}, YES{}, kt);     ktile(I1{}, I1{}, I0{}, YES{}, kt + 1); ktile(I0{}, I2{}, I0{}, YES{}, kt + 2);
+      ktile(I1{}, I0{}, I1{}, YES{}, kt + 3); ktile(I0{}, I1{}, I1{}, YES{}, kt + 4); ktile(I1{}, I2{}, I1{}, YES{}, kt + 5);
+    }
+    if (kt < kt_end) { ktile(I0{}, I0{}, I0{}, NO{}, kt); ktile(I1{}, I1{}, I0{}, NO{}, kt + 1); ktile(I0{}, I2{}, I0{}, NO{}, kt + 2); kt += 3; }
+    if (kt < kt_end) { ktile(I1{}, I0{}, I1{}, NO{}, kt); ktile(I0{}, I1{}, I1{}, NO{}, kt + 1); ktile(I1{}, I2{}, I1{}, NO{}, kt + 2); kt += 3; }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  __syncthreads();   // every fragment read and every DMA is done before the epilogue reuses the LDS
+  write_tile<64, 64, 2, 2, GENERAL>(p, *(f32x16(*)[2][2])(acc + 0), wave_stage<64, 64>(smem, wave), lane, m0 + wr * 128, n0 + wc * 64);
+  __syncthreads();
+  write_tile<64, 64, 2, 2, GENERAL>(p, *(f32x16(*)[2][2])(acc + 2), wave_stage<64, 64>(smem, wave), lane, m0 + wr * 128 + 64, n0 + wc * 64);
+}
+// may a 256 x 256 ping-pong conv launch go to gemm_pps_kernel?
+static bool conv_pps_ok(const GemmArgs& p, int batch) {
+  static const bool on = CONV_STRIP && getenv("E4T_CONV_NOSTRIP") == nullptr;          // A/B switch
+  const bool rows = p.Win % 256 == 0 || (p.Win >= 16 && 256 % p.Win == 0 && p.Hin % (256 / p.Win) == 0);
+  return on && p.mode == E4T_CONV_S1 && p.chan_major && batch == 1 && rows && p.Wout == p.Win && p.Hout == p.Hin && p.Cin % 64 == 0 &&
+         p.K == 9 * p.Cin && p.ktiles_per_split % 3 == 0 && p.M % 256 == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // 256 x 320 ping-pong, phases = (k half) x (16-wide k step)      [round 3; the template also builds BN = 256, measured = gemm_pp_kernel]
 //
 // The same machine as gemm_pp_kernel — two groups of four waves alternating an LDS/DMA segment with an MFMA segment, operand
@@ -2126,6 +2335,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
     if (p.residual) by += ((p.flags & E4T_RES_F32) ? 4.0 : 2.0) * (double)p.M * p.N;
     if (p.flags & E4T_ACCUM) by += osz * (double)p.M * p.N;
     const char* sym = !(use_dma && buf_ok) ? "gemm_kernel"
+                      : tile == 512 && conv && conv_pps_ok(p, batch) ? (general_epi ? "gemm_pps_kernel<true>" : "gemm_pps_kernel<false>")
                       : tile == 512 ? (general_epi ? (conv ? (p.chan_major ? "gemm_pp_kernel<1, true, true>" : "gemm_pp_kernel<1, true, false>") : "gemm_pp_kernel<0, true, false>")
                                                    : (conv ? (p.chan_major ? "gemm_pp_kernel<1, false, true>" : "gemm_pp_kernel<1, false, false>") : "gemm_pp_kernel<0, false, false>"))
                       : tile == 640 ? (conv ? "gemm_pt_kernel<1>" : "gemm_pt_kernel<0>")
@@ -2171,7 +2381,10 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
 #endif
     } else if (tile == 512) {
       block = dim3(512);
-      if (general_epi) {
+      if (conv && conv_pps_ok(p, batch)) {
+        if (general_epi) hipLaunchKernelGGL((gemm_pps_kernel<true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gemm_pps_kernel<false>), grid, block, 0, st, p);
+      } else if (general_epi) {
         if (conv && p.chan_major) hipLaunchKernelGGL((gemm_pp_kernel<1, true, true>), grid, block, 0, st, p);
         else if (conv) hipLaunchKernelGGL((gemm_pp_kernel<1, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gemm_pp_kernel<0, true>), grid, block, 0, st, p);

@@ -11,7 +11,7 @@ rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() +
 bad = 0
 for B, H, W, Cin, Cout, tile in ([(2, 512, 512, 128, 128, 0), (1, 9, 256, 64, 128, 5256), (2, 5, 512, 64, 256, 5256), (3, 3, 768, 192, 128, 5256), (1, 1, 256, 64, 128, 5256), (2, 64, 256, 128, 256, 5256), (3, 16, 16, 64, 128, 5256), (2, 32, 32, 128, 256, 5256), (2, 64, 64, 64, 320, 5256), (1, 8, 128, 64, 128, 5256), (5, 16, 64, 128, 128, 5256)]
          + ([(2, 64, 256, 128, 256, 512), (3, 16, 16, 64, 256, 512), (2, 32, 32, 128, 512, 512), (2, 64, 64, 64, 320, 512), (1, 8, 128, 64, 128, 512), (1, 4, 512, 128, 384, 512)]
-            if os.environ.get('E4T_CONV_STRIP256') else [])):      # (experimental build: the 16-wave 256 x 256 variant in place of the ping-pong kernel)
+            if True else [])):      # (experimental build: the 16-wave 256 x 256 variant in place of the ping-pong kernel)
     x = (torch.randn(B * H * W, Cin, device=dev) * 0.5).to(bf16)
     w = (torch.randn(Cout, 9 * Cin, device=dev) * (9 * Cin) ** -0.5).to(bf16)
     bias = torch.randn(Cout, device=dev)
