@@ -231,6 +231,9 @@ def check_conv(hip, emu, dev):
         # segments per row, one-row images, Cout beyond one column tile, batch crossing
         (2, 6, 256, 64, 128, CONV_S1, 6, 256, 5256, 1), (1, 3, 768, 192, 256, CONV_S1, 3, 768, 5256, 1), (3, 1, 256, 64, 128, CONV_S1, 1, 256, 5256, 1),
         (2, 5, 512, 128, 128, CONV_S1, 5, 512, 0, 0),
+        # ... and gemm_pps_kernel (the ping-pong kernel on half-strips): whole-row tiles W = 16 / 64, row segments W = 256 / 512, split-K on kernel-row boundaries
+        (2, 64, 64, 64, 256, CONV_S1, 64, 64, 512, 1), (1, 4, 256, 128, 320, CONV_S1, 4, 256, 512, 1), (1, 2, 512, 64, 256, CONV_S1, 2, 512, 512, 1),
+        (2, 16, 16, 192, 256, CONV_S1, 16, 16, 512, 3), (3, 128, 128, 64, 128, CONV_S1, 128, 128, 512, 1),
     ]
     for i, (B, Hin, Win, Cin, Cout, mode, Hout, Wout, tile, sk) in enumerate(cases):
         if not _product_tile(hip, tile):
