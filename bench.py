@@ -286,9 +286,11 @@ def main():
         names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, *, false, 64>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, *, false, 64>",
                  "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, *, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, *, false, 64>",
                  "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, *, false, 64>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, *, false, 64>",
-                 "conv512": "gemm_pp_kernel<1, false, true>", "gemm512": "gemm_pp_kernel<0, false, false>", "gemm_tn": "gemm_tn_kernel",
+                 # (round 6: the stride-1 convs of the 256 x 256 plan run gemm_pps_kernel — 40 of the 45 launches per step; stride-2 / upsampling
+                 # convs stay on gemm_pp_kernel<1, false, false>; the 256 x 128 x 32 plan's stride-1 convs run conv_strip_kernel<2>)
+                 "conv512": "gemm_pps_kernel<false>", "gemm512": "gemm_pp_kernel<0, false, false>", "gemm_tn": "gemm_tn_kernel",
                  "conv2320": "gemm_pq_kernel<1, 320, false>", "gemm2320": "gemm_pq_kernel<0, 320, false>",
-                 "conv5256": "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>", "gemm5256": "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>",
+                 "conv5256": "conv_strip_kernel<2>", "gemm5256": "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>",
                  "gn_fwd_colstats": "gn_stats_cols_kernel + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",
                  "gn_fwd_2pass": "gn_stats_kernel<*> + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",
                  "gn_bwd": "gn_bwd_stats_kernel<*> + gn_bwd_apply_kernel<*>",      # (small maps: gn_slab_bwd_kernel<*>)
