@@ -2340,7 +2340,7 @@ int launch_gemm(GemmArgs p, bool conv, int tile_hint, size_t ws_bytes, int split
                                                    : (conv ? (p.chan_major ? "gemm_pp_kernel<1, false, true>" : "gemm_pp_kernel<1, false, false>") : "gemm_pp_kernel<0, false, false>"))
                       : tile == 640 ? (conv ? "gemm_pt_kernel<1>" : "gemm_pt_kernel<0>")
                       : tile == 256 && !kt32 ? (conv ? "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 64>" : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 64>")
-                      : tile == 256 ? (conv ? (conv_strip_ok(p, splitk, batch) ? "conv_strip_kernel" : "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>")
+                      : tile == 256 ? (conv ? (conv_strip_ok(p, splitk, batch) ? "conv_strip_kernel<2>" : "gemm_dma_kernel<256, 128, 4, 2, 1, 3, false, 32>")
                                             : "gemm_dma_kernel<256, 128, 4, 2, 0, 3, false, 32>")
                       : nullptr;
     char symbuf[64];
