@@ -1034,16 +1034,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs p) {
 // on both sides, as two HALF-STRIPS (k 0-31 | 32-63 of the 64-channel chunk; <= 288 rows x 64 B, staged as 24 pieces = 3 per wave, rows
 // beyond the strip / outside the image fetch nothing).  The fragment of output pixel o for tap kx is strip row (o / w)(w + 2) + o % w + kx.
 //   * LDS: [strip parity][k half] 4 x 24 KB + [B buffer][k half] 4 x 16 KB = 160 KB — all of it;
-//   * issue stream per K-tile: ph0 B-hi(t + 1), ph2 B-lo(t + 2) as before; the A stream shrinks to the kx = 0 tile's ph1 (lo half of strip
-//     s + 1) and ph3 (hi half): 18 instead of 24 DMA instructions per wave and three K-tiles; a half-strip slot is re-staged >= 4 phases
-//     after its last read and first read >= 8 phases after its issue;
+//   * issue stream per K-tile: ph0 B-hi(t + 1), ph2 B-lo(t + 2) as before; the A stream shrinks to ONE piece of each half of strip s + 1 in
+//     phases g = 1, 3, 5 of the strip's twelve (g = 4 kx + ph): 18 instead of 24 DMA instructions per wave and three K-tiles, two per phase like
+//     the B events beside them (issued as two bursts of three in g = 1 / 3 the kernel measured 1-2 % slower: the long L segment makes the other
+//     wave group wait); a half-strip slot is re-staged >= 2 phases after its last read and first read >= 7 phases after its last piece's issue;
 //   * the counted wait keeps the ping-pong kernel's rule — after a phase's issue, at most the pieces of the LAST FOUR issue events may be
-//     outstanding — with the events' sizes now 2, 3 or 0 pieces: vmcnt(4, 7, 7, 10 | 10, 7, 7, 4 | 4, 4, 4, 4) over the 12 phases of a strip;
+//     outstanding — with events of 2 or 0 pieces: vmcnt(4, 6, 6, 8 | 8, 8, 8, 6 | 6, 4, 4, 4) over the 12 phases of a strip;
 //   * 6 K-tiles per loop body (tap shift, strip parity and B buffer are compile-time in every phase); the last tiles run the same phases
 //     with the "is there anything left to stage" decisions, draining the counter where an issue is skipped.
 // Requires: E4T_CONV_S1, chan_major, Cin % 64 == 0, W % 256 == 0 or (256 % W == 0, W >= 16, H % (256 / W) == 0), a K range per split that
 // starts and ends on a kernel row (ktiles_per_split % 3 == 0).  Results differ from gemm_pp_kernel's in nothing (same K order, same MFMAs).
 // ------------------------------------------------------------------------------------------------
+#ifndef PPS_SPREAD
+#define PPS_SPREAD 1      // 1: the next strip goes out one piece of each half per phase g = 1, 3, 5 (0: both halves as bursts of three in g = 1 / 3 — 1-2 % slower)
+#endif
 template <bool GENERAL>
 __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p) {
   constexpr int BM = 256, BN = 256, HK = 32;
@@ -1123,6 +1127,16 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p) {
       buf_dma16(rs_a, a_vo[i] | (unsigned)__builtin_amdgcn_sbfe(a_inv[i], (unsigned)a_ky, 1u), so, dst + (wave + 8 * i) * 512);
     if (hi && ++a_ky == 3) { a_ky = 0; a_chb += BK * 2; }
   };
+  // PPS_SPREAD: piece i of BOTH halves of the next strip per call (three calls per strip, in phase 1 of the kx = 0, 1, 2 tiles... see phase())
+  auto issue_strip_piece = [&](auto Ic, bool last, bf16_t* dst_lo) __attribute__((always_inline)) {
+    constexpr int i = decltype(Ic)::value;
+    const int iy = y + a_ky - 1;
+    const int so = __builtin_amdgcn_readfirstlane((int)((((long long)ib * p.Hin + iy + 1) * p.Win + x0) * p.Cin * 2) + a_chb);
+    const unsigned vo = a_vo[i] | (unsigned)__builtin_amdgcn_sbfe(a_inv[i], (unsigned)a_ky, 1u);
+    buf_dma16(rs_a, vo, so, dst_lo + (wave + 8 * i) * 512);
+    buf_dma16(rs_a, vo, so + HK * 2, dst_lo + HSTRIP + (wave + 8 * i) * 512);
+    if (last && ++a_ky == 3) { a_ky = 0; a_chb += BK * 2; }
+  };
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -1160,6 +1174,8 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p) {
   __builtin_amdgcn_s_barrier();
 
   bf16x8 af[2][2], bfr[2][2];
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   auto phase = [&](auto Bc, auto Pc, auto ALLc, auto KXc, auto SPc, int kt) {
     constexpr int bb = decltype(Bc)::value, ph = decltype(Pc)::value, KX = decltype(KXc)::value, SP = decltype(SPc)::value;
     constexpr bool ALL = decltype(ALLc)::value;      // steady state: everything this phase stages exists
@@ -1180,9 +1196,18 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p) {
     bool staged = true;              // phases that issue nothing by design keep the pattern's count
     if (ph == 0)      { staged = ALL || kt + 1 < kt_end; if (staged) issue_b(true, Bq + (2 * (bb ^ 1) + 1) * QUART); }
     else if (ph == 2) { staged = ALL || kt + 2 < kt_end; if (staged) issue_b(false, Bq + (2 * bb + 0) * QUART); }
+#if PPS_SPREAD
+    // one piece of each half of the next strip in phases g = 1, 3, 5 of the strip's twelve (both halves land >= 5 events before their first read at g = 12 / 14)
+    else if (4 * KX + ph == 1) { staged = ALL || kt + 3 < kt_end; if (staged) issue_strip_piece(I0{}, false, smem + 2 * (SP ^ 1) * HSTRIP); }
+    else if (4 * KX + ph == 3) { staged = ALL || kt + 3 < kt_end; if (staged) issue_strip_piece(I1{}, false, smem + 2 * (SP ^ 1) * HSTRIP); }
+    else if (4 * KX + ph == 5) { staged = ALL || kt + 2 < kt_end; if (staged) issue_strip_piece(I2{}, true, smem + 2 * (SP ^ 1) * HSTRIP); }
+    constexpr int G_ = 4 * KX + ph;
+    constexpr int NW_ = G_ == 0 ? 4 : G_ <= 2 ? 6 : G_ <= 6 ? 8 : G_ <= 8 ? 6 : 4;
+#else
     else if (KX == 0) { staged = ALL || kt + 3 < kt_end; if (staged) issue_strip(ph == 3, smem + (2 * (SP ^ 1) + kh) * HSTRIP); }
     // at most the pieces of the last four issue events outstanding (2 per B quarter, 3 per half-strip, 0 where nothing is issued)
     constexpr int NW_ = KX == 0 ? (ph == 0 ? 4 : ph == 3 ? 10 : 7) : KX == 1 ? (ph == 0 ? 10 : ph == 3 ? 4 : 7) : 4;
+#endif
     if (ALL || staged) wait_vmcnt<NW_>(); else wait_vmcnt<0>();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -1201,8 +1226,6 @@ __global__ __launch_bounds__(512) void gemm_pps_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
   // K-tile i of a 6-tile body: B buffer i & 1, tap shift i % 3, strip parity (i / 3) & 1
   auto ktile = [&](auto Bc, auto KXc, auto SPc, auto ALLc, int kt) __attribute__((always_inline)) {
     phase(Bc, I0{}, ALLc, KXc, SPc, kt); phase(Bc, I1{}, ALLc, KXc, SPc, kt); phase(Bc, I2{}, ALLc, KXc, SPc, kt); phase(Bc, I3{}, ALLc, KXc, SPc, kt);
