@@ -282,10 +282,13 @@ def main():
         # summary of its own command under profiles/
         agg_timed, agg = aggregate(hip.prof), aggregate(prof_alone)
         hip.prof = None
-        # (the 64 / 128 / 160 tiles run with 2 - 4 LDS stages, chosen per launch by the planner: `*` in the stages slot)
-        names = {"conv128": "gemm_dma_kernel<128, 128, 4, 2, 1, *, false, 64>", "conv160": "gemm_dma_kernel<128, 160, 4, 1, 1, *, false, 64>",
-                 "conv64": "gemm_dma_kernel<64, 64, 2, 2, 1, *, false, 64>", "gemm128": "gemm_dma_kernel<128, 128, 4, 2, 0, *, false, 64>",
-                 "gemm160": "gemm_dma_kernel<128, 160, 4, 1, 0, *, false, 64>", "gemm64": "gemm_dma_kernel<64, 64, 2, 2, 0, *, false, 64>",
+        # op label = kernel symbol: the 64 / 128 / 160 tiles carry their LDS stage count (e4t_gemm_plan_t.stages), a template argument of the symbol
+        names = {}
+        for t_, (bm_, wgm_, wgn_) in {64: (64, 2, 2), 128: (128, 4, 2), 160: (128, 4, 1)}.items():
+            for st_ in (2, 3, 4):
+                names[f"conv{t_}s{st_}"] = f"gemm_dma_kernel<{bm_}, {t_}, {wgm_}, {wgn_}, 1, {st_}, false, 64>"
+                names[f"gemm{t_}s{st_}"] = f"gemm_dma_kernel<{bm_}, {t_}, {wgm_}, {wgn_}, 0, {st_}, false, 64>"
+        names.update({
                  # (round 6: the stride-1 convs of the 256 x 256 plan run gemm_pps_kernel — 40 of the 45 launches per step; stride-2 / upsampling
                  # convs stay on gemm_pp_kernel<1, false, false>; the 256 x 128 x 32 plan's stride-1 convs run conv_strip_kernel<2>)
                  "conv512": "gemm_pps_kernel<false>", "gemm512": "gemm_pp_kernel<0, false, false>", "gemm_tn": "gemm_tn_kernel",
@@ -295,7 +298,7 @@ def main():
                  "gn_fwd_2pass": "gn_stats_kernel<*> + gn_apply_kernel<true, *> (small maps: gn_slab_fwd_kernel<*>)",
                  "gn_bwd": "gn_bwd_stats_kernel<*> + gn_bwd_apply_kernel<*>",      # (small maps: gn_slab_bwd_kernel<*>)
                  "ln_fwd": "ln_fwd_kernel<*>", "ln_bwd": "ln_bwd_kernel<*>",
-                 "geglu_fwd": "geglu_fwd_kernel", "geglu_bwd": "geglu_bwd_kernel", "adamw": "adamw_kernel"}
+                 "geglu_fwd": "geglu_fwd_kernel", "geglu_bwd": "geglu_bwd_kernel", "adamw": "adamw_kernel"})
         # HBM bytes per launch of each kernel symbol from the TCC counters: collected offline with tools/profile_round.sh on this
         # very command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 on gfx950 as
         # MI355X_MICROARCH.md prescribes; check: adamw_kernel = 28 B x parameters) -> profiles/rNN_pmc_traffic.csv, whose header

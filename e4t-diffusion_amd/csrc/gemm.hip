@@ -2557,7 +2557,7 @@ int tn_splitk(int M, int N, int K, int req) {
 void export_plan(const GemmPlan& pl, const GemmArgs& p, int batch, e4t_gemm_plan_t* out, int tail = 0) {
   out->tile = pl.kt32 ? 5000 + pl.tile : pl.tile; out->tile_m = pl.tm; out->tile_n = pl.tn; out->splitk = pl.splitk;
   out->workspace_bytes = plan_workspace_bytes(pl, p, batch);
-  out->tail_rows = tail; out->reserved = 0;
+  out->tail_rows = tail; out->stages = (!pl.kt32 && (pl.tile == 64 || pl.tile == 128 || pl.tile == 160)) ? pl.stages : 0;
 }
 
 }  // namespace
@@ -2583,7 +2583,7 @@ extern "C" int e4t_conv3x3_plan(const e4t_conv_desc* d, e4t_gemm_plan_t* out) {
 
 extern "C" int e4t_gemm_tn_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out) {
   E4T_REQUIRE(d && out && d->M > 0 && d->N > 0 && d->K > 0, "gemm_tn_plan: bad arguments");
-  out->tile = 128; out->tile_m = out->tile_n = 128; out->tail_rows = out->reserved = 0;
+  out->tile = 128; out->tile_m = out->tile_n = 128; out->tail_rows = out->stages = 0;
   out->splitk = tn_splitk(d->M, d->N, d->K, d->splitk);
   out->workspace_bytes = out->splitk > 1 ? (size_t)out->splitk * d->M * d->N * sizeof(float) : 0;
   return 0;

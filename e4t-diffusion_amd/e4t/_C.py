@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
 
 class GemmPlan(C.Structure):
     """e4t_gemm_plan_t: what the launcher will run for a descriptor (tile code, tile dims, split-K, workspace it wants)"""
-    _fields_ = [("tile", i32), ("tile_m", i32), ("tile_n", i32), ("splitk", i32), ("workspace_bytes", sz), ("tail_rows", i32), ("reserved", i32)]
+    _fields_ = [("tile", i32), ("tile_m", i32), ("tile_n", i32), ("splitk", i32), ("workspace_bytes", sz), ("tail_rows", i32), ("stages", i32)]
 
 
 class WODesc(C.Structure):

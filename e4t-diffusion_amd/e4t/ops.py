@@ -226,7 +226,7 @@ class HipBackend:
         # algorithmic bytes: A, B once; C once (+ once more when read: residual / accumulate)
         nbytes = lambda: (2.0 * nb * M * K + 2.0 * N * K * (nb if sB else 1) + out.element_size() * M * N * (1 if reduce_batch else nb) * (2 if accum else 1)
                           + (residual.element_size() * M * N if residual is not None else 0))
-        rc = self._timed(f"gemm{pl.tile}", 2.0 * M * N * K * nb,
+        rc = self._timed(f"gemm{pl.tile}" + (f"s{pl.stages}" if pl.stages else ""), 2.0 * M * N * K * nb,
                          lambda: _C.check(self.lib.e4t_gemm_nt(C.byref(d), st), "e4t_gemm_nt"), nbytes)
         if cs is not None and rc == 1:
             out._e4t_colstats = cs          # consumed by groupnorm_fwd (the GroupNorm of this activation skips its statistics pass)
@@ -285,7 +285,7 @@ class HipBackend:
         # algorithmic bytes: the input map once (not once per tap), the weights once, the output once (+ residual)
         nbytes = 2.0 * B * Hin * Win * Cin + 2.0 * Cout * 9 * Cin + out.element_size() * M * Cout * (2 if accum else 1) + \
             (residual.element_size() * M * Cout if residual is not None else 0)
-        rc = self._timed(f"conv{pl.tile}", 2.0 * M * Cout * 9 * Cin,
+        rc = self._timed(f"conv{pl.tile}" + (f"s{pl.stages}" if pl.stages else ""), 2.0 * M * Cout * 9 * Cin,
                          lambda: _C.check(self.lib.e4t_conv3x3(C.byref(d), st), "e4t_conv3x3"), nbytes)
         if cs is not None and rc == 1:
             out._e4t_colstats = cs

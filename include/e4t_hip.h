@@ -135,7 +135,9 @@ typedef struct {
    * token rows, [3P] open_clip via e4t/encoder.py:154) are computed by a tail stage at the end of the same launch and the tile, split-K and
    * workspace above are those of the first M - tail_rows rows (gemm.hip: plan_gemm_tail) */
   int tail_rows;
-  int reserved;
+  /* LDS stages (2 - 4) of the 64 / 128 / 160 tiles — a template argument of the kernel symbol the launch will show in a trace (round 6; the field was
+   * `reserved` before); 0 for every other tile */
+  int stages;
 } e4t_gemm_plan_t;
 int e4t_gemm_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out);
 int e4t_gemm_tn_plan(const e4t_gemm_desc* d, e4t_gemm_plan_t* out);
